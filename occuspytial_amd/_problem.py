@@ -1,0 +1,125 @@
+"""Host-side flattening of the sampler inputs into the plain arrays the C ABI takes.
+
+The reference keeps ``W`` and ``y`` as ``Dict[int, ndarray]`` behind the Cython ``Data`` class
+(``data.pyx:34-147``) and gathers/concatenates per-site blocks on every iteration
+(``gibbs/logit.py:187-189, 221``).  Here the ragged per-site blocks are laid out ONCE as a flat
+``(R, q)`` matrix plus a ``site_ptr`` offset array (surveyed sites in dict order, exactly the order
+``Data.surveyed`` reports), and ``Q`` becomes CSR with sorted column indices.  Set-up only; numpy
+and scipy are used here and nowhere on the per-iteration path.
+"""
+import numpy as np
+from scipy import sparse
+
+MAX_COVARIATES = 8  # compile-time limit of the register-resident p x p / q x q accumulators
+
+
+class FlatProblem:
+    """Plain-array view of ``(Q, W, X, y, hparams)``.
+
+    Index sets follow ``gibbs/base.py:112-152``: ``obs_site[s]`` says whether surveyed site ``s``
+    had any detection; sites without one are the reference's ``not_obs``; sites absent from ``W`` are
+    ``not_surveyed``.
+    """
+
+    def __init__(self, Q, W, X, y, hparams=None, check_singular=True):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError('X must be a 2-D array')
+        self.n, self.p = X.shape
+        self.X = X
+
+        Qc = sparse.csr_matrix(Q).astype(np.float64)
+        Qc.sum_duplicates()
+        Qc.sort_indices()
+        if Qc.shape != (self.n, self.n):
+            raise ValueError('Q must be n x n with n = X.shape[0]')
+        if check_singular:
+            _verify_spatial_precision(Qc)
+        self.Q = Qc
+
+        if list(W.keys()) != list(y.keys()):
+            if set(W.keys()) != set(y.keys()):
+                raise ValueError('W and y must describe the same surveyed sites')
+        sites = list(W.keys())
+        self.S = len(sites)
+        self.site_id = np.asarray(sites, dtype=np.int64)
+        if self.S and (self.site_id.min() < 0 or self.site_id.max() >= self.n):
+            raise ValueError('site numbers must lie in [0, n)')
+        visits = np.array([np.asarray(W[s]).shape[0] for s in sites], dtype=np.int64)
+        self.site_ptr = np.zeros(self.S + 1, dtype=np.int64)
+        np.cumsum(visits, out=self.site_ptr[1:])
+        self.R = int(self.site_ptr[-1])
+        first = np.asarray(W[sites[0]])
+        self.q = first.shape[1] if first.ndim == 2 else 1
+        self.W = np.ascontiguousarray(
+            np.concatenate([np.asarray(W[s], dtype=np.float64).reshape(-1, self.q) for s in sites]))
+        self.y = np.ascontiguousarray(
+            np.concatenate([np.asarray(y[s], dtype=np.float64).ravel() for s in sites]))
+        if self.y.size != self.R:
+            raise ValueError('y and W disagree on the number of visits')
+        if self.p > MAX_COVARIATES or self.q > MAX_COVARIATES:
+            raise ValueError(f'at most {MAX_COVARIATES} occupancy and {MAX_COVARIATES} detection covariates are supported')
+
+        # gibbs/base.py:113-137
+        seg_any = np.add.reduceat(self.y != 0, self.site_ptr[:-1]) > 0 if self.R else np.zeros(0, bool)
+        seg_any = np.where(visits > 0, seg_any, False)
+        self.obs_site = seg_any.astype(np.uint8)
+        self.surveyed = sites
+        surveyed_mask = np.zeros(self.n, dtype=bool)
+        surveyed_mask[self.site_id] = True
+        self.not_surveyed = np.flatnonzero(~surveyed_mask).tolist()
+        self.obs = [s for s, o in zip(sites, self.obs_site) if o]
+        self.not_obs = [s for s, o in zip(sites, self.obs_site) if not o]
+        self.z0 = np.ones(self.n)
+        self.z0[self.site_id] = self.obs_site
+
+        self._set_hyperparams(hparams)
+
+    def _set_hyperparams(self, hparams):
+        # defaults: gibbs/base.py:177-186
+        hp = {
+            'tau_rate': 0.005,
+            'tau_shape': 0.5 + 0.5 * (self.n - 1),
+            'a_mu': np.zeros(self.q),
+            'a_prec': np.eye(self.q) / 10,
+            'b_mu': np.zeros(self.p),
+            'b_prec': np.eye(self.p) / 10,
+        }
+        if hparams:
+            # the reference sets user keys verbatim and nothing else (base.py:154-157, 172-175):
+            # a partial dict there fails later with AttributeError; defaults fill the gaps here.
+            hp.update(hparams)
+        self.hparams = hp
+        self.tau_rate = float(hp['tau_rate'])
+        self.tau_shape = float(hp['tau_shape'])
+        self.a_mu = np.ascontiguousarray(hp['a_mu'], dtype=np.float64)
+        self.a_prec = np.ascontiguousarray(hp['a_prec'], dtype=np.float64)
+        self.b_mu = np.ascontiguousarray(hp['b_mu'], dtype=np.float64)
+        self.b_prec = np.ascontiguousarray(hp['b_prec'], dtype=np.float64)
+        if self.a_mu.shape != (self.q,) or self.a_prec.shape != (self.q, self.q):
+            raise ValueError('a_mu / a_prec do not match the number of detection covariates')
+        if self.b_mu.shape != (self.p,) or self.b_prec.shape != (self.p, self.p):
+            raise ValueError('b_mu / b_prec do not match the number of occupancy covariates')
+        if not (self.tau_shape > 0 and self.tau_rate > 0):
+            raise ValueError('tau_shape and tau_rate must be positive')
+
+
+def _verify_spatial_precision(Q):
+    """ICAR precision check: ``Q 1 = 0``, symmetric, non-positive off-diagonals.
+
+    Replaces the reference's shift-invert ``eigsh`` test (``gibbs/base.py:166-170``), which rejects
+    valid lattices from 100 columns up (lambda_2 of a 100-wide rook lattice is 9.9e-4, below its
+    shift) and costs a sparse factorisation.  For an ICAR precision ``D - W`` the zero row sums ARE
+    the singularity, so the test is exact; the exception text is the reference's.
+    """
+    scale = abs(Q).sum(axis=1).max() if Q.nnz else 0.0
+    rowsum = np.abs(np.asarray(Q.sum(axis=1)).ravel()).max() if Q.nnz else 1.0
+    if not (scale > 0) or rowsum > 1e-10 * scale:
+        raise ValueError('Spatial precision matrix Q must be singular.')
+    asym = abs(Q - Q.T)
+    if asym.nnz and asym.max() > 1e-12 * scale:
+        raise ValueError('Spatial precision matrix Q must be symmetric.')
+    off = Q - sparse.diags(Q.diagonal())
+    if off.nnz and off.max() > 0:
+        raise ValueError('Spatial precision matrix Q must have non-positive off-diagonal entries '
+                         '(Q = D - W with non-negative weights W).')

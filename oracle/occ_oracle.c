@@ -1,0 +1,812 @@
+/*
+ * occ_oracle.c -- CPU restatement of the reference's LogitICARGibbs inner loop (see occ_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: never shipped, never on the product path.
+ *
+ * Sequential, one chain, plain CSR, plain loops.  Each function cites the reference lines it
+ * follows (paths relative to /root/reference/occuspytial/).
+ */
+#define _GNU_SOURCE
+#include "occ_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_SQRT1_2
+#define M_SQRT1_2 0.70710678118654752440
+#endif
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ================================================================================================
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011, "Parallel random numbers: as easy as 1, 2, 3")
+ * ================================================================================================ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void philox_words(uint64_t key, uint32_t c0, uint32_t c1, uint32_t iter, uint32_t stream,
+                         uint64_t w[2])
+{
+    uint32_t ctr[4] = {c0, c1, iter, stream};
+    uint32_t k[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+    uint32_t o[4];
+    orc_philox4x32_10(ctr, k, o);
+    w[0] = ((uint64_t)o[1] << 32) | o[0];
+    w[1] = ((uint64_t)o[3] << 32) | o[2];
+}
+
+/* 52 random bits, centred: (k + 1/2) 2^-52, k in [0, 2^52) -- exactly representable, never 0 or 1 */
+double orc_u01(uint64_t w) { return ((double)(w >> 12) + 0.5) * 0x1.0p-52; }
+
+static double box_muller(const uint64_t w[2])
+{
+    double u1 = orc_u01(w[0]), u2 = orc_u01(w[1]);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+double orc_block_normal(uint64_t key, uint32_t c0, uint32_t c1, uint32_t iter, uint32_t stream)
+{
+    uint64_t w[2];
+    philox_words(key, c0, c1, iter, stream, w);
+    return box_muller(w);
+}
+
+double orc_block_uniform(uint64_t key, uint32_t c0, uint32_t c1, uint32_t iter, uint32_t stream)
+{
+    uint64_t w[2];
+    philox_words(key, c0, c1, iter, stream, w);
+    return orc_u01(w[0]);
+}
+
+/* sequential cursor over the sub-stream (index, iter, stream): words are handed out one at a time,
+ * two per Philox block; a normal always takes a fresh block and drops a pending half block. */
+typedef struct {
+    uint64_t key;
+    uint32_t index, iter, stream, sub;
+    int have;
+    uint64_t cached;
+} cursor_t;
+
+static cursor_t cursor_open(uint64_t key, uint32_t index, uint32_t iter, uint32_t stream)
+{
+    cursor_t c = {key, index, iter, stream, 0, 0, 0};
+    return c;
+}
+static uint64_t cur_word(cursor_t *c)
+{
+    if (c->have) { c->have = 0; return c->cached; }
+    uint64_t w[2];
+    philox_words(c->key, c->index, c->sub++, c->iter, c->stream, w);
+    c->cached = w[1];
+    c->have = 1;
+    return w[0];
+}
+static double cur_unif(cursor_t *c) { return orc_u01(cur_word(c)); }
+static double cur_expo(cursor_t *c) { return -log(orc_u01(cur_word(c))); }
+static double cur_norm(cursor_t *c)
+{
+    uint64_t w[2];
+    c->have = 0;
+    philox_words(c->key, c->index, c->sub++, c->iter, c->stream, w);
+    return box_muller(w);
+}
+
+/* ================================================================================================
+ * PG(1, z): Polson, Scott & Windle (2013) sec. 4 / Devroye (2009): J*(1, z/2)/4 with truncation
+ * point t = 0.64.  Stands where the reference calls polyagamma.random_polyagamma(1, b, ...)
+ * (gibbs/logit.py:191-193, 202-204).  Distribution-exact; the reference's own draws come from a
+ * third-party C library that is not available, so values are not comparable draw for draw.
+ * ================================================================================================ */
+#define PG_T 0.64
+
+static double pg_a(int n, double x)
+{
+    double K = (n + 0.5) * M_PI;
+    if (x > PG_T) return K * exp(-0.5 * K * K * x);
+    double e = -1.5 * (log(0.5 * M_PI) + log(x)) + log(K) - 2.0 * (n + 0.5) * (n + 0.5) / x;
+    return exp(e);
+}
+static double log_phi(double x) { return log(0.5 * erfc(-x * M_SQRT1_2)); }
+
+/* probability of proposing from the exponential tail, p/(p+q) */
+static double pg_mass_texpon(double Z)
+{
+    double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
+    double b = sqrt(1.0 / PG_T) * (PG_T * Z - 1.0);
+    double a = -sqrt(1.0 / PG_T) * (PG_T * Z + 1.0);
+    double x0 = log(fz) + fz * PG_T;
+    double xb = x0 - Z + log_phi(b);
+    double xa = x0 + Z + log_phi(a);
+    double qdivp = 4.0 / M_PI * (exp(xb) + exp(xa));
+    return 1.0 / (1.0 + qdivp);
+}
+/* inverse-Gaussian(1/Z, 1) truncated to (0, t] */
+static double pg_rtigauss(cursor_t *c, double Z)
+{
+    double X = PG_T + 1.0;
+    if (1.0 / PG_T > Z) {
+        double alpha = 0.0, U = 1.0;
+        while (U > alpha) {
+            double E1 = cur_expo(c), E2 = cur_expo(c);
+            while (E1 * E1 > 2.0 * E2 / PG_T) { E1 = cur_expo(c); E2 = cur_expo(c); }
+            X = 1.0 + E1 * PG_T;
+            X = PG_T / (X * X);
+            alpha = exp(-0.5 * Z * Z * X);
+            U = cur_unif(c);
+        }
+    } else {
+        double mu = 1.0 / Z;
+        while (X > PG_T) {
+            double Y = cur_norm(c);
+            Y *= Y;
+            double half_mu = 0.5 * mu, mu_Y = mu * Y;
+            X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
+            if (cur_unif(c) > mu / (mu + X)) X = mu * mu / X;
+        }
+    }
+    return X;
+}
+static double pg1_draw(cursor_t *c, double z)
+{
+    double Z = 0.5 * fabs(z);
+    double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
+    double ptail = pg_mass_texpon(Z);
+    for (;;) {
+        double X;
+        if (cur_unif(c) < ptail) X = PG_T + cur_expo(c) / fz;
+        else X = pg_rtigauss(c, Z);
+        double S = pg_a(0, X);
+        double Y = cur_unif(c) * S;
+        int n = 0;
+        for (;;) {
+            ++n;
+            if (n & 1) {
+                S -= pg_a(n, X);
+                if (Y <= S) return 0.25 * X;
+            } else {
+                S += pg_a(n, X);
+                if (Y > S) break;
+            }
+        }
+    }
+}
+void orc_pg1_array(uint64_t key, uint32_t iter, uint32_t stream, long n, const double *z, double *out)
+{
+    for (long i = 0; i < n; ++i) {
+        cursor_t c = cursor_open(key, (uint32_t)i, iter, stream);
+        out[i] = pg1_draw(&c, z[i]);
+    }
+}
+
+/* standard gamma, Marsaglia & Tsang (2000); shape < 1 by the U^(1/a) boost.  Stands where the
+ * reference calls Generator.gamma (gibbs/logit.py:209); same distribution, different stream. */
+static double std_gamma(cursor_t *c, double shape)
+{
+    double boost = 1.0, a = shape;
+    if (a < 1.0) {
+        boost = pow(cur_unif(c), 1.0 / a);
+        a += 1.0;
+    }
+    double d = a - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x = cur_norm(c);
+        double v = 1.0 + cc * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = cur_unif(c);
+        if (u < 1.0 - 0.0331 * (x * x) * (x * x)) return boost * d * v;
+        if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+    }
+}
+double orc_std_gamma_draw(uint64_t key, uint32_t iter, uint32_t stream, double shape)
+{
+    cursor_t c = cursor_open(key, 0, iter, stream);
+    return std_gamma(&c, shape);
+}
+
+/* ================================================================================================
+ * Reference pieces
+ * ================================================================================================ */
+double orc_expit(double x)
+{ /* scipy.special.expit as used at gibbs/logit.py:241-242,249 */
+    if (x < 0.0) { double e = exp(x); return e / (1.0 + e); }
+    return 1.0 / (1.0 + exp(-x));
+}
+
+/* gibbs/logit.py:208  rate = 0.5 * (eta @ Q @ eta) + tau_rate */
+double orc_tau_rate(long n, const int64_t *indptr, const int64_t *indices, const double *qdata,
+                    const double *eta, double tau_rate)
+{
+    double quad = 0.0;
+    for (long i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) acc += qdata[k] * eta[indices[k]];
+        quad += eta[i] * acc;
+    }
+    return 0.5 * quad + tau_rate;
+}
+
+/* distributions.pyx:24-39 */
+void orc_ensure_sums_to_zero(long n, const double *x, const double *z, double *out)
+{
+    double xs = 0.0, zs = 0.0;
+    for (long i = 0; i < n; ++i) { xs += x[i]; zs += z[i]; }
+    double a = -xs / zs;
+    for (long i = 0; i < n; ++i) out[i] = x[i] + a * z[i];
+}
+
+/* distributions.pyx:95-105: eps ~ N(0,I); U = chol(prec) upper (dpotrf 'U'); out = U'eps + b (dtrmv
+ * 'U','T'); solve U'U out = out (dpotrs).  prec (row-major, symmetric) is overwritten: its upper
+ * triangle holds U (the reference's test_distributions.py:15-16 relies on the overwrite). */
+int orc_precision_mvnorm(int d, const double *b, double *prec, const double *eps, double *out)
+{
+    double *U = prec;
+    for (int j = 0; j < d; ++j) {
+        double s = U[j * d + j];
+        for (int k = 0; k < j; ++k) s -= U[k * d + j] * U[k * d + j];
+        if (!(s > 0.0)) return j + 1;
+        double ujj = sqrt(s);
+        U[j * d + j] = ujj;
+        for (int i = j + 1; i < d; ++i) {
+            double t = U[j * d + i];
+            for (int k = 0; k < j; ++k) t -= U[k * d + j] * U[k * d + i];
+            U[j * d + i] = t / ujj;
+        }
+    }
+    /* out = U' eps + b */
+    for (int i = d - 1; i >= 0; --i) {
+        double t = 0.0;
+        for (int k = 0; k <= i; ++k) t += U[k * d + i] * eps[k];
+        out[i] = t + b[i];
+    }
+    /* U' y = out (forward), U x = y (backward) */
+    for (int i = 0; i < d; ++i) {
+        double t = out[i];
+        for (int k = 0; k < i; ++k) t -= U[k * d + i] * out[k];
+        out[i] = t / U[i * d + i];
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        double t = out[i];
+        for (int k = i + 1; k < d; ++k) t -= U[i * d + k] * out[k];
+        out[i] = t / U[i * d + i];
+    }
+    return 0;
+}
+
+/* gibbs/logit.py:229-231 */
+void orc_beta_system(long n, int p, const double *X, const double *omega, const double *k,
+                     const double *spat, const double *b_prec, const double *b_prec_by_mu, double *A,
+                     double *r)
+{
+    for (int a = 0; a < p * p; ++a) A[a] = 0.0;
+    for (int a = 0; a < p; ++a) r[a] = 0.0;
+    for (long i = 0; i < n; ++i) {
+        const double *x = X + i * p;
+        double t = k[i] - omega[i] * spat[i];
+        for (int a = 0; a < p; ++a) {
+            double xo = x[a] * omega[i];
+            for (int c = 0; c < p; ++c) A[a * p + c] += xo * x[c];
+            r[a] += x[a] * t;
+        }
+    }
+    for (int a = 0; a < p * p; ++a) A[a] += b_prec[a];
+    for (int a = 0; a < p; ++a) r[a] += b_prec_by_mu[a];
+}
+
+/* gibbs/logit.py:187-190 (which rows exist) and 220-223 (the q x q system).  The reference stacks
+ * the rows of the observed sites first and of the newly occupied sites after them; a sum does not
+ * depend on that order beyond rounding, so rows are visited in flat order here. */
+void orc_alpha_system(long S, int q, const int64_t *site_ptr, const uint8_t *exists_site,
+                      const double *W, const double *yrow, const double *omega_a,
+                      const double *a_prec, const double *a_prec_by_mu, double *A, double *r)
+{
+    for (int a = 0; a < q * q; ++a) A[a] = 0.0;
+    for (int a = 0; a < q; ++a) r[a] = 0.0;
+    for (long s = 0; s < S; ++s) {
+        if (!exists_site[s]) continue;
+        for (int64_t row = site_ptr[s]; row < site_ptr[s + 1]; ++row) {
+            const double *w = W + row * q;
+            double t = yrow[row] - 0.5;
+            for (int a = 0; a < q; ++a) {
+                double wo = w[a] * omega_a[row];
+                for (int c = 0; c < q; ++c) A[a * q + c] += wo * w[c];
+                r[a] += w[a] * t;
+            }
+        }
+    }
+    for (int a = 0; a < q * q; ++a) A[a] += a_prec[a];
+    for (int a = 0; a < q; ++a) r[a] += a_prec_by_mu[a];
+}
+
+/* gibbs/logit.py:241-245 for one site */
+double orc_z_prob(int p, int q, const double *xrow, const double *beta, double eta_i, long nrows,
+                  const double *Wrows, const double *alpha)
+{
+    double lin = 0.0;
+    for (int a = 0; a < p; ++a) lin += xrow[a] * beta[a];
+    double num1 = orc_expit(lin + eta_i);
+    double prod = 1.0;
+    for (long v = 0; v < nrows; ++v) {
+        double wa = 0.0;
+        for (int a = 0; a < q; ++a) wa += Wrows[v * q + a] * (-alpha[a]);
+        double e = orc_expit(wa);
+        prod = (v == 0) ? e : prod * e;
+    }
+    double num = num1 * prod;
+    return num / ((1.0 - num1) + num);
+}
+
+/* Edge form of the prior term.  The reference draws E @ (sqrt(tau) eps) with E the dense
+ * eigenfactor of Q (gibbs/logit.py:66-67,77), i.e. a N(0, tau Q) vector.  With Q = D - A a weighted
+ * graph Laplacian, Q = B'B for the |edges| x n incidence matrix B whose row for edge (lo,hi), lo<hi,
+ * is sqrt(w) (e_lo - e_hi); so u = B' eps, eps ~ N(0, I_edges), is N(0, Q) too -- same law, O(nnz)
+ * work, no O(n^2) factor.  eps for edge (lo,hi) is the Box-Muller normal of Philox block
+ * (c0=lo, c1=hi, iter, ETA_EDGE). */
+void orc_edge_prior_term(long n, const int64_t *indptr, const int64_t *indices, const double *qdata,
+                         uint64_t key, uint32_t iter, double *u)
+{
+    for (long i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+            long j = (long)indices[k];
+            if (j == i) continue;
+            double w = -qdata[k];
+            if (!(w > 0.0)) continue;
+            uint32_t lo = (uint32_t)(i < j ? i : j), hi = (uint32_t)(i < j ? j : i);
+            double e = orc_block_normal(key, lo, hi, iter, ORC_STREAM_ETA_EDGE);
+            double t = sqrt(w) * e;
+            acc += (i < j) ? t : -t;
+        }
+        u[i] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Joint MINRES.  gibbs/logit.py:80-87 builds P = blockdiag(tau Q, tau Q) + diag([omega; omega]) and
+ * rhs = [y; 1] and calls scipy.sparse.linalg.minres(P, rhs, x0=previous xz) with the defaults
+ * (rtol 1e-5, shift 0, maxiter 5 * 2n, no preconditioner).  The recurrence below restates
+ * Paige & Saunders' MINRES in the form of scipy's _isolve/minres.py (the reference's dependency,
+ * scipy 1.15.3 installed here; pinned 1.6.1 in poetry.lock has the same recurrence with `tol`).
+ * ------------------------------------------------------------------------------------------------ */
+static void joint_matvec(long n, const int64_t *indptr, const int64_t *indices, const double *qdata,
+                         const double *omega, double tau, const double *v, double *out)
+{
+    for (int h = 0; h < 2; ++h) {
+        const double *vh = v + h * n;
+        double *oh = out + h * n;
+        for (long i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+                long j = (long)indices[k];
+                double a = tau * qdata[k];
+                if (j == i) a = a + omega[i];
+                acc += a * vh[j];
+            }
+            oh[i] = acc;
+        }
+    }
+}
+static double dotn(long N, const double *a, const double *b)
+{
+    double s = 0.0;
+    for (long i = 0; i < N; ++i) s += a[i] * b[i];
+    return s;
+}
+
+long orc_minres_joint(long n, const int64_t *indptr, const int64_t *indices, const double *qdata,
+                      const double *omega, double tau, const double *rhs, double *xz, double rtol,
+                      long maxiter, long *itn_out, int *istop_out)
+{
+    const long N = 2 * n;
+    const double eps = DBL_EPSILON;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)N * 8);
+    double *b = buf, *r1 = buf + N, *r2 = buf + 2 * N, *y = buf + 3 * N, *v = buf + 4 * N;
+    double *w = buf + 5 * N, *w1 = buf + 6 * N, *w2 = buf + 7 * N;
+    double *x = xz;
+    long itn = 0;
+    int istop = 0;
+
+    for (long i = 0; i < n; ++i) { b[i] = rhs[i]; b[n + i] = 1.0; }
+    /* r1 = b - A x   (x0=None in the reference is x = 0, for which this is b exactly) */
+    joint_matvec(n, indptr, indices, qdata, omega, tau, x, y);
+    for (long i = 0; i < N; ++i) r1[i] = b[i] - y[i];
+    memcpy(y, r1, sizeof(double) * (size_t)N);
+    double beta1 = dotn(N, r1, y);
+    if (beta1 == 0.0) goto done_ok;
+    if (dotn(N, b, b) == 0.0) { memcpy(x, b, sizeof(double) * (size_t)N); goto done_ok; }
+    beta1 = sqrt(beta1);
+    {
+        double oldb = 0.0, beta = beta1, dbar = 0.0, epsln = 0.0, phibar = beta1;
+        double rhs1 = beta1, rhs2 = 0.0, tnorm2 = 0.0, gmax = 0.0, gmin = DBL_MAX, cs = -1.0, sn = 0.0;
+        memset(w, 0, sizeof(double) * (size_t)N);
+        memset(w2, 0, sizeof(double) * (size_t)N);
+        memcpy(r2, r1, sizeof(double) * (size_t)N);
+        while (itn < maxiter) {
+            itn += 1;
+            double s = 1.0 / beta;
+            for (long i = 0; i < N; ++i) v[i] = s * y[i];
+            joint_matvec(n, indptr, indices, qdata, omega, tau, v, y);
+            if (itn >= 2) {
+                double f = beta / oldb;
+                for (long i = 0; i < N; ++i) y[i] = y[i] - f * r1[i];
+            }
+            double alfa = dotn(N, v, y);
+            {
+                double f = alfa / beta;
+                for (long i = 0; i < N; ++i) y[i] = y[i] - f * r2[i];
+            }
+            { double *t = r1; r1 = r2; r2 = t; }
+            memcpy(r2, y, sizeof(double) * (size_t)N);
+            oldb = beta;
+            beta = dotn(N, r2, y);
+            if (beta < 0.0) { istop = 7; break; }
+            beta = sqrt(beta);
+            tnorm2 += alfa * alfa + oldb * oldb + beta * beta;
+            if (itn == 1 && beta / beta1 <= 10.0 * eps) istop = -1;
+
+            double oldeps = epsln;
+            double delta = cs * dbar + sn * alfa;
+            double gbar = sn * dbar - cs * alfa;
+            epsln = sn * beta;
+            dbar = -cs * beta;
+            double root = sqrt(gbar * gbar + dbar * dbar);
+
+            double gamma = sqrt(gbar * gbar + beta * beta);
+            if (gamma < eps) gamma = eps;
+            cs = gbar / gamma;
+            sn = beta / gamma;
+            double phi = cs * phibar;
+            phibar = sn * phibar;
+
+            double denom = 1.0 / gamma;
+            { double *t = w1; w1 = w2; w2 = w; w = t; }
+            for (long i = 0; i < N; ++i) w[i] = (v[i] - oldeps * w1[i] - delta * w2[i]) * denom;
+            for (long i = 0; i < N; ++i) x[i] = x[i] + phi * w[i];
+
+            if (gamma > gmax) gmax = gamma;
+            if (gamma < gmin) gmin = gamma;
+            double zz = rhs1 / gamma;
+            rhs1 = rhs2 - delta * zz;
+            rhs2 = -epsln * zz;
+
+            double Anorm = sqrt(tnorm2);
+            double ynorm = sqrt(dotn(N, x, x));
+            double epsx = Anorm * ynorm * eps;
+            double rnorm = phibar;
+            double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+            double test2 = (Anorm == 0.0) ? INFINITY : root / Anorm;
+            double Acond = gmax / gmin;
+            if (istop == 0) {
+                double t1 = 1.0 + test1, t2 = 1.0 + test2;
+                if (t2 <= 1.0) istop = 2;
+                if (t1 <= 1.0) istop = 1;
+                if (itn >= maxiter) istop = 6;
+                if (Acond >= 0.1 / eps) istop = 4;
+                if (epsx >= beta1) istop = 3;
+                if (test2 <= rtol) istop = 2;
+                if (test1 <= rtol) istop = 1;
+            }
+            if (istop != 0) break;
+        }
+    }
+done_ok:
+    free(buf);
+    if (itn_out) *itn_out = itn;
+    if (istop_out) *istop_out = istop;
+    return (istop == 6) ? maxiter : 0;
+}
+
+/* ================================================================================================
+ * Whole sampler
+ * ================================================================================================ */
+struct orc_sampler {
+    long n, S, R;
+    int p, q;
+    int64_t *indptr, *indices, *site_id, *site_ptr;
+    double *qdata, *X, *W, *yrow;
+    double *a_prec, *b_prec, *a_prec_by_mu, *b_prec_by_mu;
+    double tau_rate, tau_shape;
+    uint64_t key;
+    uint32_t iter;
+    /* derived index sets (gibbs/base.py:112-137) */
+    uint8_t *surveyed_flag; /* n */
+    uint8_t *obs_site;      /* S: species seen on some visit */
+    /* state */
+    double *alpha, *beta, tau, *eta, *z, *k, *omega_b, *omega_a, *xz, *rhs;
+    uint8_t *exists_site; /* S */
+    long minres_itn;
+    int have_guess;
+};
+
+static void *dupmem(const void *src, size_t bytes)
+{
+    void *d = malloc(bytes ? bytes : 1);
+    if (src) memcpy(d, src, bytes);
+    return d;
+}
+
+orc_sampler *orc_create(long n, int p, int q, long S, const int64_t *indptr, const int64_t *indices,
+                        const double *qdata, const double *X, const int64_t *site_id,
+                        const int64_t *site_ptr, const double *W, const double *yrow,
+                        const double *a_mu, const double *a_prec, const double *b_mu,
+                        const double *b_prec, double tau_rate, double tau_shape, uint64_t key)
+{
+    orc_sampler *s = (orc_sampler *)calloc(1, sizeof(*s));
+    long nnz = (long)indptr[n], R = (long)site_ptr[S];
+    s->n = n; s->p = p; s->q = q; s->S = S; s->R = R;
+    s->indptr = dupmem(indptr, sizeof(int64_t) * (size_t)(n + 1));
+    s->indices = dupmem(indices, sizeof(int64_t) * (size_t)nnz);
+    s->qdata = dupmem(qdata, sizeof(double) * (size_t)nnz);
+    s->X = dupmem(X, sizeof(double) * (size_t)(n * p));
+    s->site_id = dupmem(site_id, sizeof(int64_t) * (size_t)S);
+    s->site_ptr = dupmem(site_ptr, sizeof(int64_t) * (size_t)(S + 1));
+    s->W = dupmem(W, sizeof(double) * (size_t)(R * q));
+    s->yrow = dupmem(yrow, sizeof(double) * (size_t)R);
+    s->a_prec = dupmem(a_prec, sizeof(double) * (size_t)(q * q));
+    s->b_prec = dupmem(b_prec, sizeof(double) * (size_t)(p * p));
+    s->a_prec_by_mu = calloc((size_t)q, sizeof(double));
+    s->b_prec_by_mu = calloc((size_t)p, sizeof(double));
+    /* base.py:161-162 */
+    for (int a = 0; a < q; ++a) for (int c = 0; c < q; ++c) s->a_prec_by_mu[a] += a_prec[a * q + c] * a_mu[c];
+    for (int a = 0; a < p; ++a) for (int c = 0; c < p; ++c) s->b_prec_by_mu[a] += b_prec[a * p + c] * b_mu[c];
+    s->tau_rate = tau_rate; s->tau_shape = tau_shape; s->key = key; s->iter = 0;
+    s->surveyed_flag = calloc((size_t)n, 1);
+    s->obs_site = calloc((size_t)S, 1);
+    s->exists_site = calloc((size_t)S, 1);
+    s->alpha = calloc((size_t)q, sizeof(double));
+    s->beta = calloc((size_t)p, sizeof(double));
+    s->eta = calloc((size_t)n, sizeof(double));
+    s->z = calloc((size_t)n, sizeof(double));
+    s->k = calloc((size_t)n, sizeof(double));
+    s->omega_b = calloc((size_t)n, sizeof(double));
+    s->omega_a = calloc((size_t)(R ? R : 1), sizeof(double));
+    s->xz = calloc((size_t)(2 * n), sizeof(double));
+    s->rhs = calloc((size_t)n, sizeof(double));
+    /* base.py:113-119: z = 1 everywhere, then z[surveyed] = any(y_i); k = z - 1/2 */
+    for (long i = 0; i < n; ++i) s->z[i] = 1.0;
+    for (long t = 0; t < S; ++t) {
+        int any = 0;
+        for (int64_t r = site_ptr[t]; r < site_ptr[t + 1]; ++r) any |= (yrow[r] != 0.0);
+        s->obs_site[t] = (uint8_t)any;
+        s->surveyed_flag[site_id[t]] = 1;
+        s->z[site_id[t]] = any ? 1.0 : 0.0;
+    }
+    for (long i = 0; i < n; ++i) s->k[i] = s->z[i] - 0.5;
+    return s;
+}
+
+void orc_destroy(orc_sampler *s)
+{
+    if (!s) return;
+    free(s->indptr); free(s->indices); free(s->site_id); free(s->site_ptr); free(s->qdata); free(s->X);
+    free(s->W); free(s->yrow); free(s->a_prec); free(s->b_prec); free(s->a_prec_by_mu);
+    free(s->b_prec_by_mu); free(s->surveyed_flag); free(s->obs_site); free(s->exists_site);
+    free(s->alpha); free(s->beta); free(s->eta); free(s->z); free(s->k); free(s->omega_b);
+    free(s->omega_a); free(s->xz); free(s->rhs);
+    free(s);
+}
+
+/* base.py:188-197 (explicit start; the default start is drawn on the host with numpy exactly as
+ * base.py:199-212 does and handed in here) */
+void orc_set_start(orc_sampler *s, const double *alpha, const double *beta, double tau, const double *eta)
+{
+    memcpy(s->alpha, alpha, sizeof(double) * (size_t)s->q);
+    memcpy(s->beta, beta, sizeof(double) * (size_t)s->p);
+    s->tau = tau;
+    memcpy(s->eta, eta, sizeof(double) * (size_t)s->n);
+}
+
+static double xdot(const orc_sampler *s, long i, const double *coef)
+{
+    double acc = 0.0;
+    for (int a = 0; a < s->p; ++a) acc += s->X[i * s->p + a] * coef[a];
+    return acc;
+}
+
+/* gibbs/logit.py:195-204 */
+int orc_update_omega_b(orc_sampler *s)
+{
+    for (long i = 0; i < s->n; ++i) {
+        cursor_t c = cursor_open(s->key, (uint32_t)i, s->iter, ORC_STREAM_OMEGA_B);
+        s->omega_b[i] = pg1_draw(&c, xdot(s, i, s->beta) + s->eta[i]);
+    }
+    return 0;
+}
+
+/* gibbs/logit.py:206-209:  tau = Generator.gamma(shape, 1/rate) = (1/rate) * standard_gamma(shape) */
+int orc_update_tau(orc_sampler *s)
+{
+    double rate = orc_tau_rate(s->n, s->indptr, s->indices, s->qdata, s->eta, s->tau_rate);
+    double g = orc_std_gamma_draw(s->key, s->iter, ORC_STREAM_TAU, s->tau_shape);
+    s->tau = (1.0 / rate) * g;
+    return 0;
+}
+
+/* gibbs/logit.py:211-217 and 73-99 (prior term in edge form, see orc_edge_prior_term) */
+int orc_update_eta(orc_sampler *s)
+{
+    long n = s->n;
+    double *u = (double *)malloc(sizeof(double) * (size_t)n);
+    orc_edge_prior_term(n, s->indptr, s->indices, s->qdata, s->key, s->iter, u);
+    double st = sqrt(s->tau);
+    for (long i = 0; i < n; ++i) {
+        double b = s->k[i] - s->omega_b[i] * xdot(s, i, s->beta);
+        double e = orc_block_normal(s->key, (uint32_t)i, 0, s->iter, ORC_STREAM_ETA_SITE);
+        s->rhs[i] = (b + sqrt(s->omega_b[i]) * e) + st * u[i];
+    }
+    free(u);
+    int istop;
+    long info = orc_minres_joint(n, s->indptr, s->indices, s->qdata, s->omega_b, s->tau, s->rhs, s->xz,
+                                 1e-5, 5 * 2 * n, &s->minres_itn, &istop);
+    s->have_guess = 1;
+    if (info) return ORC_ERR_MINRES;
+    orc_ensure_sums_to_zero(n, s->xz, s->xz + n, s->eta);
+    return 0;
+}
+
+/* gibbs/logit.py:226-232 */
+int orc_update_beta(orc_sampler *s)
+{
+    int p = s->p;
+    double A[16 * 16], r[16], eps[16], out[16];
+    if (p > 16) return ORC_ERR_CHOLESKY;
+    orc_beta_system(s->n, p, s->X, s->omega_b, s->k, s->eta, s->b_prec, s->b_prec_by_mu, A, r);
+    for (int j = 0; j < p; ++j) eps[j] = orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_BETA);
+    if (orc_precision_mvnorm(p, r, A, eps, out)) return ORC_ERR_CHOLESKY;
+    memcpy(s->beta, out, sizeof(double) * (size_t)p);
+    return 0;
+}
+
+/* gibbs/logit.py:180-193: rows of every site with a detection plus rows of not-observed sites whose
+ * current z is 1; PG(1, w'alpha) per such row.  Row r of the flat W is sub-stream index r. */
+int orc_update_omega_a(orc_sampler *s)
+{
+    for (long t = 0; t < s->S; ++t) {
+        int ex = s->obs_site[t] || (s->z[s->site_id[t]] != 0.0);
+        s->exists_site[t] = (uint8_t)ex;
+        if (!ex) continue;
+        for (int64_t r = s->site_ptr[t]; r < s->site_ptr[t + 1]; ++r) {
+            double wa = 0.0;
+            for (int a = 0; a < s->q; ++a) wa += s->W[r * s->q + a] * s->alpha[a];
+            cursor_t c = cursor_open(s->key, (uint32_t)r, s->iter, ORC_STREAM_OMEGA_A);
+            s->omega_a[r] = pg1_draw(&c, wa);
+        }
+    }
+    return 0;
+}
+
+/* gibbs/logit.py:219-224 */
+int orc_update_alpha(orc_sampler *s)
+{
+    int q = s->q;
+    double A[16 * 16], r[16], eps[16], out[16];
+    if (q > 16) return ORC_ERR_CHOLESKY;
+    orc_alpha_system(s->S, q, s->site_ptr, s->exists_site, s->W, s->yrow, s->omega_a, s->a_prec,
+                     s->a_prec_by_mu, A, r);
+    for (int j = 0; j < q; ++j) eps[j] = orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_ALPHA);
+    if (orc_precision_mvnorm(q, r, A, eps, out)) return ORC_ERR_CHOLESKY;
+    memcpy(s->alpha, out, sizeof(double) * (size_t)q);
+    return 0;
+}
+
+/* gibbs/logit.py:234-252 */
+int orc_update_z(orc_sampler *s)
+{
+    for (long t = 0; t < s->S; ++t) {
+        if (s->obs_site[t]) continue;
+        long i = (long)s->site_id[t];
+        double pr = orc_z_prob(s->p, s->q, s->X + i * s->p, s->beta, s->eta[i],
+                               (long)(s->site_ptr[t + 1] - s->site_ptr[t]), s->W + s->site_ptr[t] * s->q,
+                               s->alpha);
+        double u = orc_block_uniform(s->key, (uint32_t)i, 0, s->iter, ORC_STREAM_Z);
+        s->z[i] = (u < pr) ? 1.0 : 0.0;
+    }
+    for (long i = 0; i < s->n; ++i) {
+        if (s->surveyed_flag[i]) continue;
+        double pr = orc_expit(xdot(s, i, s->beta) + s->eta[i]);
+        double u = orc_block_uniform(s->key, (uint32_t)i, 0, s->iter, ORC_STREAM_Z);
+        s->z[i] = (u < pr) ? 1.0 : 0.0;
+    }
+    for (long i = 0; i < s->n; ++i) s->k[i] = s->z[i] - 0.5;
+    return 0;
+}
+
+/* gibbs/logit.py:254-266 */
+int orc_step(orc_sampler *s)
+{
+    int e;
+    if ((e = orc_update_omega_b(s))) return e;
+    if ((e = orc_update_tau(s))) return e;
+    if ((e = orc_update_eta(s))) return e;
+    if ((e = orc_update_beta(s))) return e;
+    if ((e = orc_update_omega_a(s))) return e;
+    if ((e = orc_update_alpha(s))) return e;
+    if ((e = orc_update_z(s))) return e;
+    s->iter += 1;
+    return 0;
+}
+
+/* gibbs/base.py:236-239 */
+int orc_run(orc_sampler *s, long n_iter, long burnin, double *out_alpha, double *out_beta, double *out_tau)
+{
+    for (long i = 0; i < n_iter; ++i) {
+        int e = orc_step(s);
+        if (e) return e;
+        if (i >= burnin) {
+            long row = i - burnin;
+            memcpy(out_alpha + row * s->q, s->alpha, sizeof(double) * (size_t)s->q);
+            memcpy(out_beta + row * s->p, s->beta, sizeof(double) * (size_t)s->p);
+            out_tau[row] = s->tau;
+        }
+    }
+    return 0;
+}
+
+static long copy_out(const double *src, long len, double *out, long cap)
+{
+    if (out && cap >= len) memcpy(out, src, sizeof(double) * (size_t)len);
+    return len;
+}
+
+long orc_get(orc_sampler *s, const char *name, double *out, long cap)
+{
+    if (!strcmp(name, "alpha")) return copy_out(s->alpha, s->q, out, cap);
+    if (!strcmp(name, "beta")) return copy_out(s->beta, s->p, out, cap);
+    if (!strcmp(name, "tau")) return copy_out(&s->tau, 1, out, cap);
+    if (!strcmp(name, "eta")) return copy_out(s->eta, s->n, out, cap);
+    if (!strcmp(name, "z")) return copy_out(s->z, s->n, out, cap);
+    if (!strcmp(name, "k")) return copy_out(s->k, s->n, out, cap);
+    if (!strcmp(name, "omega_b")) return copy_out(s->omega_b, s->n, out, cap);
+    if (!strcmp(name, "omega_a")) return copy_out(s->omega_a, s->R, out, cap);
+    if (!strcmp(name, "xz")) return copy_out(s->xz, 2 * s->n, out, cap);
+    if (!strcmp(name, "rhs")) return copy_out(s->rhs, s->n, out, cap);
+    if (!strcmp(name, "minres_itn")) { double v = (double)s->minres_itn; return copy_out(&v, 1, out, cap); }
+    if (!strcmp(name, "iter")) { double v = (double)s->iter; return copy_out(&v, 1, out, cap); }
+    if (!strcmp(name, "exists")) {
+        if (out && cap >= s->S) for (long t = 0; t < s->S; ++t) out[t] = s->exists_site[t];
+        return s->S;
+    }
+    return -1;
+}
+
+int orc_set(orc_sampler *s, const char *name, const double *in, long len)
+{
+    double *dst = NULL;
+    long want = 0;
+    if (!strcmp(name, "alpha")) { dst = s->alpha; want = s->q; }
+    else if (!strcmp(name, "beta")) { dst = s->beta; want = s->p; }
+    else if (!strcmp(name, "tau")) { dst = &s->tau; want = 1; }
+    else if (!strcmp(name, "eta")) { dst = s->eta; want = s->n; }
+    else if (!strcmp(name, "omega_b")) { dst = s->omega_b; want = s->n; }
+    else if (!strcmp(name, "omega_a")) { dst = s->omega_a; want = s->R; }
+    else if (!strcmp(name, "xz")) { dst = s->xz; want = 2 * s->n; }
+    else if (!strcmp(name, "z")) {
+        if (len != s->n) return -1;
+        for (long i = 0; i < s->n; ++i) { s->z[i] = in[i]; s->k[i] = in[i] - 0.5; }
+        return 0;
+    } else if (!strcmp(name, "iter")) {
+        if (len != 1) return -1;
+        s->iter = (uint32_t)in[0];
+        return 0;
+    } else return -1;
+    if (len != want) return -1;
+    memcpy(dst, in, sizeof(double) * (size_t)want);
+    return 0;
+}
