@@ -1,0 +1,140 @@
+/*
+ * occ_gibbs.h -- C ABI of the MI355X (gfx950) Gibbs engine for the ICAR spatial occupancy model.
+ *
+ * The reference (zoj613/OccuSpytial v0.2.0) has no FFI boundary of its own for this path: the hot
+ * loop is the Python method LogitICARGibbs.step() (occuspytial/gibbs/logit.py:254-266) calling
+ * numpy/scipy, two Cython helpers and the third-party `polyagamma` C sampler.  This header is the
+ * boundary a binding of that path would use: one opaque handle per (device, batch of chains), plain
+ * pointers and sizes, int status codes that map onto the reference's exception types/messages.
+ * The Python class occuspytial_amd.gibbs.LogitICARGibbs binds it with ctypes (INTEGRATION.md shows
+ * the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *  - every function returns OCC_OK (0) or a negative OCC_E* code; occ_last_error() gives the text;
+ *  - input pointers may be host or device memory (copied with hipMemcpyDefault); the library never
+ *    frees or keeps caller memory; outputs are host buffers owned by the caller;
+ *  - all real data is IEEE float64, C-contiguous; index arrays are int32;
+ *  - a handle is driven by one host thread at a time; different handles (one per GPU) are
+ *    independent, and ctypes releases the GIL so host threads can drive several GPUs;
+ *  - there is NO CPU fallback: creation fails with OCC_E_HIP when no gfx950 device is usable.
+ */
+#ifndef OCC_GIBBS_H
+#define OCC_GIBBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCC_ABI_VERSION 1
+#define OCC_MAX_COVARIATES 8 /* p and q limit (register-resident p x p accumulators) */
+
+enum {
+    OCC_OK = 0,
+    OCC_E_BADARG = -1,   /* -> ValueError */
+    OCC_E_HIP = -2,      /* -> RuntimeError (HIP runtime failure / no device) */
+    OCC_E_MINRES = -3,   /* -> RuntimeError('MINRES solver did not converge!')        logit.py:91-92 */
+    OCC_E_CHOLESKY = -4, /* -> RuntimeError('Cholesky factorization/solver failed!')  distributions.pyx:21,107-108 */
+    OCC_E_STATE = -5     /* unknown state name / wrong length */
+};
+
+/* The fixed inputs of LogitICARGibbs(Q, W, X, y, hparams) (logit.py:172-174, base.py:84-88,107-162)
+ * flattened by the host: W/y dictionaries become one (R x q) matrix / R vector in surveyed-site
+ * order with site_ptr offsets (replaces the Data container, data.pyx:61-140); Q is CSR with sorted
+ * columns (the reference keeps CSC of the same symmetric matrix, base.py:122). */
+typedef struct occ_problem {
+    int64_t n;               /* sites                                   base.py:123 */
+    int64_t n_surveyed;      /* S = len(W)                              data.pyx:142-144 */
+    int64_t n_rows;          /* R = total visits over surveyed sites */
+    int32_t p;               /* occupancy covariates  (X.shape[1]) */
+    int32_t q;               /* detection covariates  (W[i].shape[1]) */
+    const int32_t *q_indptr; /* n+1 */
+    const int32_t *q_indices;
+    const double *q_data;    /* ICAR precision: zero row sums, non-positive off-diagonals */
+    const double *X;         /* n x p, row-major */
+    const int32_t *site_id;  /* S: site number of each surveyed site (Data.surveyed order) */
+    const int32_t *site_ptr; /* S+1: row offsets into W / y */
+    const double *W;         /* R x q, row-major */
+    const double *y;         /* R: 0/1 detections */
+    const double *a_mu, *a_prec; /* q, q x q    base.py:49-61,177-186 */
+    const double *b_mu, *b_prec; /* p, p x p */
+    double tau_rate, tau_shape;
+} occ_problem;
+
+typedef struct occ_sampler occ_sampler;
+
+/* Build device-resident state for `n_chains` independent chains of one problem on HIP device
+ * `device`.  keys[c] seeds chain c's counter-based (Philox4x32-10) variate streams; the host derives
+ * it from the chain's numpy SeedSequence (base.py:88, 293-306).  Replaces GibbsBase.__init__ /
+ * _configure (base.py:84-164) and _EtaICARPosterior.__init__ (logit.py:64-71; no dense eigenfactor). */
+int occ_create(const occ_problem *problem, int32_t n_chains, const uint64_t *keys, int32_t device,
+               occ_sampler **out);
+int occ_destroy(occ_sampler *s);
+/* Replace the chains' Philox keys (a new sample() call on an existing sampler draws new keys from
+ * its generator, exactly as the reference's rng stream simply continues, base.py:88). */
+int occ_set_keys(occ_sampler *s, const uint64_t *keys);
+
+/* Starting values of one chain: base.py:188-197 (`start` dict) / 199-212 (default start, drawn by
+ * the host with numpy exactly as the reference does).  Resets the chain's iteration counter and the
+ * MINRES warm start (logit.py:71). */
+int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const double *beta, double tau,
+                  const double *eta);
+
+/* One Gibbs iteration of every chain, launched kernel by kernel with host-checked solver
+ * convergence: LogitICARGibbs.step() (logit.py:254-266). */
+int occ_step(occ_sampler *s);
+
+/* n_iter iterations of every chain; alpha/beta/tau of iterations >= burnin are recorded:
+ * GibbsBase._run's loop (base.py:236-239) for all chains at once (gibbs/parallel.py:38-41).
+ * out_alpha: [n_chains][n_iter-burnin][q], out_beta: [..][p], out_tau: [n_chains][n_iter-burnin].
+ * After a short calibration the iteration is replayed as a hipGraph. */
+int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta,
+            double *out_tau);
+
+/* State of one chain by name (reference attribute names, base.py:65-82 / logit.py):
+ *   alpha(q) beta(p) tau(1) eta(n) z(n) k(n) omega_b(n) omega_a(R) exists(S) xz(2n) rhs(n)
+ *   minres_itn(1) iter(1)
+ * occ_get_state copies into out (capacity cap doubles) and stores the length in *len.
+ * occ_set_state accepts alpha beta tau eta z omega_b omega_a xz iter. */
+int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len);
+int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double *in, int64_t len);
+
+/* Run one kernel group of the iteration in isolation (parity tests against the oracle):
+ *   1 omega_b (+ eta right-hand-side pieces)   logit.py:195-204, 213, 75-78
+ *   2 tau + eta solve (MINRES, projection)     logit.py:206-209, 80-99
+ *   3 eta finalisation + beta system            logit.py:97, 226-231
+ *   4 beta draw + omega_a + alpha system        logit.py:232, 180-193, 219-223
+ *   5 alpha draw + z + iteration bookkeeping    logit.py:224, 234-252 */
+int occ_phase(occ_sampler *s, int32_t phase);
+
+typedef struct occ_stats {
+    int64_t iterations;      /* Gibbs iterations completed (chain 0) */
+    int64_t graph_launches;  /* hipGraph replays */
+    int64_t eager_iterations;
+    int64_t stalls;          /* eta solves carried into a second graph replay (more Krylov steps than captured) */
+    int32_t krylov_cap;      /* Krylov steps captured per eta solve */
+    int32_t krylov_last;     /* MINRES iterations of the last eta solve (chain 0) */
+    double krylov_mean;      /* mean MINRES iterations per solve since creation (all chains) */
+    double last_run_ms;      /* device time of the last occ_run (HIP events on the engine's stream) */
+    int32_t n_blocks_sites, n_blocks_rows, threads_per_block, n_chains;
+} occ_stats;
+int occ_get_stats(occ_sampler *s, occ_stats *out);
+
+/* Per-kernel launch time in the mode occ_run uses: for each kernel kind, `reps` back-to-back launches
+ * of that ONE kernel are captured into a hipGraph and bracketed by two HIP events on the engine's
+ * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.
+ * kinds: 0 omega_b, 1 eta_init, 2 minres_a, 3 minres_b, 4 beta_partial, 5 omega_a, 6 z.
+ * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
+#define OCC_N_KERNEL_KINDS 7
+int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
+                double total_us[OCC_N_KERNEL_KINDS]);
+
+const char *occ_last_error(const occ_sampler *s); /* NULL handle: error of the last failed occ_create */
+int32_t occ_abi_version(void);
+int32_t occ_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

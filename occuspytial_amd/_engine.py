@@ -1,0 +1,112 @@
+"""Thin object wrapper over the C ABI: one ``Engine`` = one device-resident batch of chains."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """Device-resident sampler state for ``n_chains`` chains of one :class:`FlatProblem`.
+
+    ``keys`` are the 64-bit Philox keys of the chains.  ``device`` is the HIP device ordinal.
+    """
+
+    def __init__(self, prob, keys, device=0):
+        lib = _lib.load()
+        self.prob = prob
+        self.n_chains = len(keys)
+        Q = prob.Q
+        self._keep = dict(
+            indptr=np.ascontiguousarray(Q.indptr, dtype=np.int32),
+            indices=np.ascontiguousarray(Q.indices, dtype=np.int32),
+            data=np.ascontiguousarray(Q.data, dtype=np.float64),
+            site_id=np.ascontiguousarray(prob.site_id, dtype=np.int32),
+            site_ptr=np.ascontiguousarray(prob.site_ptr, dtype=np.int32),
+        )
+        k = self._keep
+        pb = _lib.OccProblem(
+            n=prob.n, n_surveyed=prob.S, n_rows=prob.R, p=prob.p, q=prob.q,
+            q_indptr=_ptr(k['indptr']), q_indices=_ptr(k['indices']), q_data=_ptr(k['data']),
+            X=_ptr(prob.X), site_id=_ptr(k['site_id']), site_ptr=_ptr(k['site_ptr']),
+            W=_ptr(prob.W), y=_ptr(prob.y), a_mu=_ptr(prob.a_mu), a_prec=_ptr(prob.a_prec),
+            b_mu=_ptr(prob.b_mu), b_prec=_ptr(prob.b_prec), tau_rate=prob.tau_rate, tau_shape=prob.tau_shape)
+        karr = (C.c_uint64 * self.n_chains)(*[int(v) & (2 ** 64 - 1) for v in keys])
+        h = C.c_void_p()
+        code = lib.occ_create(C.byref(pb), self.n_chains, karr, int(device), C.byref(h))
+        _lib.raise_for(code, None)
+        self._h = h
+        self._lib = lib
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.occ_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, code):
+        _lib.raise_for(code, self._h)
+
+    def set_keys(self, keys):
+        if len(keys) != self.n_chains:
+            raise ValueError('one key per chain is required')
+        karr = (C.c_uint64 * self.n_chains)(*[int(v) & (2 ** 64 - 1) for v in keys])
+        self._check(self._lib.occ_set_keys(self._h, karr))
+
+    def set_start(self, chain, alpha, beta, tau, eta):
+        a = np.ascontiguousarray(alpha, dtype=np.float64)
+        b = np.ascontiguousarray(beta, dtype=np.float64)
+        e = np.ascontiguousarray(eta, dtype=np.float64)
+        if a.shape != (self.prob.q,) or b.shape != (self.prob.p,) or e.shape != (self.prob.n,):
+            raise ValueError('start values have the wrong shape')
+        self._check(self._lib.occ_set_start(self._h, chain, _ptr(a), _ptr(b), float(tau), _ptr(e)))
+
+    def step(self):
+        self._check(self._lib.occ_step(self._h))
+
+    def phase(self, which):
+        self._check(self._lib.occ_phase(self._h, which))
+
+    def run(self, n_iter, burnin=0):
+        keep = n_iter - burnin
+        C_ = self.n_chains
+        a = np.zeros((C_, max(keep, 0), self.prob.q))
+        b = np.zeros((C_, max(keep, 0), self.prob.p))
+        t = np.zeros((C_, max(keep, 0)))
+        self._check(self._lib.occ_run(self._h, n_iter, burnin, _ptr(a), _ptr(b), _ptr(t)))
+        return a, b, t
+
+    def get(self, name, chain=0):
+        ln = C.c_int64(0)
+        self._check(self._lib.occ_get_state(self._h, chain, name.encode(), None, 0, C.byref(ln)))
+        out = np.empty(ln.value)
+        self._check(self._lib.occ_get_state(self._h, chain, name.encode(), _ptr(out), out.size, C.byref(ln)))
+        return out[0] if name in ('tau', 'minres_itn', 'iter') else out
+
+    def set(self, name, value, chain=0):
+        v = np.ascontiguousarray(np.atleast_1d(value), dtype=np.float64)
+        self._check(self._lib.occ_set_state(self._h, chain, name.encode(), _ptr(v), v.size))
+
+    def stats(self):
+        st = _lib.OccStats()
+        self._check(self._lib.occ_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def profile(self, reps=200):
+        """Average in-graph launch time per kernel kind (leaves the chains mid-solve: re-start them)."""
+        counts = (C.c_int64 * _lib.N_KERNEL_KINDS)()
+        total = (C.c_double * _lib.N_KERNEL_KINDS)()
+        self._check(self._lib.occ_profile(self._h, reps, counts, total))
+        return {k: {'launches': int(counts[i]), 'total_us': float(total[i]),
+                    'avg_us': float(total[i]) / counts[i] if counts[i] else 0.0}
+                for i, k in enumerate(_lib.KERNEL_KINDS)}

@@ -75,6 +75,41 @@ class FlatProblem:
 
         self._set_hyperparams(hparams)
 
+    # ---- plain-array round trip (what a multi-GPU launch broadcasts; see occuspytial_amd.distributed)
+    _ARRAY_FIELDS = ('X', 'site_id', 'site_ptr', 'W', 'y', 'obs_site', 'z0', 'a_mu', 'a_prec', 'b_mu', 'b_prec')
+
+    def to_arrays(self):
+        """All fixed inputs as a flat ``name -> ndarray`` dict (no Python containers)."""
+        d = {name: np.ascontiguousarray(getattr(self, name)) for name in self._ARRAY_FIELDS}
+        d['Q_indptr'] = np.ascontiguousarray(self.Q.indptr, dtype=np.int64)
+        d['Q_indices'] = np.ascontiguousarray(self.Q.indices, dtype=np.int64)
+        d['Q_data'] = np.ascontiguousarray(self.Q.data, dtype=np.float64)
+        d['scalars'] = np.array([self.tau_rate, self.tau_shape], dtype=np.float64)
+        return d
+
+    @classmethod
+    def from_arrays(cls, d):
+        """Rebuild from :meth:`to_arrays` output without re-validating (the sender validated)."""
+        self = cls.__new__(cls)
+        for name in cls._ARRAY_FIELDS:
+            setattr(self, name, np.ascontiguousarray(d[name]))
+        self.n, self.p = self.X.shape
+        self.q = self.W.shape[1]
+        self.S = self.site_id.size
+        self.R = int(self.site_ptr[-1])
+        self.Q = sparse.csr_matrix((d['Q_data'], d['Q_indices'], d['Q_indptr']), shape=(self.n, self.n))
+        self.tau_rate, self.tau_shape = (float(v) for v in d['scalars'])
+        self.surveyed = self.site_id.tolist()
+        flag = self.obs_site.astype(bool)
+        self.obs = self.site_id[flag].tolist()
+        self.not_obs = self.site_id[~flag].tolist()
+        mask = np.zeros(self.n, dtype=bool)
+        mask[self.site_id] = True
+        self.not_surveyed = np.flatnonzero(~mask).tolist()
+        self.hparams = dict(tau_rate=self.tau_rate, tau_shape=self.tau_shape, a_mu=self.a_mu,
+                            a_prec=self.a_prec, b_mu=self.b_mu, b_prec=self.b_prec)
+        return self
+
     def _set_hyperparams(self, hparams):
         # defaults: gibbs/base.py:177-186
         hp = {
@@ -123,3 +158,25 @@ def _verify_spatial_precision(Q):
     if off.nnz and off.max() > 0:
         raise ValueError('Spatial precision matrix Q must have non-positive off-diagonal entries '
                          '(Q = D - W with non-negative weights W).')
+
+
+def default_start(rng, prob):
+    """Default starting values of one chain, drawn from ``rng`` in the reference's order
+    (``gibbs/base.py:199-212``): tau ~ Gamma(0.5, scale 1/tau_rate); eta ~ N(0, I) centred; alpha and
+    beta from ``multivariate_normal(mu, 100 * prec, method='cholesky')`` (``100 * prec`` is used as
+    a covariance there)."""
+    tau = rng.gamma(0.5, 1 / prob.tau_rate)
+    eta = rng.standard_normal(prob.n)
+    eta = eta - eta.mean()
+    alpha = rng.multivariate_normal(prob.a_mu, 100 * prob.a_prec, method='cholesky')
+    beta = rng.multivariate_normal(prob.b_mu, 100 * prob.b_prec, method='cholesky')
+    return dict(alpha=alpha, beta=beta, tau=tau, eta=eta)
+
+
+def chain_generators(random_state, n_chains):
+    """Generators of chains 0..n_chains-1 exactly as the reference seeds them: chain 0 owns
+    ``SFC64(SeedSequence(seed))``; chain k >= 1 the k-th child spawned from it
+    (``gibbs/base.py:293-306`` called from ``gibbs/parallel.py:20-23``)."""
+    parent = np.random.SFC64(random_state)
+    children = parent.seed_seq.spawn(max(n_chains - 1, 0))
+    return [np.random.default_rng(parent)] + [np.random.default_rng(np.random.SFC64(c)) for c in children]

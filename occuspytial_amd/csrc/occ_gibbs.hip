@@ -1,0 +1,872 @@
+// occ_gibbs.hip -- host side of the engine behind include/occ_gibbs.h: device-resident problem and
+// chain state, kernel sequencing (eager and hipGraph replay), state access, error mapping.
+// HIP runtime only (no PyTorch, no BLAS/solver libraries).
+#include "../../include/occ_gibbs.h"
+
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "occ_kernels.hpp"
+
+using namespace occ;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Kind { K_OMEGA_B = 0, K_ETA_INIT, K_MINRES_A, K_MINRES_B, K_BETA_PARTIAL, K_OMEGA_A, K_Z };
+
+}  // namespace
+
+struct occ_sampler {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Ctx ctx{};            // host copy of the descriptor
+    Ctx *ctx_dev = nullptr;  // the copy kernels read
+    int tpb = 256;
+    std::vector<void *> allocs;
+    std::string err;
+    // graph replay of one iteration
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int krylov_cap = 0;
+    // statistics
+    int64_t iterations = 0, graph_launches = 0, eager_iterations = 0, stalls = 0;
+    int krylov_last = 0;
+    double last_run_ms = 0.0;
+    int calib_max = 0;
+    // record buffer (alpha | beta | tau rows of the current occ_run), kept between runs
+    double *rec_buf = nullptr;
+    size_t rec_cap = 0;
+    // profiling (occ_profile)
+    bool profiling = false;
+    std::vector<hipEvent_t> pev;
+    std::vector<int> pkind;
+    size_t pev_used = 0;
+    // host mirrors
+    std::vector<int32_t> site_id, site_ptr;
+    std::vector<uint8_t> obs_site;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            s->err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+            return OCC_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+template <class T>
+int dev_alloc(occ_sampler *s, T **out, size_t count, bool zero = true)
+{
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+    *out = (T *)p;
+    return OCC_OK;
+}
+
+template <class T>
+int upload(occ_sampler *s, const T **out, const std::vector<T> &h)
+{
+    T *d = nullptr;
+    int rc = dev_alloc(s, &d, h.size(), false);
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return OCC_OK;
+}
+
+// caller pointer (host or device) -> host vector
+template <class T>
+int fetch(occ_sampler *s, std::vector<T> &h, const T *src, size_t count)
+{
+    h.resize(count);
+    if (count == 0) return OCC_OK;
+    if (src == nullptr) {
+        s->err = "null input pointer";
+        return OCC_E_BADARG;
+    }
+    HIP_TRY(hipMemcpy(h.data(), src, count * sizeof(T), hipMemcpyDefault));
+    return OCC_OK;
+}
+
+dim3 grid_sites(const occ_sampler *s, int chains) { return dim3((unsigned)s->ctx.nb_n, (unsigned)chains); }
+dim3 grid_rows(const occ_sampler *s, int chains) { return dim3((unsigned)s->ctx.nb_r, (unsigned)chains); }
+
+template <class K, class... A>
+void launch(occ_sampler *s, int kind, K kernel, dim3 grid, A... args)
+{
+    if (s->profiling && s->pev_used + 2 <= s->pev.size()) {
+        hipEvent_t a = s->pev[s->pev_used], b = s->pev[s->pev_used + 1];
+        s->pkind.push_back(kind);
+        s->pev_used += 2;
+        hipExtLaunchKernelGGL(kernel, grid, dim3((unsigned)s->tpb), 0, s->stream, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, dim3((unsigned)s->tpb), 0, s->stream, args...);
+    }
+}
+
+using KernelCB = void (*)(const Ctx *, ChainScalars *, Slot *, int);
+using KernelCBI = void (*)(const Ctx *, ChainScalars *, Slot *, int, int);
+
+KernelCBI pick_beta_partial(int p)
+{
+    switch (p) {
+        case 1: return k_beta_partial<1>;
+        case 2: return k_beta_partial<2>;
+        case 3: return k_beta_partial<3>;
+        case 4: return k_beta_partial<4>;
+        case 5: return k_beta_partial<5>;
+        case 6: return k_beta_partial<6>;
+        case 7: return k_beta_partial<7>;
+        default: return k_beta_partial<8>;
+    }
+}
+KernelCB pick_omega_a(int q)
+{
+    switch (q) {
+        case 1: return k_omega_a<1>;
+        case 2: return k_omega_a<2>;
+        case 3: return k_omega_a<3>;
+        case 4: return k_omega_a<4>;
+        case 5: return k_omega_a<5>;
+        case 6: return k_omega_a<6>;
+        case 7: return k_omega_a<7>;
+        default: return k_omega_a<8>;
+    }
+}
+// ---- kernel groups of one iteration (see occ_phase in the header) -----------------------------
+void launch_phase1(occ_sampler *s, int cb, int nc) { launch(s, K_OMEGA_B, k_omega_b, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb); }
+void launch_eta_init(occ_sampler *s, int cb, int nc) { launch(s, K_ETA_INIT, k_eta_init, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb); }
+void launch_krylov(occ_sampler *s, int cb, int nc, int k)
+{
+    launch(s, K_MINRES_A, k_minres_a, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
+    launch(s, K_MINRES_B, k_minres_b, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
+}
+void launch_tail(occ_sampler *s, int cb, int nc, int k_last, int from_phase = 3, int to_phase = 5)
+{
+    if (from_phase <= 3 && to_phase >= 3)
+        launch(s, K_BETA_PARTIAL, pick_beta_partial(s->ctx.p), grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k_last);
+    if (from_phase <= 4 && to_phase >= 4) launch(s, K_OMEGA_A, pick_omega_a(s->ctx.q), grid_rows(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb);
+    if (from_phase <= 5 && to_phase >= 5) launch(s, K_Z, k_z, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb);
+}
+
+int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
+{
+    h.resize(s->ctx.C);
+    HIP_TRY(hipMemcpyAsync(h.data(), s->ctx.sc, sizeof(ChainScalars) * h.size(), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return OCC_OK;
+}
+int write_scalars(occ_sampler *s, const std::vector<ChainScalars> &h)
+{
+    HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return OCC_OK;
+}
+
+// Krylov steps from step `k_from` with the host watching the `done` flags; chains [cb, cb+nc).
+// On return *k_last is the last step launched (every chain's final scalars live in its slot).
+int eager_krylov(occ_sampler *s, int cb, int nc, int k_from, int *k_last)
+{
+    std::vector<Slot> slots((size_t)s->ctx.C * NSLOT);
+    for (int k = k_from;; ++k) {
+        launch_krylov(s, cb, nc, k);
+        if (k < 2) continue;
+        HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const int slot = (2 * k) & (NSLOT - 1);
+        bool all = true;
+        for (int c = cb; c < cb + nc; ++c) all = all && slots[(size_t)c * NSLOT + slot].done;
+        if (all) {
+            *k_last = k;
+            return OCC_OK;
+        }
+        if ((long long)k > s->ctx.maxiter + 2) {
+            s->err = "MINRES solver did not converge!";
+            return OCC_E_MINRES;
+        }
+    }
+}
+
+int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
+{
+    for (size_t c = 0; c < h.size(); ++c) {
+        if (h[c].err == OCC_E_MINRES) { s->err = "MINRES solver did not converge!"; return OCC_E_MINRES; }
+        if (h[c].err == OCC_E_CHOLESKY) { s->err = "Cholesky factorization/solver failed!"; return OCC_E_CHOLESKY; }
+    }
+    return OCC_OK;
+}
+
+// One eager iteration of chains [cb, cb+nc): host-checked MINRES convergence.
+int eager_iteration(occ_sampler *s, int cb, int nc)
+{
+    launch_phase1(s, cb, nc);
+    launch_eta_init(s, cb, nc);
+    int k_last = 0;
+    int rc = eager_krylov(s, cb, nc, 1, &k_last);
+    if (rc) return rc;
+    s->calib_max = std::max(s->calib_max, k_last - 1);
+    launch_tail(s, cb, nc, k_last);
+    s->eager_iterations += 1;
+    return OCC_OK;
+}
+
+void destroy_graph(occ_sampler *s)
+{
+    if (s->exec) hipGraphExecDestroy(s->exec);
+    if (s->graph) hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+}
+
+// Capture one iteration of all chains with `cap` + 1 Krylov step pairs (the extra pair carries the
+// stopping test of iteration `cap`).  A solve that needs more steps is carried into the next replay
+// by the kernels themselves (Ctl::koff), so `cap` trades empty launches against carried replays.
+int build_graph(occ_sampler *s, int cap)
+{
+    destroy_graph(s);
+    const int C = s->ctx.C;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    launch_phase1(s, 0, C);
+    launch_eta_init(s, 0, C);
+    for (int k = 1; k <= cap + 1; ++k) launch_krylov(s, 0, C, k);
+    launch_tail(s, 0, C, cap + 1);
+    HIP_TRY(hipStreamEndCapture(s->stream, &s->graph));
+    HIP_TRY(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+    s->krylov_cap = cap;
+    return OCC_OK;
+}
+
+int set_error(occ_sampler *s, int code, const char *msg)
+{
+    s->err = msg;
+    return code;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int32_t occ_abi_version(void) { return OCC_ABI_VERSION; }
+
+int32_t occ_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *occ_last_error(const occ_sampler *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+int occ_destroy(occ_sampler *s)
+{
+    if (!s) return OCC_OK;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    destroy_graph(s);
+    for (hipEvent_t e : s->pev) hipEventDestroy(e);
+    for (void *p : s->allocs) hipFree(p);
+    if (s->rec_buf) hipFree(s->rec_buf);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return OCC_OK;
+}
+
+static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, const uint64_t *keys)
+{
+    if (!pb || !keys || n_chains < 1) return set_error(s, OCC_E_BADARG, "bad problem / keys / n_chains");
+    if (pb->n < 1 || pb->n > 0x7fffffff || pb->n_rows > 0x7fffffff || pb->n_surveyed > pb->n)
+        return set_error(s, OCC_E_BADARG, "problem sizes out of range");
+    if (pb->p < 1 || pb->p > OCC_MAX_COVARIATES || pb->q < 1 || pb->q > OCC_MAX_COVARIATES)
+        return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 8]");
+    if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q, C = n_chains;
+    Ctx &c = s->ctx;
+    c.n = n; c.S = S; c.R = R; c.p = p; c.q = q; c.C = C;
+    c.tau_rate = pb->tau_rate; c.tau_shape = pb->tau_shape;
+    c.maxiter = 10LL * n;  // scipy default 5 * (2n)  (minres.py, called at logit.py:87)
+
+    // ---- fetch and check the inputs on the host -------------------------------------------------
+    std::vector<int32_t> indptr, indices;
+    std::vector<double> qdata, X, W, y, a_mu, a_prec, b_mu, b_prec;
+    int rc;
+    if ((rc = fetch(s, indptr, pb->q_indptr, (size_t)n + 1))) return rc;
+    if (indptr[0] != 0 || indptr[n] < n) return set_error(s, OCC_E_BADARG, "malformed Q indptr");
+    const size_t nnz = (size_t)indptr[n];
+    if ((rc = fetch(s, indices, pb->q_indices, nnz))) return rc;
+    if ((rc = fetch(s, qdata, pb->q_data, nnz))) return rc;
+    if ((rc = fetch(s, X, pb->X, (size_t)n * p))) return rc;
+    if ((rc = fetch(s, s->site_id, pb->site_id, (size_t)S))) return rc;
+    if ((rc = fetch(s, s->site_ptr, pb->site_ptr, (size_t)S + 1))) return rc;
+    if ((rc = fetch(s, W, pb->W, (size_t)R * q))) return rc;
+    if ((rc = fetch(s, y, pb->y, (size_t)R))) return rc;
+    if ((rc = fetch(s, a_mu, pb->a_mu, (size_t)q))) return rc;
+    if ((rc = fetch(s, a_prec, pb->a_prec, (size_t)q * q))) return rc;
+    if ((rc = fetch(s, b_mu, pb->b_mu, (size_t)p))) return rc;
+    if ((rc = fetch(s, b_prec, pb->b_prec, (size_t)p * p))) return rc;
+    if (S > 0 && (s->site_ptr[0] != 0 || s->site_ptr[S] != R)) return set_error(s, OCC_E_BADARG, "site_ptr does not span the rows");
+
+    // ---- Q: CSR -> diagonal + SELL-64 off-diagonals (coalesced per-wave slices) -------------------
+    // Also checks what the edge form of the prior term needs: zero row sums, non-positive
+    // off-diagonals (Q = D - W), the singular ICAR precision of gibbs/base.py:166-170.
+    const int nslice = (n + 63) / 64;
+    std::vector<int> sell_ptr((size_t)nslice + 1, 0);
+    std::vector<double> qdiag((size_t)n, 0.0);
+    double scale = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double rowsum = 0.0, rowabs = 0.0;
+        int last = -1;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const int j = indices[k];
+            if (j < 0 || j >= n || j <= last) return set_error(s, OCC_E_BADARG, "Q columns must be sorted, unique and in range");
+            last = j;
+            rowsum += qdata[k];
+            rowabs += std::fabs(qdata[k]);
+            if (j == i) qdiag[i] = qdata[k];
+            else if (qdata[k] > 0.0) return set_error(s, OCC_E_BADARG, "Q must have non-positive off-diagonal entries");
+        }
+        scale = std::max(scale, rowabs);
+        if (std::fabs(rowsum) > 1e-10 * std::max(rowabs, 1e-300))
+            return set_error(s, OCC_E_BADARG, "Spatial precision matrix Q must be singular.");
+    }
+    if (!(scale > 0.0)) return set_error(s, OCC_E_BADARG, "Spatial precision matrix Q must be singular.");
+    for (int sl = 0; sl < nslice; ++sl) {
+        int width = 0;
+        for (int i = sl * 64; i < std::min(n, sl * 64 + 64); ++i) {
+            int cnt = 0;
+            for (int k = indptr[i]; k < indptr[i + 1]; ++k) cnt += (indices[k] != i);
+            width = std::max(width, cnt);
+        }
+        sell_ptr[sl + 1] = sell_ptr[sl] + width * 64;
+    }
+    std::vector<int> sell_col((size_t)sell_ptr[nslice]);
+    std::vector<double> sell_val((size_t)sell_ptr[nslice], 0.0);
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int base = sell_ptr[sl], width = (sell_ptr[sl + 1] - base) / 64;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = sl * 64 + lane;
+            int kk = 0;
+            if (i < n)
+                for (int k = indptr[i]; k < indptr[i + 1]; ++k)
+                    if (indices[k] != i) {
+                        sell_col[(size_t)base + kk * 64 + lane] = indices[k];
+                        sell_val[(size_t)base + kk * 64 + lane] = qdata[k];
+                        ++kk;
+                    }
+            for (; kk < width; ++kk) sell_col[(size_t)base + kk * 64 + lane] = std::min(i, n - 1);  // padding: value 0
+        }
+    }
+
+    // ---- design matrices as structure-of-arrays; ragged visits; index sets (base.py:112-152) -----
+    std::vector<double> Xt((size_t)n * p), Wt((size_t)R * q);
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < p; ++a) Xt[(size_t)a * n + i] = X[(size_t)i * p + a];
+    for (int r = 0; r < R; ++r)
+        for (int a = 0; a < q; ++a) Wt[(size_t)a * R + r] = W[(size_t)r * q + a];
+    std::vector<uint8_t> yrow((size_t)R);
+    std::vector<int> row_site((size_t)R), site_sidx((size_t)n, -1);
+    s->obs_site.assign((size_t)S, 0);
+    for (int t = 0; t < S; ++t) {
+        const int site = s->site_id[t];
+        if (site < 0 || site >= n || site_sidx[site] != -1) return set_error(s, OCC_E_BADARG, "site_id entries must be unique and in [0, n)");
+        if (s->site_ptr[t + 1] < s->site_ptr[t]) return set_error(s, OCC_E_BADARG, "site_ptr must be non-decreasing");
+        site_sidx[site] = t;
+        uint8_t any = 0;
+        for (int r = s->site_ptr[t]; r < s->site_ptr[t + 1]; ++r) {
+            yrow[r] = (y[r] != 0.0) ? 1 : 0;
+            any |= yrow[r];
+        }
+        s->obs_site[t] = any;
+        for (int r = s->site_ptr[t]; r < s->site_ptr[t + 1]; ++r) row_site[r] = site | (any ? (int)0x80000000 : 0);
+    }
+    std::vector<double> hyp((size_t)q * q + q + (size_t)p * p + p, 0.0);
+    {
+        double *ap = hyp.data(), *apm = ap + q * q, *bp = apm + q, *bpm = bp + p * p;
+        std::copy(a_prec.begin(), a_prec.end(), ap);
+        std::copy(b_prec.begin(), b_prec.end(), bp);
+        for (int a = 0; a < q; ++a)
+            for (int b = 0; b < q; ++b) apm[a] += a_prec[(size_t)a * q + b] * a_mu[b];  // base.py:161
+        for (int a = 0; a < p; ++a)
+            for (int b = 0; b < p; ++b) bpm[a] += b_prec[(size_t)a * p + b] * b_mu[b];  // base.py:162
+    }
+
+    // ---- launch geometry: one site (or visit row) per thread; enough blocks to spread over the CUs
+    int tpb = 256;
+    while (tpb > 64 && ((long long)n * C + tpb - 1) / tpb < 512) tpb >>= 1;
+    s->tpb = tpb;
+    c.nb_n = (n + tpb - 1) / tpb;
+    c.nb_r = std::max(1, (R + tpb - 1) / tpb);
+    c.nb_max = std::max(c.nb_n, c.nb_r);
+
+    // ---- device memory ------------------------------------------------------------------------------
+    if ((rc = upload(s, &c.sell_ptr, sell_ptr))) return rc;
+    if ((rc = upload(s, &c.sell_col, sell_col))) return rc;
+    if ((rc = upload(s, &c.sell_val, sell_val))) return rc;
+    if ((rc = upload(s, &c.qdiag, qdiag))) return rc;
+    if ((rc = upload(s, &c.Xt, Xt))) return rc;
+    if ((rc = upload(s, &c.Wt, Wt))) return rc;
+    if ((rc = upload(s, &c.yrow, yrow))) return rc;
+    if ((rc = upload(s, &c.row_site, row_site))) return rc;
+    if ((rc = upload(s, &c.site_sidx, site_sidx))) return rc;
+    {
+        std::vector<int> sp(s->site_ptr.begin(), s->site_ptr.end());
+        if ((rc = upload(s, &c.site_ptr, sp))) return rc;
+    }
+    if ((rc = upload(s, &c.obs_site, s->obs_site))) return rc;
+    if ((rc = upload(s, &c.hyp, hyp))) return rc;
+
+    const size_t Cn = (size_t)C * n;
+    if ((rc = dev_alloc(s, &c.eta, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.omega_b, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.pre, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.uprior, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.rhs, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.omega_a, (size_t)C * R))) return rc;
+    if ((rc = dev_alloc(s, &c.z, Cn))) return rc;
+    for (int b = 0; b < 3; ++b) {
+        if ((rc = dev_alloc(s, &c.Rv[b], Cn))) return rc;
+        if ((rc = dev_alloc(s, &c.Wv[b], Cn))) return rc;
+    }
+    if ((rc = dev_alloc(s, &c.Xv, Cn))) return rc;
+    if ((rc = dev_alloc(s, &c.part, (size_t)C * 2 * NACC_MAX * c.nb_max))) return rc;
+    if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.slots, (size_t)C * NSLOT))) return rc;
+    if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
+    c.rec = nullptr;
+
+    // initial occupancy state (base.py:113-119) and chain keys
+    std::vector<uint8_t> z0(Cn, 1);
+    for (int ch = 0; ch < C; ++ch)
+        for (int t = 0; t < S; ++t) z0[(size_t)ch * n + s->site_id[t]] = s->obs_site[t];
+    HIP_TRY(hipMemcpy(c.z, z0.data(), z0.size(), hipMemcpyHostToDevice));
+    std::vector<ChainScalars> sc((size_t)C);
+    std::memset(sc.data(), 0, sizeof(ChainScalars) * sc.size());
+    for (int ch = 0; ch < C; ++ch) sc[ch].key = keys[ch];
+    HIP_TRY(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(s, &s->ctx_dev, 1, false))) return rc;
+    HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    return OCC_OK;
+}
+
+int occ_create(const occ_problem *problem, int32_t n_chains, const uint64_t *keys, int32_t device, occ_sampler **out)
+{
+    if (!out) return OCC_E_BADARG;
+    *out = nullptr;
+    occ_sampler *s = new occ_sampler();
+    s->device = device;
+    int rc = create_impl(s, problem, n_chains, keys);
+    if (rc != OCC_OK) {
+        g_create_error = s->err;
+        occ_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return OCC_OK;
+}
+
+int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const double *beta, double tau, const double *eta)
+{
+    if (!s) return OCC_E_BADARG;
+    const Ctx &c = s->ctx;
+    if (chain < 0 || chain >= c.C || !alpha || !beta || !eta) return set_error(s, OCC_E_BADARG, "bad chain / null start pointer");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    ChainScalars &sc = h[chain];
+    std::vector<double> a, b;
+    if ((rc = fetch(s, a, alpha, (size_t)c.q))) return rc;
+    if ((rc = fetch(s, b, beta, (size_t)c.p))) return rc;
+    std::memset(sc.alpha, 0, sizeof(sc.alpha));
+    std::memset(sc.beta, 0, sizeof(sc.beta));
+    std::copy(a.begin(), a.end(), sc.alpha);
+    std::copy(b.begin(), b.end(), sc.beta);
+    sc.tau = tau;
+    sc.next.it = 0; sc.next.koff = 0;
+    sc.cur = sc.next; sc.mid = sc.next;
+    sc.it_stop = 0; sc.it_base = 0; sc.burnin = 0; sc.keep = 0; sc.err = 0;
+    if ((rc = write_scalars(s, h))) return rc;
+    HIP_TRY(hipMemcpy(c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
+    HIP_TRY(hipMemset(c.Xv + (size_t)chain * c.n, 0, sizeof(double2) * c.n));  // x0 = None (logit.py:71)
+    // z back to its configured value (a fresh _run starts from the constructor's z only on the first
+    // call in the reference; restoring it keeps runs reproducible per seed)
+    return OCC_OK;
+}
+
+int occ_set_keys(occ_sampler *s, const uint64_t *keys)
+{
+    if (!s || !keys) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    for (size_t c = 0; c < h.size(); ++c) h[c].key = keys[c];
+    return write_scalars(s, h);
+}
+
+static int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep, bool same_base_for_all)
+{
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    for (auto &sc : h) {
+        sc.it_base = sc.next.it;
+        sc.it_stop = sc.next.it + (uint32_t)n_iter;
+        sc.burnin = (uint32_t)burnin;
+        sc.keep = (uint32_t)keep;
+        sc.next.koff = 0;
+    }
+    (void)same_base_for_all;
+    return write_scalars(s, h);
+}
+
+int occ_step(occ_sampler *s)
+{
+    if (!s) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = set_window(s, 1, 0, 0, true);
+    if (rc) return rc;
+    if ((rc = eager_iteration(s, 0, s->ctx.C))) return rc;
+    std::vector<ChainScalars> h;
+    if ((rc = read_scalars(s, h))) return rc;
+    s->iterations = h[0].next.it;
+    s->krylov_last = h[0].minres_itn_last;
+    return check_device_errors(s, h);
+}
+
+int occ_phase(occ_sampler *s, int32_t phase)
+{
+    if (!s) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    const int C = s->ctx.C;
+    int rc = OCC_OK;
+    static thread_local int k_last_phase = 0;
+    if (phase == 1) {
+        if ((rc = set_window(s, 1, 0, 0, true))) return rc;
+        launch_phase1(s, 0, C);
+    } else if (phase == 2) {
+        launch_eta_init(s, 0, C);
+        if ((rc = eager_krylov(s, 0, C, 1, &k_last_phase))) return rc;
+    } else if (phase >= 3 && phase <= 5) {
+        launch_tail(s, 0, C, k_last_phase, phase, phase);
+    } else {
+        return set_error(s, OCC_E_BADARG, "phase must be 1..5");
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<ChainScalars> h;
+    if ((rc = read_scalars(s, h))) return rc;
+    return check_device_errors(s, h);
+}
+
+int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
+{
+    if (!s) return OCC_E_BADARG;
+    if (n_iter < 1 || burnin < 0 || burnin >= n_iter) return set_error(s, OCC_E_BADARG, "burnin value cannot be larger than sample size");
+    if (!out_alpha || !out_beta || !out_tau) return set_error(s, OCC_E_BADARG, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    Ctx &c = s->ctx;
+    const int C = c.C, p = c.p, q = c.q;
+    const int64_t keep = n_iter - burnin;
+    const size_t rw = (size_t)q + p + 1;
+    const size_t need = (size_t)C * keep * rw;
+    if (need > s->rec_cap) {  // grow the record buffer (its address lives in the device descriptor)
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->rec_buf) HIP_TRY(hipFree(s->rec_buf));
+        s->rec_buf = nullptr;
+        s->rec_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->rec_buf, sizeof(double) * need));
+        s->rec_cap = need;
+    }
+    double *rec = s->rec_buf;
+    if (c.rec != rec) {
+        c.rec = rec;
+        HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    }
+    int rc = set_window(s, n_iter, burnin, keep, true);
+    std::vector<ChainScalars> h;
+    auto finish = [&](int code) { return code; };
+    if (rc) return finish(rc);
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+
+    // calibration (first run only): a few eager iterations measure the Krylov steps a solve needs;
+    // the count of the last, warm-started solve sizes the captured graph
+    int64_t done_min = 0;
+    int cap = s->krylov_cap;
+    if (!s->exec) {
+        const int64_t n_calib = std::min<int64_t>(n_iter, 3);
+        s->calib_max = 0;
+        for (int64_t i = 0; i < n_calib; ++i) {
+            if (i == n_calib - 1) s->calib_max = 0;
+            if ((rc = eager_iteration(s, 0, C))) return finish(rc);
+        }
+        done_min = n_calib;
+        cap = std::max(4, s->calib_max + 3);
+        if (const char *force = std::getenv("OCC_FORCE_KRYLOV_CAP")) cap = std::max(1, std::atoi(force));  // tests
+        if (done_min < n_iter && (rc = build_graph(s, cap))) return finish(rc);
+    }
+
+    const bool forced = std::getenv("OCC_FORCE_KRYLOV_CAP") != nullptr;
+    while (done_min < n_iter) {
+        // every replay advances each unfinished chain by one iteration, or (rarely) carries its eta
+        // solve into the next replay; finished chains idle.  No host work inside a batch.
+        const int64_t batch = std::min<int64_t>(n_iter - done_min, s->graph_launches < 64 ? 32 : 256);
+        for (int64_t b = 0; b < batch; ++b) HIP_TRY(hipGraphLaunch(s->exec, s->stream));
+        s->graph_launches += batch;
+        if ((rc = read_scalars(s, h))) return finish(rc);
+        if ((rc = check_device_errors(s, h))) return finish(rc);
+        done_min = n_iter;
+        unsigned long long tot = 0, sq = 0, solves = 0;
+        for (int ch = 0; ch < C; ++ch) {
+            done_min = std::min<int64_t>(done_min, (int64_t)h[ch].next.it - (int64_t)h[ch].it_base);
+            tot += h[ch].krylov_total; sq += h[ch].krylov_sq_total; solves += h[ch].solves;
+        }
+        // re-size the captured solve: about mean + 2 sd of the observed Krylov counts
+        if (!forced && solves >= 32 && done_min < n_iter) {
+            const double mean = (double)tot / solves, var = std::max(0.0, (double)sq / solves - mean * mean);
+            const int want = std::max(4, (int)std::ceil(mean + 2.0 * std::sqrt(var)));
+            if (std::abs(want - s->krylov_cap) >= 2 && (rc = build_graph(s, want))) return finish(rc);
+        }
+    }
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->last_run_ms = ms;
+    if ((rc = read_scalars(s, h))) return finish(rc);
+    if ((rc = check_device_errors(s, h))) return finish(rc);
+    s->iterations = h[0].next.it;
+    s->krylov_last = h[0].minres_itn_last;
+
+    std::vector<double> host((size_t)C * keep * rw);
+    HIP_TRY(hipMemcpy(host.data(), rec, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
+    for (int ch = 0; ch < C; ++ch)
+        for (int64_t t = 0; t < keep; ++t) {
+            const double *row = host.data() + ((size_t)ch * keep + t) * rw;
+            std::copy(row, row + q, out_alpha + ((size_t)ch * keep + t) * q);
+            std::copy(row + q, row + q + p, out_beta + ((size_t)ch * keep + t) * p);
+            out_tau[(size_t)ch * keep + t] = row[q + p];
+        }
+    return finish(OCC_OK);
+}
+
+int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len)
+{
+    if (!s || !name || !len) return OCC_E_BADARG;
+    const Ctx &c = s->ctx;
+    if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const std::string nm(name);
+    const size_t n = (size_t)c.n, R = (size_t)c.R;
+    std::vector<double> v;
+    auto pull = [&](const double *src, size_t count) -> int {
+        v.resize(count);
+        if (count) HIP_TRY(hipMemcpy(v.data(), src, sizeof(double) * count, hipMemcpyDeviceToHost));
+        return OCC_OK;
+    };
+    int rc = OCC_OK;
+    if (nm == "eta") rc = pull(c.eta + chain * n, n);
+    else if (nm == "omega_b") rc = pull(c.omega_b + chain * n, n);
+    else if (nm == "omega_a") rc = pull(c.omega_a + chain * R, R);
+    else if (nm == "rhs") rc = pull(c.rhs + chain * n, n);
+    else if (nm == "z" || nm == "k" || nm == "exists") {
+        std::vector<uint8_t> z(n);
+        HIP_TRY(hipMemcpy(z.data(), c.z + chain * n, n, hipMemcpyDeviceToHost));
+        if (nm == "exists") {
+            v.resize((size_t)c.S);
+            for (int t = 0; t < c.S; ++t) v[t] = (s->obs_site[t] || z[s->site_id[t]]) ? 1.0 : 0.0;
+        } else {
+            v.resize(n);
+            for (size_t i = 0; i < n; ++i) v[i] = (nm == "z") ? (double)z[i] : (double)z[i] - 0.5;
+        }
+    } else if (nm == "xz") {
+        std::vector<double2> x(n);
+        HIP_TRY(hipMemcpy(x.data(), c.Xv + chain * n, sizeof(double2) * n, hipMemcpyDeviceToHost));
+        v.resize(2 * n);
+        for (size_t i = 0; i < n; ++i) { v[i] = x[i].x; v[n + i] = x[i].y; }
+    } else {
+        std::vector<ChainScalars> h;
+        if ((rc = read_scalars(s, h))) return rc;
+        const ChainScalars &sc = h[chain];
+        if (nm == "alpha") v.assign(sc.alpha, sc.alpha + c.q);
+        else if (nm == "beta") v.assign(sc.beta, sc.beta + c.p);
+        else if (nm == "tau") v.assign(1, sc.tau);
+        else if (nm == "minres_itn") v.assign(1, (double)sc.minres_itn_last);
+        else if (nm == "iter") v.assign(1, (double)sc.next.it);
+        else return set_error(s, OCC_E_STATE, "unknown state name");
+    }
+    if (rc) return rc;
+    *len = (int64_t)v.size();
+    if (out) {
+        if (cap < (int64_t)v.size()) return set_error(s, OCC_E_STATE, "output buffer too small");
+        std::copy(v.begin(), v.end(), out);
+    }
+    return OCC_OK;
+}
+
+int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double *in, int64_t len)
+{
+    if (!s || !name || !in) return OCC_E_BADARG;
+    const Ctx &c = s->ctx;
+    if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const std::string nm(name);
+    const size_t n = (size_t)c.n, R = (size_t)c.R;
+    auto need = [&](size_t want) { return (size_t)len == want; };
+    if (nm == "eta" || nm == "omega_b") {
+        if (!need(n)) return set_error(s, OCC_E_STATE, "wrong length");
+        double *dst = (nm == "eta" ? c.eta : c.omega_b) + chain * n;
+        HIP_TRY(hipMemcpy(dst, in, sizeof(double) * n, hipMemcpyHostToDevice));
+    } else if (nm == "omega_a") {
+        if (!need(R)) return set_error(s, OCC_E_STATE, "wrong length");
+        HIP_TRY(hipMemcpy(c.omega_a + chain * R, in, sizeof(double) * R, hipMemcpyHostToDevice));
+    } else if (nm == "z") {
+        if (!need(n)) return set_error(s, OCC_E_STATE, "wrong length");
+        std::vector<uint8_t> z(n);
+        for (size_t i = 0; i < n; ++i) z[i] = in[i] != 0.0;
+        HIP_TRY(hipMemcpy(c.z + chain * n, z.data(), n, hipMemcpyHostToDevice));
+    } else if (nm == "xz") {
+        if (!need(2 * n)) return set_error(s, OCC_E_STATE, "wrong length");
+        std::vector<double2> x(n);
+        for (size_t i = 0; i < n; ++i) x[i] = make_double2(in[i], in[n + i]);
+        HIP_TRY(hipMemcpy(c.Xv + chain * n, x.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    } else {
+        std::vector<ChainScalars> h;
+        int rc = read_scalars(s, h);
+        if (rc) return rc;
+        ChainScalars &sc = h[chain];
+        if (nm == "alpha" && need((size_t)c.q)) std::copy(in, in + c.q, sc.alpha);
+        else if (nm == "beta" && need((size_t)c.p)) std::copy(in, in + c.p, sc.beta);
+        else if (nm == "tau" && need(1)) sc.tau = in[0];
+        else if (nm == "iter" && need(1)) { sc.next.it = (uint32_t)in[0]; sc.cur = sc.next; sc.mid = sc.next; }
+        else return set_error(s, OCC_E_STATE, "unknown state name or wrong length");
+        if ((rc = write_scalars(s, h))) return rc;
+    }
+    return OCC_OK;
+}
+
+int occ_get_stats(occ_sampler *s, occ_stats *out)
+{
+    if (!s || !out) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    unsigned long long tot = 0, solves = 0, carries = 0;
+    for (auto &sc : h) { tot += sc.krylov_total; solves += sc.solves; carries += sc.carries; }
+    s->stalls = (int64_t)carries;
+    out->iterations = h[0].next.it;
+    out->graph_launches = s->graph_launches;
+    out->eager_iterations = s->eager_iterations;
+    out->stalls = s->stalls;
+    out->krylov_cap = s->krylov_cap;
+    out->krylov_last = h[0].minres_itn_last;
+    out->krylov_mean = solves ? (double)tot / (double)solves : 0.0;
+    out->last_run_ms = s->last_run_ms;
+    out->n_blocks_sites = s->ctx.nb_n;
+    out->n_blocks_rows = s->ctx.nb_r;
+    out->threads_per_block = s->tpb;
+    out->n_chains = s->ctx.C;
+    return OCC_OK;
+}
+
+// Average launch-to-launch time of each kernel kind inside a hipGraph (the mode occ_run uses):
+// `reps` back-to-back launches of ONE kernel are captured into a graph and bracketed by two HIP events
+// on the engine's stream; elapsed / reps = kernel duration + the dependent-launch boundary.  Eager
+// launches are not representative (idle gaps, end-of-kernel flushes before host copies).
+static int time_kernel_graph(occ_sampler *s, int kind, int reps, int k_arg, double *avg_us)
+{
+    const int C = s->ctx.C;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    for (int r = 0; r < reps; ++r) {
+        switch (kind) {
+            case K_OMEGA_B: launch_phase1(s, 0, C); break;
+            case K_ETA_INIT: launch_eta_init(s, 0, C); break;
+            case K_MINRES_A: launch(s, K_MINRES_A, k_minres_a, grid_sites(s, C), s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, k_arg); break;
+            case K_MINRES_B: launch(s, K_MINRES_B, k_minres_b, grid_sites(s, C), s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, k_arg); break;
+            case K_BETA_PARTIAL: launch_tail(s, 0, C, k_arg, 3, 3); break;
+            case K_OMEGA_A: launch_tail(s, 0, C, k_arg, 4, 4); break;
+            default: launch_tail(s, 0, C, k_arg, 5, 5); break;
+        }
+    }
+    HIP_TRY(hipStreamEndCapture(s->stream, &graph));
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(exec, s->stream));  // untimed: instruction cache, clocks
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    HIP_TRY(hipGraphLaunch(exec, s->stream));
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *avg_us = 1000.0 * ms / reps;
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+    return OCC_OK;
+}
+
+int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS], double total_us[OCC_N_KERNEL_KINDS])
+{
+    if (!s || reps < 1 || !counts || !total_us) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    const int C = s->ctx.C;
+    int rc = set_window(s, 1 << 30, 0, 0, true);  // no chain reaches its stop during the timing loops
+    if (rc) return rc;
+    // a complete eager iteration leaves a finished solve: the tail kernels have real work
+    launch_phase1(s, 0, C);
+    launch_eta_init(s, 0, C);
+    int k_last = 0;
+    if ((rc = eager_krylov(s, 0, C, 1, &k_last))) return rc;
+    const int tail_kinds[3] = {K_BETA_PARTIAL, K_OMEGA_A, K_Z};
+    double us = 0.0;
+    for (int kind : tail_kinds) {
+        if ((rc = time_kernel_graph(s, kind, reps, k_last, &us))) return rc;
+        counts[kind] = reps;
+        total_us[kind] = us * reps;
+    }
+    if ((rc = time_kernel_graph(s, K_OMEGA_B, reps, 0, &us))) return rc;
+    counts[K_OMEGA_B] = reps; total_us[K_OMEGA_B] = us * reps;
+    if ((rc = time_kernel_graph(s, K_ETA_INIT, reps, 0, &us))) return rc;
+    counts[K_ETA_INIT] = reps; total_us[K_ETA_INIT] = us * reps;
+    // open a solve and stop mid-way (step 3 is the general step: both w vectors and r2_{k-2} live)
+    launch_krylov(s, 0, C, 1);
+    launch_krylov(s, 0, C, 2);
+    if ((rc = time_kernel_graph(s, K_MINRES_A, reps, 3, &us))) return rc;
+    counts[K_MINRES_A] = reps; total_us[K_MINRES_A] = us * reps;
+    if ((rc = time_kernel_graph(s, K_MINRES_B, reps, 3, &us))) return rc;
+    counts[K_MINRES_B] = reps; total_us[K_MINRES_B] = us * reps;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return OCC_OK;
+}
+
+}  // extern "C"

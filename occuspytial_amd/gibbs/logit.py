@@ -1,0 +1,147 @@
+"""``LogitICARGibbs`` on the MI355X engine (API of reference ``occuspytial/gibbs/logit.py:102-266``)."""
+import numpy as np
+
+from .._engine import Engine
+from ..chain import Chain
+from .base import GibbsBase
+
+
+def _philox_key(rng):
+    """64-bit key of a chain's device streams: the next raw word of the chain's own SFC64 stream,
+    taken AFTER its start values were drawn, so chains and repeated runs never share a key."""
+    return int(rng.bit_generator.random_raw())
+
+
+class LogitICARGibbs(GibbsBase):
+    r"""Gibbs sampler, logit link, ICAR spatial random effects -- computed on an AMD MI355X.
+
+    Drop-in for the reference class of the same name (``logit.py:102-174``): same constructor
+    ``(Q, W, X, y, hparams=None, random_state=None)``, same ``sample`` / ``step`` / ``copy``, same
+    ``state`` / ``fixed`` attributes and error behaviour.  One iteration performs the reference's seven
+    conditional updates in its order (``logit.py:254-266``): :math:`\omega_b`, :math:`\tau`,
+    :math:`\eta`, :math:`\beta`, :math:`\omega_a`, :math:`\alpha`, :math:`z`.
+
+    Differences that are visible to a user, all documented in DESIGN.md:
+
+    * variates come from counter-based Philox streams keyed per chain, not from one sequential SFC64
+      stream, so draws are equal to the reference's in distribution, not value for value;
+    * the prior term of the :math:`\eta` conditional uses the edge factorisation
+      :math:`Q = B^\top B` instead of a dense eigenfactor (``logit.py:66-67``): no O(n^2) memory, no
+      O(n^3) set-up; ``Q`` must be an ICAR precision (zero row sums, non-positive off-diagonals);
+    * ``device`` selects the HIP device; all chains of one ``sample`` call run batched on it.
+    """
+
+    def __init__(self, Q, W, X, y, hparams=None, random_state=None, device=0):
+        super().__init__(Q, W, X, y, hparams, random_state)
+        self.device = device
+        self._configure(Q, hparams)
+
+    def _configure(self, Q, hparams):
+        super()._configure(Q, hparams)
+
+    # ------------------------------------------------------------------ engine management
+    def _get_engine(self, keys):
+        eng = self.__dict__.get('_engine')
+        if eng is None or eng.n_chains != len(keys):
+            if eng is not None:
+                eng.close()
+            eng = Engine(self._problem, keys, device=self.device)
+            self.__dict__['_engine'] = eng
+        else:
+            eng.set_keys(keys)
+        return eng
+
+    def _push_start(self, eng, chain, state):
+        eng.set_start(chain, np.atleast_1d(np.asarray(state.alpha, dtype=float)),
+                      np.atleast_1d(np.asarray(state.beta, dtype=float)), float(state.tau),
+                      np.asarray(state.eta, dtype=float))
+
+    def _pull_state(self, eng, chain=0):
+        """Mirror the device state of one chain into ``self.state`` (reference attribute names)."""
+        st = self.state
+        st.alpha = eng.get('alpha', chain)
+        st.beta = eng.get('beta', chain)
+        st.tau = float(eng.get('tau', chain))
+        st.eta = eng.get('eta', chain)
+        st.spatial = st.eta
+        st.z = eng.get('z', chain)
+        st.k = st.z - 0.5
+        st.omega_b = eng.get('omega_b', chain)
+        prob = self._problem
+        exists_flag = eng.get('exists', chain).astype(bool)
+        # reference order (logit.py:187-188): sites with a detection first, then newly occupied ones
+        obs = prob.obs_site.astype(bool)
+        order = np.concatenate([np.flatnonzero(obs), np.flatnonzero(exists_flag & ~obs)])
+        st.exists = [prob.surveyed[i] for i in order]
+        rows = [np.arange(prob.site_ptr[i], prob.site_ptr[i + 1]) for i in order]
+        rows = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+        st.omega_a = eng.get('omega_a', chain)[rows]
+        st.W = prob.W[rows]
+
+    # ------------------------------------------------------------------ public stepping (logit.py:254-266)
+    def step(self):
+        """One Gibbs iteration of this sampler's own chain (its state must have start values:
+        ``sample`` sets them, or call ``_initialize_posterior_state`` first, as ``_run`` does)."""
+        if 'alpha' not in self.state.__dict__:
+            self._initialize_posterior_state(None)
+        eng = self.__dict__.get('_engine')
+        if eng is None or eng.n_chains != 1 or not self.__dict__.get('_stepping'):
+            eng = self._get_engine([_philox_key(self.rng)])
+            self._push_start(eng, 0, self.state)
+            eng.set('z', self.state.z, 0)
+            self.__dict__['_stepping'] = True
+        eng.step()
+        self._pull_state(eng, 0)
+
+    # ------------------------------------------------------------------ batched chains
+    def _run_chains(self, samplers, size, burnin=0, start=None, progressbar=True):
+        """All chains of one ``sample`` call as one device batch.
+
+        Mirrors ``GibbsBase._run`` (base.py:214-241) per chain: start values from the chain's own
+        generator (or the ``start`` dict), then ``size`` iterations keeping those ``>= burnin``.
+        """
+        from tqdm.auto import tqdm
+
+        for s in samplers:
+            if s is not self:  # copies share `state` by reference in the reference too; give each its own
+                s.__dict__['state'] = type(self.state)(**self.state.__dict__)
+            s._initialize_posterior_state(start)
+        keys = [_philox_key(s.rng) for s in samplers]
+        self.__dict__['_stepping'] = False
+        eng = self._get_engine(keys)
+        z0 = self._problem.z0
+        for c, s in enumerate(samplers):
+            self._push_start(eng, c, s.state)
+            eng.set('z', z0, c)
+
+        C = len(samplers)
+        keep = size - burnin
+        alpha = np.zeros((C, keep, self._problem.q))
+        beta = np.zeros((C, keep, self._problem.p))
+        tau = np.zeros((C, keep))
+        bars = [tqdm(total=size, disable=not progressbar, position=pos) for pos in range(C)]
+        chunk = size if not progressbar else max(1, min(size, max(16, size // 25)))
+        done = kept = 0
+        while done < size:
+            step = min(chunk, size - done)
+            b = min(max(burnin - done, 0), step)
+            if b == step:  # the whole chunk is burn-in: run it, keep only its last draw, drop it
+                eng.run(step, step - 1)
+            else:
+                a_, b_, t_ = eng.run(step, b)
+                m = step - b
+                alpha[:, kept:kept + m], beta[:, kept:kept + m], tau[:, kept:kept + m] = a_, b_, t_
+                kept += m
+            done += step
+            for bar in bars:
+                bar.update(step)
+        for bar in bars:
+            bar.close()
+
+        chains = []
+        for c, s in enumerate(samplers):
+            ch = Chain._from_arrays({'alpha': alpha[c], 'beta': beta[c], 'tau': tau[c]})
+            s.chain = ch
+            chains.append(ch)
+        self._pull_state(eng, 0)
+        return chains

@@ -1,0 +1,202 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle.  Needs an MI355X: ``-m gpu``.
+
+Bar: every conditional of an iteration, computed from the same state and the same Philox streams,
+agrees with the oracle to FP64 rounding amplified by the solver (stated per quantity below); z and
+the MINRES iteration count agree exactly.
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+KEY = 0x9E3779B97F4A7C15
+
+# relative tolerances (max-norm, relative to the max magnitude of the oracle's vector)
+TOL = {
+    'omega_b': 1e-10, 'omega_a': 1e-10,  # PG(1,z): same accept/reject path, libm-level differences
+    'tau': 1e-11, 'rhs': 1e-11,
+    'xz': 1e-8, 'eta': 1e-8,            # 2n MINRES: rounding in the reductions amplified by the recurrence
+    'beta': 1e-8, 'alpha': 1e-8,
+}
+
+
+def _problem_from_golden(name):
+    from occuspytial_amd._problem import FlatProblem
+    g = load_golden(name)
+    n = g['X'].shape[0]
+    Q = sparse.csr_matrix((g['Q_data'], g['Q_indices'], g['Q_indptr']), shape=(n, n))
+    W, y, cur = {}, {}, 0
+    for s, v in zip(g['sites'], g['visits']):
+        W[int(s)] = g['W_flat'][cur:cur + v]
+        y[int(s)] = g['y_flat'][cur:cur + v]
+        cur += v
+    hp = {k[3:]: g[k] for k in g if k.startswith('hp_')} or None
+    start = dict(alpha=g['start_alpha'], beta=g['start_beta'], tau=float(g['start_tau']), eta=g['start_eta'])
+    return FlatProblem(Q, W, g['X'], y, hp), start
+
+
+def _rel(a, b):
+    a, b = np.atleast_1d(a), np.atleast_1d(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _existing_rows(prob, exists_flag):
+    rows = [np.arange(prob.site_ptr[i], prob.site_ptr[i + 1]) for i in np.flatnonzero(exists_flag)]
+    return np.concatenate(rows) if rows else np.zeros(0, dtype=int)
+
+
+def _compare_iteration(eng, orc, prob, chain=0):
+    worst = {}
+    for name in ('omega_b', 'tau', 'rhs', 'xz', 'eta', 'beta', 'alpha'):
+        worst[name] = _rel(eng.get(name, chain), orc.get(name))
+        assert worst[name] < TOL[name], (name, worst[name])
+    assert int(eng.get('minres_itn', chain)) == int(orc.get('minres_itn'))
+    # the oracle's `exists` is the set used by the omega_a update (z before its own update); the
+    # engine derives `exists` from the current z, i.e. what the NEXT omega_a update will use
+    ex_o = orc.get('exists')
+    rows = _existing_rows(prob, ex_o.astype(bool))
+    z_now = orc.get('z')
+    assert np.array_equal(eng.get('exists', chain),
+                          (prob.obs_site.astype(bool) | (z_now[prob.site_id] != 0)).astype(float))
+    worst['omega_a'] = _rel(eng.get('omega_a', chain)[rows], orc.get('omega_a')[rows])
+    assert worst['omega_a'] < TOL['omega_a']
+    assert np.array_equal(eng.get('z', chain), orc.get('z'))
+    assert np.array_equal(eng.get('k', chain), orc.get('k'))
+    return worst
+
+
+@pytest.mark.parametrize('case', ['ref_queen150_ragged', 'ref_queen150_hparams', 'ref_rook400_v3',
+                                  'ref_queen400_v3', 'ref_graph300_weighted'])
+def test_lockstep_iterations_match_oracle(oracle, case):
+    """Six iterations; after each one every conditional's output is compared, then the engine is
+    re-seated on the oracle's state so that each iteration is tested from identical inputs."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _problem_from_golden(case)
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    for it in range(6):
+        eng.step()
+        orc.step()
+        _compare_iteration(eng, orc, prob)
+        for name in ('alpha', 'beta', 'tau', 'eta', 'z', 'xz'):
+            eng.set(name, orc.get(name))
+    eng.close()
+
+
+def test_free_running_chain_tracks_oracle(oracle):
+    """40 iterations without re-seating: recorded alpha/beta/tau stay together."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _problem_from_golden('ref_queen400_v3')
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    a, b, t = eng.run(40, 5)
+    ao, bo, to = orc.run(40, 5)
+    assert a.shape == (1, 35, prob.q)
+    assert _rel(a[0], ao) < 1e-6 and _rel(b[0], bo) < 1e-6 and _rel(t[0], to) < 1e-6
+    assert np.array_equal(eng.get('z'), orc.get('z'))
+    eng.close()
+
+
+def test_graph_replay_equals_eager_stepping():
+    """occ_run (calibration + hipGraph replay) and occ_step (eager) are the same kernels: bitwise."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _problem_from_golden('ref_queen150_ragged')
+    e1, e2 = Engine(prob, [KEY]), Engine(prob, [KEY])
+    e1.set_start(0, **start)
+    e2.set_start(0, **start)
+    a, b, t = e1.run(25, 0)
+    for i in range(25):
+        e2.step()
+        assert np.array_equal(e2.get('alpha'), a[0, i]) and np.array_equal(e2.get('beta'), b[0, i])
+        assert e2.get('tau') == t[0, i]
+    st = e1.stats()
+    assert st['graph_launches'] >= 20 and st['iterations'] == 25
+    e1.close()
+    e2.close()
+
+
+def test_batched_chains_equal_single_chain_runs():
+    """Chain c of a 3-chain batch == the same key run alone (chains share nothing but the inputs)."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _problem_from_golden('ref_graph300_weighted')
+    keys = [KEY, KEY ^ 0xABCDEF, 12345]
+    rng = np.random.default_rng(3)
+    starts = [dict(alpha=rng.standard_normal(prob.q), beta=rng.standard_normal(prob.p), tau=1.0 + c,
+                   eta=(lambda e: e - e.mean())(rng.standard_normal(prob.n))) for c in range(3)]
+    batch = Engine(prob, keys)
+    for c in range(3):
+        batch.set_start(c, **starts[c])
+    A, B, T = batch.run(20, 4)
+    for c in range(3):
+        solo = Engine(prob, [keys[c]])
+        solo.set_start(0, **starts[c])
+        a, b, t = solo.run(20, 4)
+        assert np.array_equal(a[0], A[c]) and np.array_equal(b[0], B[c]) and np.array_equal(t[0], T[c])
+        assert np.array_equal(solo.get('eta'), batch.get('eta', c))
+        solo.close()
+    batch.close()
+
+
+def test_krylov_cap_overflow_is_resumed_exactly(monkeypatch):
+    """A captured graph with too few Krylov steps carries the unfinished solve into the next replay
+    (same arithmetic, continued), so results equal an unconstrained run bit for bit."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _problem_from_golden('ref_queen150_ragged')
+    ref = Engine(prob, [KEY, KEY + 1])
+    for c in range(2):
+        ref.set_start(c, **start)
+    A, B, T = ref.run(12, 0)
+    monkeypatch.setenv('OCC_FORCE_KRYLOV_CAP', '4')
+    low = Engine(prob, [KEY, KEY + 1])
+    for c in range(2):
+        low.set_start(c, **start)
+    a, b, t = low.run(12, 0)
+    assert low.stats()['stalls'] > 0
+    assert np.array_equal(a, A) and np.array_equal(b, B) and np.array_equal(t, T)
+    ref.close()
+    low.close()
+
+
+def test_eta_solve_at_baseline_size_equals_the_reference_solver_call():
+    """100x100 queen lattice (BASELINE config 2).  scipy is the reference's own dependency and is
+    installed on the GPU box: the engine's joint solve must equal
+    ``scipy.sparse.linalg.minres(P, [y;1], x0=previous)`` (reference logit.py:80-87) on the system the
+    engine built -- same iteration count, same solution -- plus size-independent properties."""
+    from scipy.sparse.linalg import minres
+
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(100, 100, visits=5, p=2, q=2, random_state=0)
+    prob = FlatProblem(Q, W, X, y)
+    rng = np.random.default_rng(1)
+    eng = Engine(prob, [KEY])
+    eta0 = rng.standard_normal(prob.n)
+    eng.set_start(0, rng.standard_normal(2), rng.standard_normal(2), 0.7, eta0 - eta0.mean())
+    n = prob.n
+    x0 = None
+    for _ in range(3):
+        eng.step()
+        eta, xz = eng.get('eta'), eng.get('xz')
+        om, tau, rhs = eng.get('omega_b'), eng.get('tau'), eng.get('rhs')
+        assert abs(eta.sum()) < 1e-8 * np.abs(eta).sum()          # sum-to-zero constraint
+        L = tau * prob.Q + sparse.diags(om)
+        P = sparse.block_diag((L, L), format='csc')
+        cnt = [0]
+        ref_xz, info = minres(P, np.concatenate([rhs, np.ones(n)]), x0=x0,
+                              callback=lambda xk: cnt.__setitem__(0, cnt[0] + 1))
+        assert info == 0 and cnt[0] == int(eng.get('minres_itn'))
+        assert np.abs(xz - ref_xz).max() <= 1e-9 * np.abs(ref_xz).max()
+        x0 = xz
+        z = eng.get('z')
+        assert set(np.unique(z)) <= {0.0, 1.0}
+        assert np.all(z[prob.site_id[prob.obs_site.astype(bool)]] == 1.0)
+        assert tau > 0 and np.all(om > 0)
+    eng.close()

@@ -1,0 +1,161 @@
+// kbench.hip -- developer micro-benchmark: times single kernels of occ_kernels.hpp on a synthetic
+// lattice state, interleaved rounds in one process (not part of the product or the test-suite).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I occuspytial_amd/csrc tools/kbench.hip -o tools/kbench
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "occ_kernels.hpp"
+
+using namespace occ;
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e = (x);                                                         \
+        if (e != hipSuccess) {                                                      \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                  \
+            exit(1);                                                                \
+        }                                                                           \
+    } while (0)
+
+template <class T>
+T *dalloc(size_t n, int fill = 0)
+{
+    T *p;
+    CK(hipMalloc(&p, n * sizeof(T)));
+    CK(hipMemset(p, fill, n * sizeof(T)));
+    return p;
+}
+template <class T>
+T *dup(const std::vector<T> &h)
+{
+    T *p;
+    CK(hipMalloc(&p, h.size() * sizeof(T)));
+    CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+
+int main(int argc, char **argv)
+{
+    const int side = argc > 1 ? atoi(argv[1]) : 100, C = argc > 2 ? atoi(argv[2]) : 4;
+    const int tpb = argc > 3 ? atoi(argv[3]) : 64, V = 5, reps = 200;
+    const int n = side * side, R = n * V, p = 2, q = 2;
+    Ctx c{};
+    c.n = n; c.S = n; c.R = R; c.p = p; c.q = q; c.C = C;
+    c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; c.nb_max = std::max(c.nb_n, c.nb_r);
+    c.maxiter = 10LL * n; c.tau_rate = 0.005; c.tau_shape = 0.5 * n;
+    // queen lattice SELL-64
+    const int nslice = (n + 63) / 64;
+    std::vector<int> sell_ptr(nslice + 1, 0), sell_col((size_t)nslice * 64 * 8);
+    std::vector<double> sell_val((size_t)nslice * 64 * 8, 0.0), qdiag(n, 0.0);
+    for (int s = 0; s <= nslice; ++s) sell_ptr[s] = s * 64 * 8;
+    for (int i = 0; i < nslice * 64; ++i) {
+        int kk = 0;
+        const int sl = i / 64, lane = i % 64, r = i / side, cc = i % side;
+        if (i < n)
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    if (!dr && !dc) continue;
+                    const int rr = r + dr, c2 = cc + dc;
+                    if (rr < 0 || rr >= side || c2 < 0 || c2 >= side) continue;
+                    sell_col[(size_t)sl * 512 + kk * 64 + lane] = rr * side + c2;
+                    sell_val[(size_t)sl * 512 + kk * 64 + lane] = -1.0;
+                    ++kk;
+                }
+        if (i < n) qdiag[i] = kk;
+        for (; kk < 8; ++kk) sell_col[(size_t)sl * 512 + kk * 64 + lane] = std::min(i, n - 1);
+    }
+    std::vector<double> Xt((size_t)n * p), Wt((size_t)R * q), hyp(q * q + q + p * p + p, 0.0);
+    for (int i = 0; i < n; ++i) { Xt[i] = 1.0; Xt[n + i] = ((i * 37) % 100) / 25.0 - 2.0; }
+    for (int r = 0; r < R; ++r) { Wt[r] = 1.0; Wt[R + r] = ((r * 53) % 100) / 25.0 - 2.0; }
+    hyp[0] = hyp[3] = 0.1; hyp[6] = hyp[9] = 0.1;
+    std::vector<uint8_t> yrow(R, 0), obs(n, 0);
+    std::vector<int> row_site(R), sidx(n), sptr(n + 1);
+    for (int i = 0; i < n; ++i) {
+        sidx[i] = i; sptr[i] = i * V;
+        obs[i] = (i % 5) < 2;
+        for (int v = 0; v < V; ++v) { row_site[i * V + v] = i | (obs[i] ? 0x80000000 : 0); yrow[i * V + v] = obs[i] && v == 0; }
+    }
+    sptr[n] = R;
+    c.sell_ptr = dup(sell_ptr); c.sell_col = dup(sell_col); c.sell_val = dup(sell_val); c.qdiag = dup(qdiag);
+    c.Xt = dup(Xt); c.Wt = dup(Wt); c.yrow = dup(yrow); c.row_site = dup(row_site);
+    c.site_sidx = dup(sidx); c.site_ptr = dup(sptr); c.obs_site = dup(obs); c.hyp = dup(hyp);
+    const size_t Cn = (size_t)C * n;
+    c.eta = dalloc<double>(Cn); c.omega_b = dalloc<double>(Cn); c.pre = dalloc<double>(Cn);
+    c.uprior = dalloc<double>(Cn); c.rhs = dalloc<double>(Cn); c.omega_a = dalloc<double>((size_t)C * R);
+    c.z = dalloc<uint8_t>(Cn, 1);
+    for (int b = 0; b < 3; ++b) { c.Rv[b] = dalloc<double2>(Cn); c.Wv[b] = dalloc<double2>(Cn); }
+    c.Xv = dalloc<double2>(Cn);
+    c.part = dalloc<double>((size_t)C * 2 * NACC_MAX * c.nb_max);
+    c.part_proj = dalloc<double>((size_t)C * 2 * c.nb_n);
+    c.slots = dalloc<Slot>((size_t)C * NSLOT);
+    c.sc = dalloc<ChainScalars>(C);
+    c.rec = nullptr;
+    std::vector<ChainScalars> sc(C);
+    memset(sc.data(), 0, sizeof(ChainScalars) * C);
+    for (int ch = 0; ch < C; ++ch) {
+        sc[ch].key = 1234567 + ch; sc[ch].tau = 1.0; sc[ch].it_stop = 1u << 30;
+        sc[ch].alpha[0] = 0.3; sc[ch].alpha[1] = -0.5; sc[ch].beta[0] = 0.2; sc[ch].beta[1] = 0.7;
+    }
+    CK(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
+
+    Ctx *cp; CK(hipMalloc(&cp, sizeof(Ctx))); CK(hipMemcpy(cp, &c, sizeof(Ctx), hipMemcpyHostToDevice));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const dim3 gs(c.nb_n, C), gr(c.nb_r, C), blk(tpb);
+    // a sane mid-solve state
+    hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0);
+    hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0);
+    for (int k = 1; k <= 2; ++k) {
+        hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
+        hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
+    }
+    CK(hipStreamSynchronize(st));
+
+    const bool eager = getenv("KB_EAGER") != nullptr;
+    auto time_graph = [&](const char *name, std::function<void()> one) {
+        if (eager) {  // plain launches (for counter collection, which cannot follow graph launches)
+            for (int r = 0; r < 20; ++r) one();
+            CK(hipStreamSynchronize(st));
+            printf("%-28s eager x20\n", name);
+            return;
+        }
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int r = 0; r < reps; ++r) one();
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, st));
+        float best = 1e30f;
+        for (int round = 0; round < 3; ++round) {
+            CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ge, st)); CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+        printf("%-28s %8.3f us/launch\n", name, 1000.0 * best / reps);
+        hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    };
+    for (int round = 0; round < 2; ++round) {
+        time_graph("minres_a k=3", [&] { hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3); });
+        time_graph("minres_b k=3", [&] { hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3); });
+        time_graph("a+b pair k=3", [&] {
+            hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3);
+            hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3);
+        });
+        time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
+        time_graph("eta_init", [&] { hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
+#ifdef KB_EXTRA
+        KB_EXTRA
+#endif
+    }
+    return 0;
+}
