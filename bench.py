@@ -13,7 +13,7 @@ arrays from rank 0; there is no per-iteration collective.  value = chain-iterati
 max-over-ranks wall time of exactly K timed steps.
 
 The JSON line also carries
-  roofline     : the dominant kernel (k_minres_a, one Krylov half-step of the eta solve): algorithmic
+  roofline     : the dominant kernel (k_minres, one MINRES iteration of the eta solve): algorithmic
                  bytes per launch / its mean launch time, measured live right after the timed region
                  with HIP events on the engine's stream around 200 back-to-back graph-captured launches
                  (occ_profile);
@@ -35,16 +35,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def minres_a_bytes_per_launch(prob, n_chains, sell_entries):
-    """Algorithmic bytes one k_minres_a launch must move (DESIGN.md "Roofline accounting").
+def minres_bytes_per_launch(prob, n_chains, sell_entries):
+    """Algorithmic bytes one k_minres launch (one MINRES iteration of the joint system) must move
+    (DESIGN.md "Roofline accounting").
 
-    per chain and site : reads r2_{k-1}, r2_{k-2}, w_{k-3}, w_{k-2}, x (5 x 16 B) + omega_b (8 B);
-                         writes w_{k-1}, x, y'_k (3 x 16 B)                          -> 136 B
+    per chain and site : reads g_{k-1}, p_{k-2}, p_{k-3}, w_{k-4}, w_{k-3}, x (6 x 16 B) + omega_b (8 B);
+                         writes p_{k-1}, g_k, w_{k-2}, x (4 x 16 B)                   -> 168 B
     shared by the chains: Q diagonal (8 B/site) + SELL-64 off-diagonals (4 B index + 8 B value per
-                         stored entry, padding included)
-    Neighbour gathers of r2 hit lines already counted; partial sums are O(blocks).
+                         stored slot, padding included)
+    Neighbour gathers hit lines already counted; partial sums are O(blocks).
     """
-    return n_chains * prob.n * 136 + prob.n * 8 + sell_entries * 12
+    return n_chains * prob.n * 168 + prob.n * 8 + sell_entries * 12
 
 
 def sell_entry_count(prob):
@@ -152,11 +153,10 @@ def main():
         # ---- roofline of the dominant kernel, live, HIP events on the engine's stream --------------
         prof = eng.profile(reps=200)
         kmean = stats['krylov_mean']
-        per_iter = {'omega_b': 1, 'eta_init': 1, 'minres_a': stats['krylov_cap'] + 1, 'minres_b': stats['krylov_cap'] + 1,
-                    'beta_partial': 1, 'omega_a': 1, 'z': 1}
-        ka = prof['minres_a']
+        per_iter = {'omega_b': 1, 'eta_init': 1, 'minres': stats['krylov_cap'] + 3, 'beta_partial': 1, 'omega_a': 1, 'z': 1}
+        ka = prof['minres']
         sell = sell_entry_count(prob)
-        bytes_launch = minres_a_bytes_per_launch(prob, C, sell)
+        bytes_launch = minres_bytes_per_launch(prob, C, sell)
         achieved = bytes_launch / (ka['avg_us'] * 1e-6) / 1e9 if ka['avg_us'] > 0 else 0.0
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in prof)
         out = {
@@ -184,14 +184,14 @@ def main():
                 'device_ms_last_run': round(stats['last_run_ms'], 3),
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_minres_a',
+                'bound': 'hbm', 'kernel': 'k_minres',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
                 'timing': 'mean of 200 back-to-back launches captured in a hipGraph, HIP events on the engine stream '
                           '(kernel duration + one dependent-launch boundary)',
-                'share_of_iteration_launch_time': round(ka['avg_us'] * per_iter['minres_a'] / total_us, 3) if total_us else None,
+                'share_of_iteration_launch_time': round(ka['avg_us'] * per_iter['minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},
             },
         }

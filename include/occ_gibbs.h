@@ -124,9 +124,9 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 /* Per-kernel launch time in the mode occ_run uses: for each kernel kind, `reps` back-to-back launches
  * of that ONE kernel are captured into a hipGraph and bracketed by two HIP events on the engine's
  * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.
- * kinds: 0 omega_b, 1 eta_init, 2 minres_a, 3 minres_b, 4 beta_partial, 5 omega_a, 6 z.
+ * kinds: 0 omega_b, 1 eta_init, 2 minres, 3 beta_partial, 4 omega_a, 5 z.
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
-#define OCC_N_KERNEL_KINDS 7
+#define OCC_N_KERNEL_KINDS 6
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
 

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libocc_gibbs.so')
 
 OCC_OK = 0
 OCC_E_BADARG, OCC_E_HIP, OCC_E_MINRES, OCC_E_CHOLESKY, OCC_E_STATE = -1, -2, -3, -4, -5
-N_KERNEL_KINDS = 7
-KERNEL_KINDS = ('omega_b', 'eta_init', 'minres_a', 'minres_b', 'beta_partial', 'omega_a', 'z')
+N_KERNEL_KINDS = 6
+KERNEL_KINDS = ('omega_b', 'eta_init', 'minres', 'beta_partial', 'omega_a', 'z')
 
 
 class OccProblem(C.Structure):

@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_ETA_INIT, K_MINRES_A, K_MINRES_B, K_BETA_PARTIAL, K_OMEGA_A, K_Z };
+enum Kind { K_OMEGA_B = 0, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_Z };
 
 }  // namespace
 
@@ -155,8 +155,7 @@ void launch_phase1(occ_sampler *s, int cb, int nc) { launch(s, K_OMEGA_B, k_omeg
 void launch_eta_init(occ_sampler *s, int cb, int nc) { launch(s, K_ETA_INIT, k_eta_init, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb); }
 void launch_krylov(occ_sampler *s, int cb, int nc, int k)
 {
-    launch(s, K_MINRES_A, k_minres_a, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
-    launch(s, K_MINRES_B, k_minres_b, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
+    launch(s, K_MINRES, k_minres, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
 }
 void launch_tail(occ_sampler *s, int cb, int nc, int k_last, int from_phase = 3, int to_phase = 5)
 {
@@ -187,10 +186,10 @@ int eager_krylov(occ_sampler *s, int cb, int nc, int k_from, int *k_last)
     std::vector<Slot> slots((size_t)s->ctx.C * NSLOT);
     for (int k = k_from;; ++k) {
         launch_krylov(s, cb, nc, k);
-        if (k < 2) continue;
+        if (k < 4) continue;
         HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        const int slot = (2 * k) & (NSLOT - 1);
+        const int slot = k & (NSLOT - 1);
         bool all = true;
         for (int c = cb; c < cb + nc; ++c) all = all && slots[(size_t)c * NSLOT + slot].done;
         if (all) {
@@ -221,7 +220,7 @@ int eager_iteration(occ_sampler *s, int cb, int nc)
     int k_last = 0;
     int rc = eager_krylov(s, cb, nc, 1, &k_last);
     if (rc) return rc;
-    s->calib_max = std::max(s->calib_max, k_last - 1);
+    s->calib_max = std::max(s->calib_max, k_last - 3);
     launch_tail(s, cb, nc, k_last);
     s->eager_iterations += 1;
     return OCC_OK;
@@ -235,8 +234,8 @@ void destroy_graph(occ_sampler *s)
     s->graph = nullptr;
 }
 
-// Capture one iteration of all chains with `cap` + 1 Krylov step pairs (the extra pair carries the
-// stopping test of iteration `cap`).  A solve that needs more steps is carried into the next replay
+// Capture one iteration of all chains with `cap` + 3 Krylov launches (iteration j is tested by
+// launch j + 3, once beta_{j+1} and then ||x_j|| have been reduced).  A solve that needs more steps is carried into the next replay
 // by the kernels themselves (Ctl::koff), so `cap` trades empty launches against carried replays.
 int build_graph(occ_sampler *s, int cap)
 {
@@ -245,8 +244,8 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     launch_phase1(s, 0, C);
     launch_eta_init(s, 0, C);
-    for (int k = 1; k <= cap + 1; ++k) launch_krylov(s, 0, C, k);
-    launch_tail(s, 0, C, cap + 1);
+    for (int k = 1; k <= cap + 3; ++k) launch_krylov(s, 0, C, k);
+    launch_tail(s, 0, C, cap + 3);
     HIP_TRY(hipStreamEndCapture(s->stream, &s->graph));
     HIP_TRY(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
     s->krylov_cap = cap;
@@ -423,7 +422,9 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
-    c.nb_max = std::max(c.nb_n, c.nb_r);
+    c.nw_n = c.nb_n * (tpb / 64);
+    c.nw_r = c.nb_r * (tpb / 64);
+    c.nw_max = std::max(c.nw_n, c.nw_r);
 
     // ---- device memory ------------------------------------------------------------------------------
     if ((rc = upload(s, &c.sell_ptr, sell_ptr))) return rc;
@@ -450,13 +451,15 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if ((rc = dev_alloc(s, &c.rhs, Cn))) return rc;
     if ((rc = dev_alloc(s, &c.omega_a, (size_t)C * R))) return rc;
     if ((rc = dev_alloc(s, &c.z, Cn))) return rc;
-    for (int b = 0; b < 3; ++b) {
-        if ((rc = dev_alloc(s, &c.Rv[b], Cn))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = dev_alloc(s, &c.Gv[b], Cn))) return rc;
         if ((rc = dev_alloc(s, &c.Wv[b], Cn))) return rc;
     }
+    for (int b = 0; b < 3; ++b)
+        if ((rc = dev_alloc(s, &c.Pv[b], Cn))) return rc;
     if ((rc = dev_alloc(s, &c.Xv, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.part, (size_t)C * 2 * NACC_MAX * c.nb_max))) return rc;
-    if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part, (size_t)C * 2 * NACC_MAX * c.nw_max))) return rc;
+    if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nw_n))) return rc;
     if ((rc = dev_alloc(s, &c.slots, (size_t)C * NSLOT))) return rc;
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
@@ -813,8 +816,7 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int k_arg, doub
         switch (kind) {
             case K_OMEGA_B: launch_phase1(s, 0, C); break;
             case K_ETA_INIT: launch_eta_init(s, 0, C); break;
-            case K_MINRES_A: launch(s, K_MINRES_A, k_minres_a, grid_sites(s, C), s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, k_arg); break;
-            case K_MINRES_B: launch(s, K_MINRES_B, k_minres_b, grid_sites(s, C), s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, k_arg); break;
+            case K_MINRES: launch_krylov(s, 0, C, k_arg); break;
             case K_BETA_PARTIAL: launch_tail(s, 0, C, k_arg, 3, 3); break;
             case K_OMEGA_A: launch_tail(s, 0, C, k_arg, 4, 4); break;
             default: launch_tail(s, 0, C, k_arg, 5, 5); break;
@@ -858,13 +860,11 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     counts[K_OMEGA_B] = reps; total_us[K_OMEGA_B] = us * reps;
     if ((rc = time_kernel_graph(s, K_ETA_INIT, reps, 0, &us))) return rc;
     counts[K_ETA_INIT] = reps; total_us[K_ETA_INIT] = us * reps;
-    // open a solve and stop mid-way (step 3 is the general step: both w vectors and r2_{k-2} live)
-    launch_krylov(s, 0, C, 1);
-    launch_krylov(s, 0, C, 2);
-    if ((rc = time_kernel_graph(s, K_MINRES_A, reps, 3, &us))) return rc;
-    counts[K_MINRES_A] = reps; total_us[K_MINRES_A] = us * reps;
-    if ((rc = time_kernel_graph(s, K_MINRES_B, reps, 3, &us))) return rc;
-    counts[K_MINRES_B] = reps; total_us[K_MINRES_B] = us * reps;
+    // open a solve and stop mid-way (step 5 is the general step: every vector of the recurrence is live);
+    // repeating one step re-reads the same slot, so the repeated launches all do the full work
+    for (int k = 1; k <= 4; ++k) launch_krylov(s, 0, C, k);
+    if ((rc = time_kernel_graph(s, K_MINRES, reps, 5, &us))) return rc;
+    counts[K_MINRES] = reps; total_us[K_MINRES] = us * reps;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return OCC_OK;
 }

@@ -10,7 +10,7 @@
 //   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials; eta-rhs pieces
 //                  (logit.py:195-204, 208, 213, 75-78)
 //   k_eta_init     tau ~ Gamma (logit.py:206-209); rhs y; r1 = [y;1] - Lambda x0  (logit.py:78-87)
-//   k_minres_a/b   one Lanczos/MINRES iteration of the joint 2n system, two kernels per iteration
+//   k_minres       one Lanczos/MINRES iteration of the joint 2n system per launch
 //                  (scipy _isolve/minres.py as called at logit.py:87)
 //   k_beta_partial eta = x - (sum x / sum z) z (distributions.pyx:24-39); X' Omega X, X'(k - omega eta)
 //   k_omega_a      beta draw (block 0; distributions.pyx:42-110); omega_a ~ PG(1, w'alpha) for rows of
@@ -90,7 +90,8 @@ struct ChainScalars {
 // scalar loads the compiler could not batch -- while a 40-byte argument block is one fetch.
 struct Ctx {
     int n, S, R, p, q, C;
-    int nb_n, nb_r, nb_max;
+    int nb_n, nb_r;          // blocks over sites / visit rows
+    int nw_n, nw_r, nw_max;  // waves over sites / visit rows = number of partial sums per quantity
     long long maxiter;
     // fixed inputs (shared by all chains)
     const int *sell_ptr, *sell_col;
@@ -106,47 +107,78 @@ struct Ctx {
     // per-chain state
     double *eta, *omega_b, *pre, *uprior, *rhs, *omega_a;
     uint8_t *z;
-    double2 *Rv[3], *Wv[3], *Xv;
-    double *part;       // [C][2][NACC_MAX * nb_max]
-    double *part_proj;  // [C][2 * nb_n]
+    double2 *Gv[2], *Pv[3], *Wv[2], *Xv;  // g_m = A p_{m-1}, p_m = r2_m, w_m, x: (x-part, z-part) interleaved
+    double *part;       // [C][2][NACC_MAX * nw_max]
+    double *part_proj;  // [C][2 * nw_n]
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
+// Wave-level sums use DPP row operations (register-to-register, a few cycles each) instead of
+// ds_bpermute shuffles, and leave the total in every lane through v_readlane: no LDS, no barrier.
+// Partial sums are kept per WAVE (not per block), so producing and consuming them needs no
+// __syncthreads at all; every wave of the consumer re-reduces all partials in the same fixed order,
+// which makes the derived scalars bit-identical in every wave, block and run (no float atomics).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;  // lane 0 holds the sum
+    v += dpp_shifted<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_shifted<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_shifted<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_shifted<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_shifted<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_shifted<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave sum
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
 }
 
-// Each block writes one partial per quantity: out[q * nb + blk].  lds: MAX_WAVES * NQ doubles.
+__device__ __forceinline__ int global_wave() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+
+// Each wave writes one partial per quantity: out[q * nw + wave].
 template <int NQ>
-__device__ __forceinline__ void block_partials(const double (&v)[NQ], double *lds, double *out, int nb, int blk)
+__device__ __forceinline__ void wave_partials(const double (&v)[NQ], double *out, int nw)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int gw = global_wave();
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         const double r = wave_sum(v[qi]);
-        if (lane == 0) lds[wave * NQ + qi] = r;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < NQ) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += lds[w * NQ + threadIdx.x];
-        out[threadIdx.x * nb + blk] = s;
+        if ((threadIdx.x & 63) == 0) out[qi * nw + gw] = r;
     }
 }
 
-// Every block reduces all nb partials of nq quantities in the same order -> identical scalars.
-__device__ __forceinline__ void reduce_partials(const double *part, int nq, int nb, double *lds_out)
+// Every wave reduces all nw partials of NQ quantities itself (registers only).
+template <int NQ>
+__device__ __forceinline__ void reduce_partials(const double *part, int nw, double (&out)[NQ])
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int qi = wave; qi < nq; qi += nw) {
+    const int lane = threadIdx.x & 63;
+    double acc[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0;
+    for (int b = lane; b < nw; b += 64) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) acc[qi] += part[qi * nw + b];
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) out[qi] = wave_sum(acc[qi]);
+}
+
+// Runtime quantity count (the p x p / q x q systems): waves share the quantities, results go to LDS.
+__device__ __forceinline__ void reduce_partials_lds(const double *part, int nq, int nw, double *lds_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    for (int qi = wave; qi < nq; qi += nwb) {
         double s = 0.0;
-        for (int b = lane; b < nb; b += 64) s += part[qi * nb + b];
+        for (int b = lane; b < nw; b += 64) s += part[qi * nw + b];
         s = wave_sum(s);
         if (lane == 0) lds_out[qi] = s;
     }
@@ -155,7 +187,7 @@ __device__ __forceinline__ void reduce_partials(const double *part, int nq, int 
 
 __device__ __forceinline__ double *part_buf(const Ctx &c, int chain, int parity)
 {
-    return c.part + ((size_t)chain * 2 + parity) * ((size_t)NACC_MAX * c.nb_max);
+    return c.part + ((size_t)chain * 2 + parity) * ((size_t)NACC_MAX * c.nw_max);
 }
 
 __device__ __forceinline__ double expit(double x)
@@ -222,7 +254,6 @@ __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d):
 // =================================================================================================
 __global__ void __launch_bounds__(256) k_omega_b(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
 {
-    __shared__ double s_w[MAX_WAVES];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
@@ -262,33 +293,29 @@ __global__ void __launch_bounds__(256) k_omega_b(const Ctx *__restrict__ cp, Cha
         c.pre[ci] = b + sqrt(om) * e;
         c.uprior[ci] = u;
     }
-    block_partials<1>(quad, s_w, part_buf(c, chain, 0), c.nb_n, blockIdx.x);
+    wave_partials<1>(quad, part_buf(c, chain, 0), c.nw_n);
 }
 
 __global__ void __launch_bounds__(256) k_eta_init(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
 {
-    __shared__ double s_w[MAX_WAVES], s_red[1], s_tau;
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.cur;
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    reduce_partials(part_buf(c, chain, 0), 1, c.nb_n, s_red);
-    if (threadIdx.x == 0) {
-        const double rate = 0.5 * s_red[0] + c.tau_rate;
-        Cursor g(sc.key, 0u, ctl.it, STREAM_TAU);
-        const double tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
-        s_tau = tau;
-        if (blockIdx.x == 0) {
-            sc.tau = tau;
-            Slot s = {};
-            slot_store(&slots[(size_t)chain * NSLOT], s);
-        }
+    double quad[1];
+    reduce_partials<1>(part_buf(c, chain, 0), c.nw_n, quad);
+    // every lane draws the same tau from the same sub-stream (uniform control flow, no broadcast)
+    const double rate = 0.5 * quad[0] + c.tau_rate;
+    Cursor g(sc.key, 0u, ctl.it, STREAM_TAU);
+    const double tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc.tau = tau;
+        Slot s = {};
+        slot_store(&slots[(size_t)chain * NSLOT], s);
     }
-    __syncthreads();
-    const double tau = s_tau, st = sqrt(tau);
-    double bsq[1] = {0.0};
+    const double st = sqrt(tau);
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double2 *X0 = c.Xv + (size_t)chain * n;
@@ -310,14 +337,12 @@ __global__ void __launch_bounds__(256) k_eta_init(const Ctx *__restrict__ cp, Ch
         double2 r;
         r.x = y - ax;
         r.y = 1.0 - az;
-        c.Rv[0][ci] = r;
-        bsq[0] = r.x * r.x + r.y * r.y;
+        c.Pv[0][ci] = r;
     }
-    block_partials<1>(bsq, s_w, part_buf(c, chain, 1), c.nb_n, blockIdx.x);
 }
 
-// Sum-to-zero projection partials, taken by whichever kernel detects the end of the solve.
-__device__ __forceinline__ void projection_partials(const Ctx &c, int chain, int i, double *lds)
+// Sum-to-zero projection partials, taken by the kernel that detects the end of the solve.
+__device__ __forceinline__ void projection_partials(const Ctx &c, int chain, int i)
 {
     double v[2] = {0.0, 0.0};
     if (i < c.n) {
@@ -325,144 +350,101 @@ __device__ __forceinline__ void projection_partials(const Ctx &c, int chain, int
         v[0] = x.x;
         v[1] = x.y;
     }
-    block_partials<2>(v, lds, c.part_proj + (size_t)chain * 2 * c.nb_n, c.nb_n, blockIdx.x);
+    wave_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n);
 }
 
-// Step 2k-1: finish iteration k-1 (rotation, w and x updates) once beta_k is known, then the
-// Lanczos product of iteration k:  y' = A v_k - (beta_k/beta_{k-1}) r2_{k-2},  alfa_k = v_k . y'.
-__global__ void __launch_bounds__(256) k_minres_a(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_launch)
+constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known (queen lattice: all)
+
+// One MINRES iteration per launch, pipelined so that every inner product is a DIRECT sum (no
+// algebraic shortcut): with p_m = r2_m (scipy's Lanczos residual after iteration m, p_0 = b - A x0) and
+// g_m = A p_{m-1} (unscaled), scipy's iteration m reads
+//     beta_m = ||p_{m-1}||,  v_m = p_{m-1}/beta_m,
+//     alfa_m = v_m . (A v_m - (beta_m/beta_{m-1}) p_{m-2}) = (p_{m-1}.g_m)/beta_m^2 - (p_{m-1}.p_{m-2})/beta_{m-1}
+//     p_m    = g_m/beta_m - (beta_m/beta_{m-1}) p_{m-2} - (alfa_m/beta_m) p_{m-1}.
+// Launch k (k = 1, 2, ...) of a solve:
+//   prologue  slot of launch k-1 + its sums {||p_{k-2}||^2, p_{k-2}.g_{k-1}, p_{k-2}.p_{k-3}, ||x_{k-3}||^2}
+//     (a) k >= 4: stopping test of iteration k-3, exactly scipy's            -> done: projection partials
+//     (b) k >= 2: beta_{k-1}, alfa_{k-1}
+//     (c) k >= 3: rotation of iteration k-2 (needs beta_{k-1})  -> w_{k-2}, x_{k-2}
+//   vectors   p_{k-1} = g_{k-1}/beta_{k-1} - (beta_{k-1}/beta_{k-2}) p_{k-3} - (alfa_{k-1}/beta_{k-1}) p_{k-2}
+//             at the site (stored) and at its neighbours (recomputed from three gathered vectors: this
+//             replaces the grid-wide synchronisation between "form p" and "apply A to p");
+//             g_k = A p_{k-1}
+//   sums      ||p_{k-1}||^2, p_{k-1}.g_k, p_{k-1}.p_{k-2}, ||x_{k-2}||^2
+// Iteration j is therefore tested by launch j+3.  All vector loads are issued before the
+// partial-sum reduction so that their latency overlaps it.
+__global__ void __launch_bounds__(256) k_minres(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_launch)
 {
-    __shared__ double s_w[MAX_WAVES * 2], s_red[2];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.cur;
     if (ctl.it >= sc.it_stop) return;
-    const int k = k_launch + (int)ctl.koff;  // Krylov step of THIS solve (continues across replays)
-    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((2 * k - 2) & (NSLOT - 1))]);
-    Slot *out = &slots[(size_t)chain * NSLOT + ((2 * k - 1) & (NSLOT - 1))];
+    const int k = k_launch + (int)ctl.koff;  // launch number within THIS solve (continues across replays)
+    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((k - 1) & (NSLOT - 1))]);
+    Slot *out = &slots[(size_t)chain * NSLOT + (k & (NSLOT - 1))];
     const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
     if (s.done) {
         if (writer) slot_store(out, s);
         return;
     }
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t ci = (size_t)chain * n + i;
-    reduce_partials(part_buf(c, chain, 1), 1, c.nb_n, s_red);
-    const double bsq = s_red[0];
-    __syncthreads();
-    const double beta_k = sqrt(bsq);
-    const double eps = DBL_EPSILON;
-    double part[2] = {0.0, 0.0};
-    if (k == 1) {
-        if (bsq == 0.0) {  // x0 already solves the system (minres.py: beta1 == 0)
-            s.done = 1;
-            s.istop = 0;
-            s.itn = 0;
-            if (writer) slot_store(out, s);
-            projection_partials(c, chain, i, s_w);
-            return;
+    const size_t co = (size_t)chain * n;
+    const bool act = i < n;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    // p_m lives in Pv[m % 3], g_m in Gv[m & 1], w_m in Wv[m & 1]
+    const double2 *G1 = c.Gv[(k - 1) & 1] + co;              // g_{k-1}
+    const double2 *P2 = c.Pv[(k + 1) % 3] + co;              // p_{k-2}
+    const double2 *P3 = c.Pv[k % 3] + co;                    // p_{k-3}
+    double2 *Pw = c.Pv[(k + 2) % 3] + co, *Gw = c.Gv[k & 1] + co;   // p_{k-1}, g_k
+    double2 *Ww = c.Wv[k & 1] + co;                          // holds w_{k-4}, receives w_{k-2}
+    const double2 *Wr = c.Wv[(k - 1) & 1] + co;              // w_{k-3}
+    double2 g1_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
+    double om = 0.0, qd = 0.0, tau = 0.0;
+    int width = 0, base = 0, lane = 0;
+    int col[NPRE];
+    double val[NPRE];
+    double2 ng[NPRE], n2[NPRE], n3[NPRE];
+    if (act) {
+        const int slice = i >> 6;
+        lane = i & 63;
+        base = c.sell_ptr[slice];
+        width = (c.sell_ptr[slice + 1] - base) >> 6;
+        if (k == 1) p2_i = c.Pv[0][co + i];                  // p_0 (written by k_eta_init) plays p_{k-1}
+        if (k >= 2) { g1_i = G1[i]; p2_i = P2[i]; }
+        if (k >= 3) { p3_i = P3[i]; x = c.Xv[co + i]; }
+        if (k >= 5) w1 = Ww[i];
+        if (k >= 4) w2 = Wr[i];
+        om = c.omega_b[co + i];
+        qd = c.qdiag[i];
+        tau = sc.tau;
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk) {
+            col[kk] = i; val[kk] = 0.0; ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
+            if (kk < width) {
+                col[kk] = c.sell_col[base + kk * 64 + lane];
+                val[kk] = c.sell_val[base + kk * 64 + lane];
+            }
         }
-        s.beta1 = beta_k; s.oldb = 0.0; s.beta = beta_k; s.dbar = 0.0; s.epsln = 0.0;
-        s.phibar = beta_k; s.rhs1 = beta_k; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0;
-        s.gmin = DBL_MAX; s.cs = -1.0; s.sn = 0.0; s.root = 0.0;
-    } else {
-        const int j = k - 1;  // iteration being completed
-        const double beta_j = s.beta;
-        s.oldb = beta_j;
-        s.beta = beta_k;
-        s.tnorm2 += s.alfa * s.alfa + beta_j * beta_j + beta_k * beta_k;
-        if (j == 1 && beta_k / s.beta1 <= 10.0 * eps) s.istop = -1;
-        const double oldeps = s.epsln;
-        const double delta = s.cs * s.dbar + s.sn * s.alfa;
-        const double gbar = s.sn * s.dbar - s.cs * s.alfa;
-        s.epsln = s.sn * beta_k;
-        s.dbar = -s.cs * beta_k;
-        s.root = sqrt(gbar * gbar + s.dbar * s.dbar);
-        double gamma = sqrt(gbar * gbar + beta_k * beta_k);
-        gamma = fmax(gamma, eps);
-        s.cs = gbar / gamma;
-        s.sn = beta_k / gamma;
-        const double phi = s.cs * s.phibar;
-        s.phibar = s.sn * s.phibar;
-        const double denom = 1.0 / gamma;
-        s.gmax = fmax(s.gmax, gamma);
-        s.gmin = fmin(s.gmin, gamma);
-        const double zz = s.rhs1 / gamma;
-        s.rhs1 = s.rhs2 - delta * zz;
-        s.rhs2 = -s.epsln * zz;
-        if (i < n) {
-            const double sj = 1.0 / beta_j;
-            const double2 rjm1 = c.Rv[(j - 1) % 3][ci];  // r2_{j-1}: v_j = s_j * r2_{j-1}
-            double2 w1 = make_double2(0.0, 0.0), w2 = make_double2(0.0, 0.0);
-            if (j - 2 >= 1) w1 = c.Wv[(j - 2) % 3][ci];
-            if (j - 1 >= 1) w2 = c.Wv[(j - 1) % 3][ci];
-            double2 w, x = c.Xv[ci];
-            w.x = (sj * rjm1.x - oldeps * w1.x - delta * w2.x) * denom;
-            w.y = (sj * rjm1.y - oldeps * w1.y - delta * w2.y) * denom;
-            x.x = x.x + phi * w.x;
-            x.y = x.y + phi * w.y;
-            c.Wv[j % 3][ci] = w;
-            c.Xv[ci] = x;
-            part[1] = x.x * x.x + x.y * x.y;
-        }
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk)
+            if (kk < width) {
+                if (k == 1) n2[kk] = c.Pv[0][co + col[kk]];
+                if (k >= 2) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; }
+                if (k >= 3) n3[kk] = P3[col[kk]];
+            }
     }
-    if (i < n) {
-        const double tau = sc.tau;
-        const double sk = 1.0 / beta_k;
-        const double2 *r2 = c.Rv[(k - 1) % 3] + (size_t)chain * n;
-        const double2 ri = r2[i];
-        const double vx = sk * ri.x, vy = sk * ri.y;
-        const double d = tau * c.qdiag[i] + c.omega_b[ci];
-        double yx = d * vx, yy = d * vy;
-        const int slice = i >> 6, lane = i & 63;
-        const int base = c.sell_ptr[slice], width = (c.sell_ptr[slice + 1] - base) >> 6;
-        for (int kk = 0; kk < width; ++kk) {
-            const int j = c.sell_col[base + kk * 64 + lane];
-            const double a = tau * c.sell_val[base + kk * 64 + lane];
-            const double2 rj = r2[j];
-            yx += a * (sk * rj.x);
-            yy += a * (sk * rj.y);
-        }
-        if (k >= 2) {
-            const double f = beta_k / s.oldb;
-            const double2 r1 = c.Rv[(k - 2) % 3][ci];
-            yx = yx - f * r1.x;
-            yy = yy - f * r1.y;
-        }
-        c.Rv[k % 3][ci] = make_double2(yx, yy);
-        part[0] = vx * yx + vy * yy;
-    }
-    if (writer) slot_store(out, s);
-    block_partials<2>(part, s_w, part_buf(c, chain, 0), c.nb_n, blockIdx.x);
-}
-
-// Step 2k: stopping test of iteration k-1 (needs ||x_{k-1}||), then
-//   r2_k = y' - (alfa_k/beta_k) r2_{k-1},  partial ||r2_k||^2.
-__global__ void __launch_bounds__(256) k_minres_b(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_launch)
-{
-    __shared__ double s_w[MAX_WAVES * 2], s_red[2];
-    const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
-    ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.cur;
-    if (ctl.it >= sc.it_stop) return;
-    const int k = k_launch + (int)ctl.koff;
-    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((2 * k - 1) & (NSLOT - 1))]);
-    Slot *out = &slots[(size_t)chain * NSLOT + ((2 * k) & (NSLOT - 1))];
-    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (s.done) {
-        if (writer) slot_store(out, s);
-        return;
-    }
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t ci = (size_t)chain * n + i;
-    reduce_partials(part_buf(c, chain, 0), 2, c.nb_n, s_red);
-    const double alfa = s_red[0], xn2 = s_red[1];
-    __syncthreads();
+    double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     if (k >= 2) {
-        const int j = k - 1;
-        const double eps = DBL_EPSILON, rtol = 1e-5;
+        double S[4];
+        reduce_partials<4>(part_buf(c, chain, k & 1), c.nw_n, S);
+        S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3];
+    }
+    const double eps = DBL_EPSILON;
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    if (k >= 4) {  // (a) stopping test of iteration j = k-3 (minres.py, "Estimate various norms ...")
+        const int j = k - 3;
+        const double rtol = 1e-5;
         const double Anorm = sqrt(s.tnorm2);
         const double ynorm = sqrt(xn2);
         const double epsx = Anorm * ynorm * eps;
@@ -482,41 +464,131 @@ __global__ void __launch_bounds__(256) k_minres_b(const Ctx *__restrict__ cp, Ch
             if (test1 <= rtol) istop = 1;
         }
         if (istop != 0) {
-            s.istop = istop;
-            s.itn = j;
-            s.done = 1;
+            s.istop = istop; s.itn = j; s.done = 1;
             if (writer) slot_store(out, s);
-            projection_partials(c, chain, i, s_w);
+            projection_partials(c, chain, i);
             return;
         }
     }
-    double bsq[1] = {0.0};
-    if (i < n) {
-        const double f = alfa / s.beta;
-        const double2 yp = c.Rv[k % 3][ci], r2 = c.Rv[(k - 1) % 3][ci];
-        double2 y;
-        y.x = yp.x - f * r2.x;
-        y.y = yp.y - f * r2.y;
-        c.Rv[k % 3][ci] = y;
-        bsq[0] = y.x * y.x + y.y * y.y;
+    // coefficients of p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}   (k = 1: p_0 is stored already)
+    double ca = 0.0, cb = 0.0, cc = 0.0;
+    if (k >= 2) {  // (b)
+        if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
+            s.done = 1; s.istop = 0; s.itn = 0;
+            if (writer) slot_store(out, s);
+            projection_partials(c, chain, i);
+            return;
+        }
+        const double beta_km1 = sqrt(S0);      // beta_{k-1}
+        const double beta_km2 = s.beta;        // beta_{k-2} (k >= 3)
+        double alfa_km1 = S1 / S0;             // (p.g)/beta^2
+        if (k >= 3) alfa_km1 = alfa_km1 - S2 / beta_km2;
+        if (k == 2) {
+            s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
+            s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
+            s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
+        } else {  // (c) rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
+            const int j = k - 2;
+            const double alfa = s.alfa, beta_j = beta_km2, beta_n = beta_km1;
+            s.oldb = beta_j;
+            s.tnorm2 += alfa * alfa + beta_j * beta_j + beta_n * beta_n;
+            if (j == 1 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
+            const double oldeps = s.epsln;
+            const double delta = s.cs * s.dbar + s.sn * alfa;
+            const double gbar = s.sn * s.dbar - s.cs * alfa;
+            s.epsln = s.sn * beta_n;
+            s.dbar = -s.cs * beta_n;
+            s.root = sqrt(gbar * gbar + s.dbar * s.dbar);
+            double gamma = sqrt(gbar * gbar + beta_n * beta_n);
+            gamma = fmax(gamma, eps);
+            s.cs = gbar / gamma;
+            s.sn = beta_n / gamma;
+            const double phi = s.cs * s.phibar;
+            s.phibar = s.sn * s.phibar;
+            const double denom = 1.0 / gamma;
+            s.gmax = fmax(s.gmax, gamma);
+            s.gmin = fmin(s.gmin, gamma);
+            const double zz = s.rhs1 / gamma;
+            s.rhs1 = s.rhs2 - delta * zz;
+            s.rhs2 = -s.epsln * zz;
+            if (act) {  // w_j = (v_j - oldeps w_{j-2} - delta w_{j-1}) / gamma, v_j = p_{j-1}/beta_j
+                const double sj = 1.0 / beta_j;
+                double2 w;
+                w.x = (sj * p3_i.x - oldeps * w1.x - delta * w2.x) * denom;
+                w.y = (sj * p3_i.y - oldeps * w1.y - delta * w2.y) * denom;
+                x.x = x.x + phi * w.x;
+                x.y = x.y + phi * w.y;
+                Ww[i] = w;
+                c.Xv[co + i] = x;
+                part[3] = x.x * x.x + x.y * x.y;
+            }
+            cb = beta_km1 / beta_km2;
+        }
+        ca = 1.0 / beta_km1;
+        cc = alfa_km1 / beta_km1;
+        s.beta = beta_km1;
+        s.alfa = alfa_km1;
     }
-    s.alfa = alfa;
     s.itn = k;
+    if (act) {
+        double2 p;  // p_{k-1} at this site
+        if (k == 1) {
+            p = p2_i;
+        } else {
+            p.x = (ca * g1_i.x - cb * p3_i.x) - cc * p2_i.x;
+            p.y = (ca * g1_i.y - cb * p3_i.y) - cc * p2_i.y;
+            Pw[i] = p;
+        }
+        const double d = tau * qd + om;
+        double gx = d * p.x, gy = d * p.y;
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk)
+            if (kk < width) {
+                const double a = tau * val[kk];
+                double2 pj;
+                if (k == 1) {
+                    pj = n2[kk];
+                } else {
+                    pj.x = (ca * ng[kk].x - cb * n3[kk].x) - cc * n2[kk].x;
+                    pj.y = (ca * ng[kk].y - cb * n3[kk].y) - cc * n2[kk].y;
+                }
+                gx += a * pj.x;
+                gy += a * pj.y;
+            }
+        for (int kk = NPRE; kk < width; ++kk) {  // rows longer than the prefetch window
+            const int jn = c.sell_col[base + kk * 64 + lane];
+            const double a = tau * c.sell_val[base + kk * 64 + lane];
+            double2 pj;
+            if (k == 1) {
+                pj = c.Pv[0][co + jn];
+            } else {
+                const double2 gj = G1[jn], q2 = P2[jn];
+                const double2 q3 = (k >= 3) ? P3[jn] : zero2;
+                pj.x = (ca * gj.x - cb * q3.x) - cc * q2.x;
+                pj.y = (ca * gj.y - cb * q3.y) - cc * q2.y;
+            }
+            gx += a * pj.x;
+            gy += a * pj.y;
+        }
+        Gw[i] = make_double2(gx, gy);
+        part[0] = p.x * p.x + p.y * p.y;
+        part[1] = p.x * gx + p.y * gy;
+        if (k >= 2) part[2] = p.x * p2_i.x + p.y * p2_i.y;
+    }
     if (writer) slot_store(out, s);
-    block_partials<1>(bsq, s_w, part_buf(c, chain, 1), c.nb_n, blockIdx.x);
+    wave_partials<4>(part, part_buf(c, chain, (k + 1) & 1), c.nw_n);
 }
 
 template <int P>
 __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_last_launch)
 {
-    __shared__ double s_w[MAX_WAVES * nacc(P)], s_red[2];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.cur;
     // the last Krylov kernel of this launch sequence was step k_last of the solve; its slot is final
     const int k_last = k_last_launch + (int)ctl.koff;
-    const Slot *fin = &slots[(size_t)chain * NSLOT + ((2 * k_last) & (NSLOT - 1))];
+    const Slot *fin = &slots[(size_t)chain * NSLOT + (k_last & (NSLOT - 1))];
     struct { int done, itn, istop; } s = {fin->done, fin->itn, fin->istop};
     const bool skip = ctl.it >= sc.it_stop;
     const bool stall_new = !skip && !s.done;
@@ -535,9 +607,9 @@ __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp
     }
     if (skip || stall_new) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    reduce_partials(c.part_proj + (size_t)chain * 2 * c.nb_n, 2, c.nb_n, s_red);
-    const double a = -s_red[0] / s_red[1];
-    __syncthreads();
+    double sums[2];
+    reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, sums);
+    const double a = -sums[0] / sums[1];
     double acc[nacc(P)];
 #pragma unroll
     for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
@@ -561,13 +633,13 @@ __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
     }
-    block_partials<nacc(P)>(acc, s_w, part_buf(c, chain, 0), c.nb_n, blockIdx.x);
+    wave_partials<nacc(P)>(acc, part_buf(c, chain, 0), c.nw_n);
 }
 
 template <int Q>
 __global__ void __launch_bounds__(256) k_omega_a(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
 {
-    __shared__ double s_w[MAX_WAVES * nacc(Q)], s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
+    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
@@ -576,7 +648,7 @@ __global__ void __launch_bounds__(256) k_omega_a(const Ctx *__restrict__ cp, Cha
     const uint64_t key = sc.key;
     const uint32_t it = ctl.it;
     if (blockIdx.x == 0) {  // beta draw: only k_z needs it, one block suffices (logit.py:232)
-        reduce_partials(part_buf(c, chain, 0), nacc(c.p), c.nb_n, s_red);
+        reduce_partials_lds(part_buf(c, chain, 0), nacc(c.p), c.nw_n, s_red);
         if (threadIdx.x == 0) {
             const double *b_prec = c.hyp + Q * Q + Q, *b_pbm = b_prec + c.p * c.p;
             const bool ok = precision_mvnorm_dev(c.p, s_red, b_prec, b_pbm, key, it, STREAM_BETA, s_U, s_work, sc.beta);
@@ -613,7 +685,7 @@ __global__ void __launch_bounds__(256) k_omega_a(const Ctx *__restrict__ cp, Cha
             for (int a = 0; a < Q; ++a) acc[t++] = w[a] * tt;
         }
     }
-    block_partials<nacc(Q)>(acc, s_w, part_buf(c, chain, 1), c.nb_r, blockIdx.x);
+    wave_partials<nacc(Q)>(acc, part_buf(c, chain, 1), c.nw_r);
 }
 
 __global__ void __launch_bounds__(256) k_z(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
@@ -634,7 +706,7 @@ __global__ void __launch_bounds__(256) k_z(const Ctx *__restrict__ cp, ChainScal
     if (skip) return;
     const uint64_t key = sc.key;
     const uint32_t it = ctl.it;
-    reduce_partials(part_buf(c, chain, 1), nacc(Q), c.nb_r, s_red);
+    reduce_partials_lds(part_buf(c, chain, 1), nacc(Q), c.nw_r, s_red);
     if (threadIdx.x == 0) {
         const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
         const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, key, it, STREAM_ALPHA, s_U, s_work, s_alpha);

@@ -48,7 +48,7 @@ int main(int argc, char **argv)
     const int n = side * side, R = n * V, p = 2, q = 2;
     Ctx c{};
     c.n = n; c.S = n; c.R = R; c.p = p; c.q = q; c.C = C;
-    c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; c.nb_max = std::max(c.nb_n, c.nb_r);
+    c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; c.nw_n = c.nb_n * (tpb / 64); c.nw_r = c.nb_r * (tpb / 64); c.nw_max = std::max(c.nw_n, c.nw_r);
     c.maxiter = 10LL * n; c.tau_rate = 0.005; c.tau_shape = 0.5 * n;
     // queen lattice SELL-64
     const int nslice = (n + 63) / 64;
@@ -90,10 +90,11 @@ int main(int argc, char **argv)
     c.eta = dalloc<double>(Cn); c.omega_b = dalloc<double>(Cn); c.pre = dalloc<double>(Cn);
     c.uprior = dalloc<double>(Cn); c.rhs = dalloc<double>(Cn); c.omega_a = dalloc<double>((size_t)C * R);
     c.z = dalloc<uint8_t>(Cn, 1);
-    for (int b = 0; b < 3; ++b) { c.Rv[b] = dalloc<double2>(Cn); c.Wv[b] = dalloc<double2>(Cn); }
+    for (int b = 0; b < 3; ++b) c.Pv[b] = dalloc<double2>(Cn);
+    for (int b = 0; b < 2; ++b) { c.Gv[b] = dalloc<double2>(Cn); c.Wv[b] = dalloc<double2>(Cn); }
     c.Xv = dalloc<double2>(Cn);
-    c.part = dalloc<double>((size_t)C * 2 * NACC_MAX * c.nb_max);
-    c.part_proj = dalloc<double>((size_t)C * 2 * c.nb_n);
+    c.part = dalloc<double>((size_t)C * 2 * NACC_MAX * c.nw_max);
+    c.part_proj = dalloc<double>((size_t)C * 2 * c.nw_n);
     c.slots = dalloc<Slot>((size_t)C * NSLOT);
     c.sc = dalloc<ChainScalars>(C);
     c.rec = nullptr;
@@ -114,10 +115,7 @@ int main(int argc, char **argv)
     // a sane mid-solve state
     hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0);
     hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0);
-    for (int k = 1; k <= 2; ++k) {
-        hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
-        hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
-    }
+    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
     CK(hipStreamSynchronize(st));
 
     const bool eager = getenv("KB_EAGER") != nullptr;
@@ -145,12 +143,7 @@ int main(int argc, char **argv)
         hipGraphExecDestroy(ge); hipGraphDestroy(g);
     };
     for (int round = 0; round < 2; ++round) {
-        time_graph("minres_a k=3", [&] { hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3); });
-        time_graph("minres_b k=3", [&] { hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3); });
-        time_graph("a+b pair k=3", [&] {
-            hipLaunchKernelGGL(k_minres_a, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3);
-            hipLaunchKernelGGL(k_minres_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 3);
-        });
+        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 5); });
         time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
         time_graph("eta_init", [&] { hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
 #ifdef KB_EXTRA
