@@ -88,7 +88,8 @@ int occ_step(occ_sampler *s);
 /* n_iter iterations of every chain; alpha/beta/tau of iterations >= burnin are recorded:
  * GibbsBase._run's loop (base.py:236-239) for all chains at once (gibbs/parallel.py:38-41).
  * out_alpha: [n_chains][n_iter-burnin][q], out_beta: [..][p], out_tau: [n_chains][n_iter-burnin].
- * After a short calibration the iteration is replayed as a hipGraph. */
+ * After a short calibration the iteration is replayed as a hipGraph (two streams forked and joined
+ * inside the graph: omega_a/alpha overlap the eta solve). */
 int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta,
             double *out_tau);
 
@@ -96,17 +97,10 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
  *   alpha(q) beta(p) tau(1) eta(n) z(n) k(n) omega_b(n) omega_a(R) exists(S) xz(2n) rhs(n)
  *   minres_itn(1) iter(1)
  * occ_get_state copies into out (capacity cap doubles) and stores the length in *len.
- * occ_set_state accepts alpha beta tau eta z omega_b omega_a xz iter. */
+ * occ_set_state accepts alpha beta tau eta z omega_a xz iter (omega_b of the coming iteration is then
+ * redrawn from the new state). */
 int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len);
 int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double *in, int64_t len);
-
-/* Run one kernel group of the iteration in isolation (parity tests against the oracle):
- *   1 omega_b (+ eta right-hand-side pieces)   logit.py:195-204, 213, 75-78
- *   2 tau + eta solve (MINRES, projection)     logit.py:206-209, 80-99
- *   3 eta finalisation + beta system            logit.py:97, 226-231
- *   4 beta draw + omega_a + alpha system        logit.py:232, 180-193, 219-223
- *   5 alpha draw + z + iteration bookkeeping    logit.py:224, 234-252 */
-int occ_phase(occ_sampler *s, int32_t phase);
 
 typedef struct occ_stats {
     int64_t iterations;      /* Gibbs iterations completed (chain 0) */
@@ -124,9 +118,10 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 /* Per-kernel launch time in the mode occ_run uses: for each kernel kind, `reps` back-to-back launches
  * of that ONE kernel are captured into a hipGraph and bracketed by two HIP events on the engine's
  * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.
- * kinds: 0 omega_b, 1 eta_init, 2 minres, 3 beta_partial, 4 omega_a, 5 z.
+ * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 beta_draw, 6 omega_a, 7 alpha_draw,
+ * 8 z_ob (z update + next iteration's omega_b).
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
-#define OCC_N_KERNEL_KINDS 6
+#define OCC_N_KERNEL_KINDS 9
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
 

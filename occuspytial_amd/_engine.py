@@ -74,9 +74,6 @@ class Engine:
     def step(self):
         self._check(self._lib.occ_step(self._h))
 
-    def phase(self, which):
-        self._check(self._lib.occ_phase(self._h, which))
-
     def run(self, n_iter, burnin=0):
         keep = n_iter - burnin
         C_ = self.n_chains

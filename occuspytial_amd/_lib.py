@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libocc_gibbs.so')
 
 OCC_OK = 0
 OCC_E_BADARG, OCC_E_HIP, OCC_E_MINRES, OCC_E_CHOLESKY, OCC_E_STATE = -1, -2, -3, -4, -5
-N_KERNEL_KINDS = 6
-KERNEL_KINDS = ('omega_b', 'eta_init', 'minres', 'beta_partial', 'omega_a', 'z')
+N_KERNEL_KINDS = 9
+KERNEL_KINDS = ('omega_b', 'noise', 'eta_init', 'minres', 'beta_partial', 'beta_draw', 'omega_a', 'alpha_draw', 'z_ob')
 
 
 class OccProblem(C.Structure):
@@ -53,7 +53,6 @@ SYMBOLS = (
     ('occ_get_state', C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64,
                                 C.POINTER(C.c_int64)]),
     ('occ_set_state', C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64]),
-    ('occ_phase', C.c_int, [C.c_void_p, C.c_int32]),
     ('occ_get_stats', C.c_int, [C.c_void_p, C.POINTER(OccStats)]),
     ('occ_profile', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 )

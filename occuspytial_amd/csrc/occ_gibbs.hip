@@ -3,7 +3,6 @@
 // HIP runtime only (no PyTorch, no BLAS/solver libraries).
 #include "../../include/occ_gibbs.h"
 
-#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,20 +21,27 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_Z };
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_BETA_DRAW, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB };
+static_assert(K_Z_OB + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
 
 struct occ_sampler {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    Ctx ctx{};            // host copy of the descriptor
+    hipStream_t stream = nullptr;  // main: eta_init -> minres ... -> beta -> z_ob
+    hipStream_t side = nullptr;    // side: omega_a -> alpha_draw -> noise(t+1), forked/joined inside the graph
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    Ctx ctx{};               // host copy of the descriptor
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
-    // graph replay of one iteration
+    // launch-sequence ("slot") parity: the kernels of the next sequence read ChainScalars::ctl[parity]
+    int parity = 0;
+    // start values / state were just set by the host: omega_b and the noise of the current iteration
+    // have to be produced stand-alone before the first sequence
+    bool need_prologue = true;
+    // graph replay: GRAPH_SLOTS (even) launch sequences per graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int krylov_cap = 0;
@@ -44,20 +50,18 @@ struct occ_sampler {
     int krylov_last = 0;
     double last_run_ms = 0.0;
     int calib_max = 0;
+    unsigned long long seen_tot = 0, seen_sq = 0, seen_solves = 0;  // counters at the last cap decision
     // record buffer (alpha | beta | tau rows of the current occ_run), kept between runs
     double *rec_buf = nullptr;
     size_t rec_cap = 0;
-    // profiling (occ_profile)
-    bool profiling = false;
-    std::vector<hipEvent_t> pev;
-    std::vector<int> pkind;
-    size_t pev_used = 0;
     // host mirrors
     std::vector<int32_t> site_id, site_ptr;
     std::vector<uint8_t> obs_site;
 };
 
 namespace {
+
+constexpr int GRAPH_SLOTS = 2;
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -105,26 +109,16 @@ int fetch(occ_sampler *s, std::vector<T> &h, const T *src, size_t count)
     return OCC_OK;
 }
 
-dim3 grid_sites(const occ_sampler *s, int chains) { return dim3((unsigned)s->ctx.nb_n, (unsigned)chains); }
-dim3 grid_rows(const occ_sampler *s, int chains) { return dim3((unsigned)s->ctx.nb_r, (unsigned)chains); }
-
-template <class K, class... A>
-void launch(occ_sampler *s, int kind, K kernel, dim3 grid, A... args)
+int set_error(occ_sampler *s, int code, const char *msg)
 {
-    if (s->profiling && s->pev_used + 2 <= s->pev.size()) {
-        hipEvent_t a = s->pev[s->pev_used], b = s->pev[s->pev_used + 1];
-        s->pkind.push_back(kind);
-        s->pev_used += 2;
-        hipExtLaunchKernelGGL(kernel, grid, dim3((unsigned)s->tpb), 0, s->stream, a, b, 0, args...);
-    } else {
-        hipLaunchKernelGGL(kernel, grid, dim3((unsigned)s->tpb), 0, s->stream, args...);
-    }
+    s->err = msg;
+    return code;
 }
 
-using KernelCB = void (*)(const Ctx *, ChainScalars *, Slot *, int);
-using KernelCBI = void (*)(const Ctx *, ChainScalars *, Slot *, int, int);
+using KernelE = void (*)(const Ctx *, ChainScalars *, Slot *, int, int);
+using KernelEI = void (*)(const Ctx *, ChainScalars *, Slot *, int, int, int);
 
-KernelCBI pick_beta_partial(int p)
+KernelEI pick_beta_partial(int p)
 {
     switch (p) {
         case 1: return k_beta_partial<1>;
@@ -137,7 +131,7 @@ KernelCBI pick_beta_partial(int p)
         default: return k_beta_partial<8>;
     }
 }
-KernelCB pick_omega_a(int q)
+KernelE pick_omega_a(int q)
 {
     switch (q) {
         case 1: return k_omega_a<1>;
@@ -150,19 +144,24 @@ KernelCB pick_omega_a(int q)
         default: return k_omega_a<8>;
     }
 }
-// ---- kernel groups of one iteration (see occ_phase in the header) -----------------------------
-void launch_phase1(occ_sampler *s, int cb, int nc) { launch(s, K_OMEGA_B, k_omega_b, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb); }
-void launch_eta_init(occ_sampler *s, int cb, int nc) { launch(s, K_ETA_INIT, k_eta_init, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb); }
-void launch_krylov(occ_sampler *s, int cb, int nc, int k)
+
+// ---- single launches (all chains) ----------------------------------------------------------------
+#define OCC_ARGS s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, e
+void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
 {
-    launch(s, K_MINRES, k_minres, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k);
-}
-void launch_tail(occ_sampler *s, int cb, int nc, int k_last, int from_phase = 3, int to_phase = 5)
-{
-    if (from_phase <= 3 && to_phase >= 3)
-        launch(s, K_BETA_PARTIAL, pick_beta_partial(s->ctx.p), grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb, k_last);
-    if (from_phase <= 4 && to_phase >= 4) launch(s, K_OMEGA_A, pick_omega_a(s->ctx.q), grid_rows(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb);
-    if (from_phase <= 5 && to_phase >= 5) launch(s, K_Z, k_z, grid_sites(s, nc), s->ctx_dev, s->ctx.sc, s->ctx.slots, cb);
+    const Ctx &c = s->ctx;
+    const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
+    switch (kind) {
+        case K_OMEGA_B: hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, OCC_ARGS); break;
+        case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra); break;
+        case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, OCC_ARGS); break;
+        case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, OCC_ARGS, extra); break;
+        case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
+        case K_BETA_DRAW: hipLaunchKernelGGL(k_beta_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
+        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
+        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
+        default: hipLaunchKernelGGL(k_z_ob, dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
+    }
 }
 
 int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
@@ -179,30 +178,6 @@ int write_scalars(occ_sampler *s, const std::vector<ChainScalars> &h)
     return OCC_OK;
 }
 
-// Krylov steps from step `k_from` with the host watching the `done` flags; chains [cb, cb+nc).
-// On return *k_last is the last step launched (every chain's final scalars live in its slot).
-int eager_krylov(occ_sampler *s, int cb, int nc, int k_from, int *k_last)
-{
-    std::vector<Slot> slots((size_t)s->ctx.C * NSLOT);
-    for (int k = k_from;; ++k) {
-        launch_krylov(s, cb, nc, k);
-        if (k < 4) continue;
-        HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        const int slot = k & (NSLOT - 1);
-        bool all = true;
-        for (int c = cb; c < cb + nc; ++c) all = all && slots[(size_t)c * NSLOT + slot].done;
-        if (all) {
-            *k_last = k;
-            return OCC_OK;
-        }
-        if ((long long)k > s->ctx.maxiter + 2) {
-            s->err = "MINRES solver did not converge!";
-            return OCC_E_MINRES;
-        }
-    }
-}
-
 int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
 {
     for (size_t c = 0; c < h.size(); ++c) {
@@ -212,50 +187,117 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
     return OCC_OK;
 }
 
-// One eager iteration of chains [cb, cb+nc): host-checked MINRES convergence.
-int eager_iteration(occ_sampler *s, int cb, int nc)
+// omega_b and the right-hand-side noise of the CURRENT iteration, stand-alone (after new start values).
+void launch_prologue(occ_sampler *s)
 {
-    launch_phase1(s, cb, nc);
-    launch_eta_init(s, cb, nc);
+    launch_kind(s, s->stream, K_OMEGA_B, s->parity);
+    launch_kind(s, s->stream, K_NOISE, s->parity, 0);
+    s->need_prologue = false;
+}
+
+// Krylov launches from `k_from` with the host watching the `done` flags.  On return *k_last is the
+// last launch (every chain's final scalars live in slot k_last & 3).
+int eager_krylov(occ_sampler *s, int k_from, int *k_last)
+{
+    std::vector<Slot> slots((size_t)s->ctx.C * NSLOT);
+    for (int k = k_from;; ++k) {
+        launch_kind(s, s->stream, K_MINRES, s->parity, k);
+        if (k < 4) continue;
+        HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        bool all = true;
+        for (int c = 0; c < s->ctx.C; ++c) all = all && slots[(size_t)c * NSLOT + (k & (NSLOT - 1))].done;
+        if (all) {
+            *k_last = k;
+            return OCC_OK;
+        }
+        if ((long long)k > s->ctx.maxiter + 3) return set_error(s, OCC_E_MINRES, "MINRES solver did not converge!");
+    }
+}
+
+// One launch sequence on the main stream only, every kernel in a valid topological order of the DAG
+// (the reference's own order of conditionals, logit.py:254-266, with omega_a/alpha moved up front --
+// their inputs are last iteration's alpha and z).
+int eager_sequence(occ_sampler *s)
+{
+    if (s->need_prologue) launch_prologue(s);
+    const int e = s->parity;
+    launch_kind(s, s->stream, K_OMEGA_A, e);
+    launch_kind(s, s->stream, K_ALPHA_DRAW, e);
+    launch_kind(s, s->stream, K_NOISE, e, 1);
+    launch_kind(s, s->stream, K_ETA_INIT, e);
     int k_last = 0;
-    int rc = eager_krylov(s, cb, nc, 1, &k_last);
+    int rc = eager_krylov(s, 1, &k_last);
     if (rc) return rc;
     s->calib_max = std::max(s->calib_max, k_last - 3);
-    launch_tail(s, cb, nc, k_last);
+    launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
+    launch_kind(s, s->stream, K_BETA_DRAW, e);
+    launch_kind(s, s->stream, K_Z_OB, e);
+    s->parity ^= 1;
     s->eager_iterations += 1;
     return OCC_OK;
 }
 
 void destroy_graph(occ_sampler *s)
 {
-    if (s->exec) hipGraphExecDestroy(s->exec);
-    if (s->graph) hipGraphDestroy(s->graph);
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
     s->exec = nullptr;
     s->graph = nullptr;
 }
 
-// Capture one iteration of all chains with `cap` + 3 Krylov launches (iteration j is tested by
-// launch j + 3, once beta_{j+1} and then ||x_j|| have been reduced).  A solve that needs more steps is carried into the next replay
-// by the kernels themselves (Ctl::koff), so `cap` trades empty launches against carried replays.
+// Capture GRAPH_SLOTS launch sequences.  Per sequence: the side stream forks at the start
+// (omega_a -> alpha_draw -> noise of the next iteration) and joins before k_z_ob; the main stream runs
+// eta_init, `cap` + 3 Krylov launches (iteration j is tested by launch j + 3), beta_partial, beta_draw.
+// A solve that needs more launches is carried into the next sequence by the kernels themselves
+// (Ctl::koff), so `cap` trades empty launches against carried sequences.
 int build_graph(occ_sampler *s, int cap)
 {
     destroy_graph(s);
-    const int C = s->ctx.C;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    launch_phase1(s, 0, C);
-    launch_eta_init(s, 0, C);
-    for (int k = 1; k <= cap + 3; ++k) launch_krylov(s, 0, C, k);
-    launch_tail(s, 0, C, cap + 3);
+    int e = s->parity;
+    for (int slot = 0; slot < GRAPH_SLOTS; ++slot, e ^= 1) {
+        // main chain first, so that the graph executor keeps it on the launch queue (a cross-queue
+        // dependency costs 10-18 us on MI355X; only the side work should pay it)
+        HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+        launch_kind(s, s->stream, K_ETA_INIT, e);
+        for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
+        launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
+        launch_kind(s, s->stream, K_BETA_DRAW, e);
+        if (std::getenv("OCC_NO_SIDE_STREAM")) {  // diagnostic: everything on one stream
+            launch_kind(s, s->stream, K_OMEGA_A, e);
+            launch_kind(s, s->stream, K_ALPHA_DRAW, e);
+            launch_kind(s, s->stream, K_NOISE, e, 1);
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+            launch_kind(s, s->side, K_OMEGA_A, e);
+            launch_kind(s, s->side, K_ALPHA_DRAW, e);
+            launch_kind(s, s->side, K_NOISE, e, 1);
+            HIP_TRY(hipEventRecord(s->ev_join, s->side));
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+        }
+        launch_kind(s, s->stream, K_Z_OB, e);
+    }
     HIP_TRY(hipStreamEndCapture(s->stream, &s->graph));
     HIP_TRY(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
     s->krylov_cap = cap;
     return OCC_OK;
 }
 
-int set_error(occ_sampler *s, int code, const char *msg)
+int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
 {
-    s->err = msg;
-    return code;
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    for (auto &sc : h) {
+        Ctl &ctl = sc.ctl[s->parity];
+        sc.it_base = ctl.it;
+        sc.it_stop = ctl.it + (uint32_t)n_iter;
+        sc.burnin = (uint32_t)burnin;
+        sc.keep = (uint32_t)keep;
+        ctl.koff = 0;
+    }
+    return write_scalars(s, h);
 }
 
 }  // namespace
@@ -277,15 +319,16 @@ const char *occ_last_error(const occ_sampler *s) { return s ? s->err.c_str() : g
 int occ_destroy(occ_sampler *s)
 {
     if (!s) return OCC_OK;
-    hipSetDevice(s->device);
-    if (s->stream) hipStreamSynchronize(s->stream);
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->side) (void)hipStreamSynchronize(s->side);
     destroy_graph(s);
-    for (hipEvent_t e : s->pev) hipEventDestroy(e);
-    for (void *p : s->allocs) hipFree(p);
-    if (s->rec_buf) hipFree(s->rec_buf);
-    if (s->ev0) hipEventDestroy(s->ev0);
-    if (s->ev1) hipEventDestroy(s->ev1);
-    if (s->stream) hipStreamDestroy(s->stream);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->rec_buf) (void)hipFree(s->rec_buf);
+    for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_fork, s->ev_join})
+        if (ev) (void)hipEventDestroy(ev);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return OCC_OK;
 }
@@ -303,8 +346,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
 
     const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q, C = n_chains;
     Ctx &c = s->ctx;
@@ -364,6 +410,15 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             width = std::max(width, cnt);
         }
         sell_ptr[sl + 1] = sell_ptr[sl] + width * 64;
+    }
+    // uniform width (ELL) when the padding it adds is small: the slice base becomes arithmetic
+    {
+        int wmax = 0;
+        for (int sl = 0; sl < nslice; ++sl) wmax = std::max(wmax, (sell_ptr[sl + 1] - sell_ptr[sl]) / 64);
+        const long long ell_slots = (long long)wmax * 64 * nslice;
+        c.ell_w = (wmax > 0 && ell_slots <= (long long)(1.25 * sell_ptr[nslice]) + 64) ? wmax : 0;
+        if (c.ell_w)
+            for (int sl = 0; sl <= nslice; ++sl) sell_ptr[sl] = sl * wmax * 64;
     }
     std::vector<int> sell_col((size_t)sell_ptr[nslice]);
     std::vector<double> sell_val((size_t)sell_ptr[nslice], 0.0);
@@ -445,9 +500,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
 
     const size_t Cn = (size_t)C * n;
     if ((rc = dev_alloc(s, &c.eta, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.omega_b, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.pre, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.uprior, Cn))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = dev_alloc(s, &c.omega_b[b], Cn))) return rc;
+        if ((rc = dev_alloc(s, &c.enorm[b], Cn))) return rc;
+        if ((rc = dev_alloc(s, &c.uprior[b], Cn))) return rc;
+    }
     if ((rc = dev_alloc(s, &c.rhs, Cn))) return rc;
     if ((rc = dev_alloc(s, &c.omega_a, (size_t)C * R))) return rc;
     if ((rc = dev_alloc(s, &c.z, Cn))) return rc;
@@ -458,8 +515,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     for (int b = 0; b < 3; ++b)
         if ((rc = dev_alloc(s, &c.Pv[b], Cn))) return rc;
     if ((rc = dev_alloc(s, &c.Xv, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.part, (size_t)C * 2 * NACC_MAX * c.nw_max))) return rc;
+    if ((rc = dev_alloc(s, &c.part_quad, (size_t)C * c.nw_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_kry, (size_t)C * 2 * 4 * c.nw_n))) return rc;
     if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nw_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_beta, (size_t)C * nacc(p) * c.nw_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_alpha, (size_t)C * nacc(q) * c.nw_r))) return rc;
     if ((rc = dev_alloc(s, &c.slots, (size_t)C * NSLOT))) return rc;
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
@@ -513,14 +573,13 @@ int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const doub
     std::copy(a.begin(), a.end(), sc.alpha);
     std::copy(b.begin(), b.end(), sc.beta);
     sc.tau = tau;
-    sc.next.it = 0; sc.next.koff = 0;
-    sc.cur = sc.next; sc.mid = sc.next;
+    const Ctl fresh = {0u, 0u};
+    sc.ctl[0] = sc.ctl[1] = sc.mid[0] = sc.mid[1] = fresh;
     sc.it_stop = 0; sc.it_base = 0; sc.burnin = 0; sc.keep = 0; sc.err = 0;
     if ((rc = write_scalars(s, h))) return rc;
     HIP_TRY(hipMemcpy(c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
     HIP_TRY(hipMemset(c.Xv + (size_t)chain * c.n, 0, sizeof(double2) * c.n));  // x0 = None (logit.py:71)
-    // z back to its configured value (a fresh _run starts from the constructor's z only on the first
-    // call in the reference; restoring it keeps runs reproducible per seed)
+    s->need_prologue = true;
     return OCC_OK;
 }
 
@@ -532,22 +591,7 @@ int occ_set_keys(occ_sampler *s, const uint64_t *keys)
     int rc = read_scalars(s, h);
     if (rc) return rc;
     for (size_t c = 0; c < h.size(); ++c) h[c].key = keys[c];
-    return write_scalars(s, h);
-}
-
-static int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep, bool same_base_for_all)
-{
-    std::vector<ChainScalars> h;
-    int rc = read_scalars(s, h);
-    if (rc) return rc;
-    for (auto &sc : h) {
-        sc.it_base = sc.next.it;
-        sc.it_stop = sc.next.it + (uint32_t)n_iter;
-        sc.burnin = (uint32_t)burnin;
-        sc.keep = (uint32_t)keep;
-        sc.next.koff = 0;
-    }
-    (void)same_base_for_all;
+    s->need_prologue = true;
     return write_scalars(s, h);
 }
 
@@ -555,37 +599,13 @@ int occ_step(occ_sampler *s)
 {
     if (!s) return OCC_E_BADARG;
     HIP_TRY(hipSetDevice(s->device));
-    int rc = set_window(s, 1, 0, 0, true);
+    int rc = set_window(s, 1, 0, 0);
     if (rc) return rc;
-    if ((rc = eager_iteration(s, 0, s->ctx.C))) return rc;
+    if ((rc = eager_sequence(s))) return rc;
     std::vector<ChainScalars> h;
     if ((rc = read_scalars(s, h))) return rc;
-    s->iterations = h[0].next.it;
+    s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
-    return check_device_errors(s, h);
-}
-
-int occ_phase(occ_sampler *s, int32_t phase)
-{
-    if (!s) return OCC_E_BADARG;
-    HIP_TRY(hipSetDevice(s->device));
-    const int C = s->ctx.C;
-    int rc = OCC_OK;
-    static thread_local int k_last_phase = 0;
-    if (phase == 1) {
-        if ((rc = set_window(s, 1, 0, 0, true))) return rc;
-        launch_phase1(s, 0, C);
-    } else if (phase == 2) {
-        launch_eta_init(s, 0, C);
-        if ((rc = eager_krylov(s, 0, C, 1, &k_last_phase))) return rc;
-    } else if (phase >= 3 && phase <= 5) {
-        launch_tail(s, 0, C, k_last_phase, phase, phase);
-    } else {
-        return set_error(s, OCC_E_BADARG, "phase must be 1..5");
-    }
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    std::vector<ChainScalars> h;
-    if ((rc = read_scalars(s, h))) return rc;
     return check_device_errors(s, h);
 }
 
@@ -608,54 +628,57 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         HIP_TRY(hipMalloc((void **)&s->rec_buf, sizeof(double) * need));
         s->rec_cap = need;
     }
-    double *rec = s->rec_buf;
-    if (c.rec != rec) {
-        c.rec = rec;
+    if (c.rec != s->rec_buf) {
+        c.rec = s->rec_buf;
         HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     }
-    int rc = set_window(s, n_iter, burnin, keep, true);
+    int rc = set_window(s, n_iter, burnin, keep);
+    if (rc) return rc;
     std::vector<ChainScalars> h;
-    auto finish = [&](int code) { return code; };
-    if (rc) return finish(rc);
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
 
-    // calibration (first run only): a few eager iterations measure the Krylov steps a solve needs;
+    // calibration (no graph yet): a few eager sequences measure the Krylov launches a solve needs;
     // the count of the last, warm-started solve sizes the captured graph
     int64_t done_min = 0;
-    int cap = s->krylov_cap;
+    const char *force = std::getenv("OCC_FORCE_KRYLOV_CAP");  // tests
     if (!s->exec) {
         const int64_t n_calib = std::min<int64_t>(n_iter, 3);
         s->calib_max = 0;
         for (int64_t i = 0; i < n_calib; ++i) {
             if (i == n_calib - 1) s->calib_max = 0;
-            if ((rc = eager_iteration(s, 0, C))) return finish(rc);
+            if ((rc = eager_sequence(s))) return rc;
         }
         done_min = n_calib;
-        cap = std::max(4, s->calib_max + 3);
-        if (const char *force = std::getenv("OCC_FORCE_KRYLOV_CAP")) cap = std::max(1, std::atoi(force));  // tests
-        if (done_min < n_iter && (rc = build_graph(s, cap))) return finish(rc);
+        int cap = std::max(4, s->calib_max + 2);
+        if (force) cap = std::max(1, std::atoi(force));
+        if (done_min < n_iter && (rc = build_graph(s, cap))) return rc;
+    } else if (s->need_prologue) {
+        launch_prologue(s);
     }
 
-    const bool forced = std::getenv("OCC_FORCE_KRYLOV_CAP") != nullptr;
     while (done_min < n_iter) {
-        // every replay advances each unfinished chain by one iteration, or (rarely) carries its eta
-        // solve into the next replay; finished chains idle.  No host work inside a batch.
-        const int64_t batch = std::min<int64_t>(n_iter - done_min, s->graph_launches < 64 ? 32 : 256);
+        // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
+        // solve into the next sequence; finished chains idle.  No host work inside a batch.
+        const int64_t left = n_iter - done_min;
+        const int64_t batch = std::min<int64_t>((left + GRAPH_SLOTS - 1) / GRAPH_SLOTS, s->graph_launches < 64 ? 16 : 128);
         for (int64_t b = 0; b < batch; ++b) HIP_TRY(hipGraphLaunch(s->exec, s->stream));
         s->graph_launches += batch;
-        if ((rc = read_scalars(s, h))) return finish(rc);
-        if ((rc = check_device_errors(s, h))) return finish(rc);
+        if ((rc = read_scalars(s, h))) return rc;
+        if ((rc = check_device_errors(s, h))) return rc;
         done_min = n_iter;
         unsigned long long tot = 0, sq = 0, solves = 0;
         for (int ch = 0; ch < C; ++ch) {
-            done_min = std::min<int64_t>(done_min, (int64_t)h[ch].next.it - (int64_t)h[ch].it_base);
+            done_min = std::min<int64_t>(done_min, (int64_t)h[ch].ctl[s->parity].it - (int64_t)h[ch].it_base);
             tot += h[ch].krylov_total; sq += h[ch].krylov_sq_total; solves += h[ch].solves;
         }
-        // re-size the captured solve: about mean + 2 sd of the observed Krylov counts
-        if (!forced && solves >= 32 && done_min < n_iter) {
-            const double mean = (double)tot / solves, var = std::max(0.0, (double)sq / solves - mean * mean);
-            const int want = std::max(4, (int)std::ceil(mean + 2.0 * std::sqrt(var)));
-            if (std::abs(want - s->krylov_cap) >= 2 && (rc = build_graph(s, want))) return finish(rc);
+        // re-size the captured solve from the solves since the last decision: mean + 2.5 sd
+        const unsigned long long ds = solves - s->seen_solves;
+        if (!force && ds >= 32 && done_min < n_iter) {
+            const double mean = (double)(tot - s->seen_tot) / ds;
+            const double var = std::max(0.0, (double)(sq - s->seen_sq) / ds - mean * mean);
+            const int want = std::max(4, (int)std::ceil(mean + 2.5 * std::sqrt(var)));
+            s->seen_tot = tot; s->seen_sq = sq; s->seen_solves = solves;
+            if (want != s->krylov_cap && (rc = build_graph(s, want))) return rc;
         }
     }
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -663,13 +686,13 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     s->last_run_ms = ms;
-    if ((rc = read_scalars(s, h))) return finish(rc);
-    if ((rc = check_device_errors(s, h))) return finish(rc);
-    s->iterations = h[0].next.it;
+    if ((rc = read_scalars(s, h))) return rc;
+    if ((rc = check_device_errors(s, h))) return rc;
+    s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
 
     std::vector<double> host((size_t)C * keep * rw);
-    HIP_TRY(hipMemcpy(host.data(), rec, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host.data(), s->rec_buf, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
     for (int ch = 0; ch < C; ++ch)
         for (int64_t t = 0; t < keep; ++t) {
             const double *row = host.data() + ((size_t)ch * keep + t) * rw;
@@ -677,7 +700,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
             std::copy(row + q, row + q + p, out_beta + ((size_t)ch * keep + t) * p);
             out_tau[(size_t)ch * keep + t] = row[q + p];
         }
-    return finish(OCC_OK);
+    return OCC_OK;
 }
 
 int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len)
@@ -696,8 +719,12 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
         return OCC_OK;
     };
     int rc = OCC_OK;
+    std::vector<ChainScalars> h;
+    if ((rc = read_scalars(s, h))) return rc;
+    const ChainScalars &sc = h[chain];
+    const uint32_t it = sc.ctl[s->parity].it;  // iterations completed
     if (nm == "eta") rc = pull(c.eta + chain * n, n);
-    else if (nm == "omega_b") rc = pull(c.omega_b + chain * n, n);
+    else if (nm == "omega_b") rc = pull(c.omega_b[(it + 1) & 1] + chain * n, n);  // of the last completed iteration
     else if (nm == "omega_a") rc = pull(c.omega_a + chain * R, R);
     else if (nm == "rhs") rc = pull(c.rhs + chain * n, n);
     else if (nm == "z" || nm == "k" || nm == "exists") {
@@ -715,17 +742,12 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
         HIP_TRY(hipMemcpy(x.data(), c.Xv + chain * n, sizeof(double2) * n, hipMemcpyDeviceToHost));
         v.resize(2 * n);
         for (size_t i = 0; i < n; ++i) { v[i] = x[i].x; v[n + i] = x[i].y; }
-    } else {
-        std::vector<ChainScalars> h;
-        if ((rc = read_scalars(s, h))) return rc;
-        const ChainScalars &sc = h[chain];
-        if (nm == "alpha") v.assign(sc.alpha, sc.alpha + c.q);
-        else if (nm == "beta") v.assign(sc.beta, sc.beta + c.p);
-        else if (nm == "tau") v.assign(1, sc.tau);
-        else if (nm == "minres_itn") v.assign(1, (double)sc.minres_itn_last);
-        else if (nm == "iter") v.assign(1, (double)sc.next.it);
-        else return set_error(s, OCC_E_STATE, "unknown state name");
-    }
+    } else if (nm == "alpha") v.assign(sc.alpha, sc.alpha + c.q);
+    else if (nm == "beta") v.assign(sc.beta, sc.beta + c.p);
+    else if (nm == "tau") v.assign(1, sc.tau);
+    else if (nm == "minres_itn") v.assign(1, (double)sc.minres_itn_last);
+    else if (nm == "iter") v.assign(1, (double)it);
+    else return set_error(s, OCC_E_STATE, "unknown state name");
     if (rc) return rc;
     *len = (int64_t)v.size();
     if (out) {
@@ -745,10 +767,9 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
     const std::string nm(name);
     const size_t n = (size_t)c.n, R = (size_t)c.R;
     auto need = [&](size_t want) { return (size_t)len == want; };
-    if (nm == "eta" || nm == "omega_b") {
+    if (nm == "eta") {
         if (!need(n)) return set_error(s, OCC_E_STATE, "wrong length");
-        double *dst = (nm == "eta" ? c.eta : c.omega_b) + chain * n;
-        HIP_TRY(hipMemcpy(dst, in, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.eta + chain * n, in, sizeof(double) * n, hipMemcpyHostToDevice));
     } else if (nm == "omega_a") {
         if (!need(R)) return set_error(s, OCC_E_STATE, "wrong length");
         HIP_TRY(hipMemcpy(c.omega_a + chain * R, in, sizeof(double) * R, hipMemcpyHostToDevice));
@@ -770,10 +791,13 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
         if (nm == "alpha" && need((size_t)c.q)) std::copy(in, in + c.q, sc.alpha);
         else if (nm == "beta" && need((size_t)c.p)) std::copy(in, in + c.p, sc.beta);
         else if (nm == "tau" && need(1)) sc.tau = in[0];
-        else if (nm == "iter" && need(1)) { sc.next.it = (uint32_t)in[0]; sc.cur = sc.next; sc.mid = sc.next; }
-        else return set_error(s, OCC_E_STATE, "unknown state name or wrong length");
+        else if (nm == "iter" && need(1)) {
+            const Ctl fresh = {(uint32_t)in[0], 0u};
+            sc.ctl[0] = sc.ctl[1] = sc.mid[0] = sc.mid[1] = fresh;
+        } else return set_error(s, OCC_E_STATE, "unknown state name or wrong length");
         if ((rc = write_scalars(s, h))) return rc;
     }
+    s->need_prologue = true;  // omega_b of the coming iteration must be redrawn from the new state
     return OCC_OK;
 }
 
@@ -787,7 +811,7 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     unsigned long long tot = 0, solves = 0, carries = 0;
     for (auto &sc : h) { tot += sc.krylov_total; solves += sc.solves; carries += sc.carries; }
     s->stalls = (int64_t)carries;
-    out->iterations = h[0].next.it;
+    out->iterations = h[0].ctl[s->parity].it;
     out->graph_launches = s->graph_launches;
     out->eager_iterations = s->eager_iterations;
     out->stalls = s->stalls;
@@ -802,26 +826,16 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     return OCC_OK;
 }
 
-// Average launch-to-launch time of each kernel kind inside a hipGraph (the mode occ_run uses):
-// `reps` back-to-back launches of ONE kernel are captured into a graph and bracketed by two HIP events
-// on the engine's stream; elapsed / reps = kernel duration + the dependent-launch boundary.  Eager
+// Average launch-to-launch time of one kernel kind inside a hipGraph (the mode occ_run uses): `reps`
+// back-to-back launches of ONE kernel are captured into a graph and bracketed by two HIP events on
+// the engine's stream; elapsed / reps = kernel duration + the dependent-launch boundary.  Eager
 // launches are not representative (idle gaps, end-of-kernel flushes before host copies).
-static int time_kernel_graph(occ_sampler *s, int kind, int reps, int k_arg, double *avg_us)
+static int time_kernel_graph(occ_sampler *s, int kind, int reps, int e, int extra, double *avg_us)
 {
-    const int C = s->ctx.C;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    for (int r = 0; r < reps; ++r) {
-        switch (kind) {
-            case K_OMEGA_B: launch_phase1(s, 0, C); break;
-            case K_ETA_INIT: launch_eta_init(s, 0, C); break;
-            case K_MINRES: launch_krylov(s, 0, C, k_arg); break;
-            case K_BETA_PARTIAL: launch_tail(s, 0, C, k_arg, 3, 3); break;
-            case K_OMEGA_A: launch_tail(s, 0, C, k_arg, 4, 4); break;
-            default: launch_tail(s, 0, C, k_arg, 5, 5); break;
-        }
-    }
+    for (int r = 0; r < reps; ++r) launch_kind(s, s->stream, kind, e, extra);
     HIP_TRY(hipStreamEndCapture(s->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, s->stream));  // untimed: instruction cache, clocks
@@ -832,8 +846,8 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int k_arg, doub
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *avg_us = 1000.0 * ms / reps;
-    hipGraphExecDestroy(exec);
-    hipGraphDestroy(graph);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
     return OCC_OK;
 }
 
@@ -841,31 +855,37 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
 {
     if (!s || reps < 1 || !counts || !total_us) return OCC_E_BADARG;
     HIP_TRY(hipSetDevice(s->device));
-    const int C = s->ctx.C;
-    int rc = set_window(s, 1 << 30, 0, 0, true);  // no chain reaches its stop during the timing loops
+    int rc = set_window(s, 1 << 30, 0, 0);  // no chain reaches its stop during the timing loops
     if (rc) return rc;
-    // a complete eager iteration leaves a finished solve: the tail kernels have real work
-    launch_phase1(s, 0, C);
-    launch_eta_init(s, 0, C);
-    int k_last = 0;
-    if ((rc = eager_krylov(s, 0, C, 1, &k_last))) return rc;
-    const int tail_kinds[3] = {K_BETA_PARTIAL, K_OMEGA_A, K_Z};
+    const int e = s->parity;
     double us = 0.0;
-    for (int kind : tail_kinds) {
-        if ((rc = time_kernel_graph(s, kind, reps, k_last, &us))) return rc;
+    auto timed = [&](int kind, int extra) -> int {
+        int r = time_kernel_graph(s, kind, reps, e, extra, &us);
         counts[kind] = reps;
         total_us[kind] = us * reps;
-    }
-    if ((rc = time_kernel_graph(s, K_OMEGA_B, reps, 0, &us))) return rc;
-    counts[K_OMEGA_B] = reps; total_us[K_OMEGA_B] = us * reps;
-    if ((rc = time_kernel_graph(s, K_ETA_INIT, reps, 0, &us))) return rc;
-    counts[K_ETA_INIT] = reps; total_us[K_ETA_INIT] = us * reps;
-    // open a solve and stop mid-way (step 5 is the general step: every vector of the recurrence is live);
-    // repeating one step re-reads the same slot, so the repeated launches all do the full work
-    for (int k = 1; k <= 4; ++k) launch_krylov(s, 0, C, k);
-    if ((rc = time_kernel_graph(s, K_MINRES, reps, 5, &us))) return rc;
-    counts[K_MINRES] = reps; total_us[K_MINRES] = us * reps;
+        return r;
+    };
+    // kernels that only read the state of the last completed iteration
+    if ((rc = timed(K_OMEGA_B, 0))) return rc;
+    if ((rc = timed(K_NOISE, 0))) return rc;
+    if ((rc = timed(K_OMEGA_A, 0))) return rc;
+    if ((rc = timed(K_ALPHA_DRAW, 0))) return rc;
+    if ((rc = timed(K_ETA_INIT, 0))) return rc;
+    // open a solve and stop mid-way (launch 5 is the general step: every vector of the recurrence is
+    // live); repeating one launch re-reads the same slot, so the repeated launches all do the full work
+    for (int k = 1; k <= 4; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
+    if ((rc = timed(K_MINRES, 5))) return rc;
+    // finish that solve so that the tail kernels have real work
+    int k_last = 0;
+    launch_kind(s, s->stream, K_ETA_INIT, e);
+    if ((rc = eager_krylov(s, 1, &k_last))) return rc;
+    if ((rc = timed(K_BETA_PARTIAL, k_last))) return rc;
+    if ((rc = timed(K_BETA_DRAW, 0))) return rc;
+    // k_z_ob advances the control word of the OTHER parity; launched repeatedly with the same parity
+    // it redoes the same z update and omega_b draw
+    if ((rc = timed(K_Z_OB, 0))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->need_prologue = true;
     return OCC_OK;
 }
 

@@ -1,21 +1,33 @@
 // occ_kernels.hpp -- the Gibbs iteration as gfx950 kernels (chains batched on blockIdx.y).
 //
-// One Gibbs iteration of LogitICARGibbs.step() (occuspytial/gibbs/logit.py:254-266) is a fixed
-// sequence of small kernels; a kernel boundary is the only grid-wide synchronisation used (cheaper on
-// MI355X than any in-kernel all-to-all).  Global sums are "reduce at the consumer":
-// every block writes one partial per quantity, and the NEXT kernel's blocks each re-reduce all
-// partials in the same fixed order, so scalars are bit-identical across blocks and runs (no float
-// atomics anywhere).
+// One Gibbs iteration of LogitICARGibbs.step() (occuspytial/gibbs/logit.py:254-266) is a small DAG of
+// kernels; a kernel boundary is the only grid-wide synchronisation used (cheaper on MI355X than any
+// in-kernel all-to-all).  Global sums are "reduce at the consumer": every wave writes one
+// partial per quantity, and every wave of the NEXT kernel re-reduces all partials in the same fixed
+// order, so scalars are bit-identical everywhere and in every run (no float atomics anywhere).
 //
-//   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials; eta-rhs pieces
-//                  (logit.py:195-204, 208, 213, 75-78)
-//   k_eta_init     tau ~ Gamma (logit.py:206-209); rhs y; r1 = [y;1] - Lambda x0  (logit.py:78-87)
+// The reference's order is omega_b, tau, eta, beta, omega_a, alpha, z.  omega_a/alpha of iteration t
+// read only alpha and z of iteration t-1, and the next iteration's omega_b reads only beta and eta of
+// iteration t, so (with counter-based variates, results do not depend on execution order):
+//
+//   main stream  k_eta_init -> k_minres x (cap+3) -> k_beta_partial -> k_beta_draw -> k_z_ob
+//   side stream  k_omega_a -> k_alpha_draw -> k_noise(t+1)        (joined before k_z_ob)
+//
+//   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials (logit.py:195-204, 208);
+//                  stand-alone only for the first iteration after new start values -- afterwards it is
+//                  the second role of k_z_ob
+//   k_noise        the variates of the eta right-hand side that depend on nothing but the iteration
+//                  number: site normals and the edge form of the ICAR prior term (logit.py:75-77)
+//   k_eta_init     tau ~ Gamma (logit.py:206-209); rhs y (logit.py:213, 78); r1 = [y;1] - Lambda x0
 //   k_minres       one Lanczos/MINRES iteration of the joint 2n system per launch
 //                  (scipy _isolve/minres.py as called at logit.py:87)
 //   k_beta_partial eta = x - (sum x / sum z) z (distributions.pyx:24-39); X' Omega X, X'(k - omega eta)
-//   k_omega_a      beta draw (block 0; distributions.pyx:42-110); omega_a ~ PG(1, w'alpha) for rows of
-//                  existing sites; W' Omega W, W'(y - 1/2)   (logit.py:180-193, 219-223)
-//   k_z            alpha draw; z update (logit.py:234-252); record (alpha, beta, tau) (base.py:238-239)
+//   k_beta_draw    beta ~ N(A^-1 r, A^-1) (logit.py:232, distributions.pyx:42-110), one wave per chain
+//   k_omega_a      omega_a ~ PG(1, w'alpha) for rows of existing sites; W' Omega W, W'(y - 1/2)
+//                  (logit.py:180-193, 219-223)
+//   k_alpha_draw   alpha draw (logit.py:224), one wave per chain
+//   k_z_ob         role 0: z update (logit.py:234-252), record (alpha, beta, tau) (base.py:238-239),
+//                  advance the iteration; role 1 (other half of the grid): omega_b of the NEXT iteration
 #pragma once
 #include <float.h>
 #include <hip/hip_runtime.h>
@@ -68,16 +80,20 @@ __device__ __forceinline__ void slot_store(Slot *p, const Slot &s)
 
 struct Ctl {
     uint32_t it;    // Gibbs iteration number (Philox counter word 2)
-    uint32_t koff;  // Krylov steps already spent on the current eta solve by earlier graph replays:
-                    // 0 normally; > 0 when a replay ran out of captured steps and the NEXT replay
+    uint32_t koff;  // Krylov launches already spent on the current eta solve by earlier graph replays:
+                    // 0 normally; > 0 when a replay ran out of captured launches and the NEXT replay
                     // continues the same solve (no host involvement, same arithmetic)
 };
 
+// Control words are handed over between kernels, never updated in place: the kernels of launch
+// sequence ("slot") number s read ctl[s & 1]; k_z_ob, the last kernel of the slot, writes ctl[(s+1) & 1];
+// k_beta_partial publishes the carry decision of the slot in mid[s & 1].  No kernel reads a word that
+// another block of the same kernel writes.
 struct ChainScalars {
     double alpha[MAXC], beta[MAXC];
     double tau;
     uint64_t key;
-    Ctl next, cur, mid;  // written by k_z / k_omega_b / k_beta_partial respectively (race-free hand-over)
+    Ctl ctl[2], mid[2];
     uint32_t it_stop, it_base, burnin, keep;
     int32_t err;               // OCC_E_* raised on device
     int32_t minres_itn_last;
@@ -94,6 +110,7 @@ struct Ctx {
     int nw_n, nw_r, nw_max;  // waves over sites / visit rows = number of partial sums per quantity
     long long maxiter;
     // fixed inputs (shared by all chains)
+    int ell_w;  // > 0: every 64-row slice has this width (uniform ELL): slice base is arithmetic, no sell_ptr load
     const int *sell_ptr, *sell_col;
     const double *sell_val, *qdiag;
     const double *Xt, *Wt;
@@ -104,12 +121,18 @@ struct Ctx {
     const uint8_t *obs_site;
     const double *hyp;  // a_prec[q*q], a_prec_by_mu[q], b_prec[p*p], b_prec_by_mu[p]
     double tau_rate, tau_shape;
-    // per-chain state
-    double *eta, *omega_b, *pre, *uprior, *rhs, *omega_a;
+    // per-chain state ([2] = double-buffered by the parity of the ITERATION number they belong to)
+    double *eta, *rhs, *omega_a;
+    double *omega_b[2];           // omega_b of iteration t in omega_b[t & 1]
+    double *enorm[2], *uprior[2]; // site normals and edge prior term of iteration t in [t & 1]
     uint8_t *z;
     double2 *Gv[2], *Pv[3], *Wv[2], *Xv;  // g_m = A p_{m-1}, p_m = r2_m, w_m, x: (x-part, z-part) interleaved
-    double *part;       // [C][2][NACC_MAX * nw_max]
-    double *part_proj;  // [C][2 * nw_n]
+    // per-wave partial sums (one region per producer, so that independent kernels may overlap)
+    double *part_quad;   // [C][nw_n]            eta'Q eta            k_omega_b -> k_eta_init
+    double *part_kry;    // [C][2][4 nw_n]       MINRES sums          k_minres  -> k_minres
+    double *part_proj;   // [C][2 nw_n]          sum x, sum z         k_minres  -> k_beta_partial
+    double *part_beta;   // [C][nacc(p) nw_n]    X'OX, X'(k - o eta)  k_beta_partial -> k_beta_draw
+    double *part_alpha;  // [C][nacc(q) nw_r]    W'OW, W'(y - 1/2)    k_omega_a -> k_alpha_draw
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
@@ -185,9 +208,22 @@ __device__ __forceinline__ void reduce_partials_lds(const double *part, int nq, 
     __syncthreads();
 }
 
-__device__ __forceinline__ double *part_buf(const Ctx &c, int chain, int parity)
+// Off-diagonal slots of the 64-row slice that holds site i: first slot and number of slots per row.
+__device__ __forceinline__ void slice_of(const Ctx &c, int i, int &base, int &width)
 {
-    return c.part + ((size_t)chain * 2 + parity) * ((size_t)NACC_MAX * c.nw_max);
+    const int slice = i >> 6;
+    if (c.ell_w > 0) {
+        width = c.ell_w;
+        base = slice * c.ell_w * 64;
+    } else {
+        base = c.sell_ptr[slice];
+        width = (c.sell_ptr[slice + 1] - base) >> 6;
+    }
+}
+
+__device__ __forceinline__ double *kry_buf(const Ctx &c, int chain, int parity)
+{
+    return c.part_kry + ((size_t)chain * 2 + parity) * ((size_t)4 * c.nw_n);
 }
 
 __device__ __forceinline__ double expit(double x)
@@ -252,63 +288,92 @@ __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d):
 }
 
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_omega_b(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
+#define OCC_KARGS const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int e
+
+// omega_b ~ PG(1, x_i'beta + eta_i) of iteration `it` into omega_b[it & 1], and the partials of eta'Q eta
+// (logit.py:195-204, 208).  `blk` is the block index within the role's own grid.
+__device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int blk)
 {
-    const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
-    ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.next;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc.cur = ctl;
-    if (ctl.koff || ctl.it >= sc.it_stop) return;  // mid-solve chains skip straight to the Krylov steps
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t key = sc.key;
-    const uint32_t it = ctl.it;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     double quad[1] = {0.0};
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double *eta = c.eta + (size_t)chain * n;
         const double xb = xdot(c.Xt, n, i, sc.beta, c.p);
         const double eta_i = eta[i];
-        Cursor cur(key, (uint32_t)i, it, STREAM_OMEGA_B);
-        const double om = pg1_draw(cur, xb + eta_i);
-        c.omega_b[ci] = om;
-        const int slice = i >> 6, lane = i & 63;
-        const int base = c.sell_ptr[slice], width = (c.sell_ptr[slice + 1] - base) >> 6;
-        double qe = c.qdiag[i] * eta_i, u = 0.0;
-        for (int k = 0; k < width; ++k) {
-            const int j = c.sell_col[base + k * 64 + lane];
-            const double v = c.sell_val[base + k * 64 + lane];
-            qe += v * eta[j];
-            const double w = -v;
-            if (w > 0.0) {
-                const uint32_t lo = (uint32_t)min(i, j), hi = (uint32_t)max(i, j);
-                const double t = sqrt(w) * block_normal(key, lo, hi, it, STREAM_ETA_EDGE);
-                u += (i < j) ? t : -t;
-            }
-        }
+        Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
+        c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
+        const int lane = i & 63;
+        int base, width;
+        slice_of(c, i, base, width);
+        double qe = c.qdiag[i] * eta_i;
+        for (int k = 0; k < width; ++k) qe += c.sell_val[base + k * 64 + lane] * eta[c.sell_col[base + k * 64 + lane]];
         quad[0] = eta_i * qe;
-        const double kz = (double)c.z[ci] - 0.5;
-        const double b = kz - om * xb;
-        const double e = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_SITE);
-        c.pre[ci] = b + sqrt(om) * e;
-        c.uprior[ci] = u;
     }
-    wave_partials<1>(quad, part_buf(c, chain, 0), c.nw_n);
+    const int gw = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const double r = wave_sum(quad[0]);
+    if ((threadIdx.x & 63) == 0) c.part_quad[(size_t)chain * c.nw_n + gw] = r;
 }
 
-__global__ void __launch_bounds__(256) k_eta_init(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
+// Stand-alone omega_b of the CURRENT iteration: only needed when the start values or the state were
+// just set by the host (afterwards k_z_ob's second role has already produced it).
+__global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const int chain = chain_base + blockIdx.y;
+    const ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    omega_b_body(c, sc, chain, ctl.it, blockIdx.x);
+}
+
+// Variates of the eta right-hand side that depend only on (key, iteration): the site normals eps_1
+// (logit.py:75-76) and u = B'eps, the edge form of the prior term E (sqrt(tau) eps_2) (logit.py:66-67,
+// 77; Q = B'B with B the weighted incidence matrix, so u ~ N(0, Q) like E eps_2).  Written for iteration
+// ctl.it + ahead into buffer [(it + ahead) & 1]; runs on the side stream, off the critical path.
+__global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
+{
+    const Ctx &c = *cp;
+    const int chain = chain_base + blockIdx.y;
+    const ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t it = ctl.it + (uint32_t)ahead;
+    const uint64_t key = sc.key;
+    const int lane = i & 63;
+    int base, width;
+    slice_of(c, i, base, width);
+    double u = 0.0;
+    for (int k = 0; k < width; ++k) {
+        const int j = c.sell_col[base + k * 64 + lane];
+        const double w = -c.sell_val[base + k * 64 + lane];
+        if (w > 0.0) {
+            const uint32_t lo = (uint32_t)min(i, j), hi = (uint32_t)max(i, j);
+            const double t = sqrt(w) * block_normal(key, lo, hi, it, STREAM_ETA_EDGE);
+            u += (i < j) ? t : -t;
+        }
+    }
+    const size_t ci = (size_t)chain * n + i;
+    c.uprior[it & 1][ci] = u;
+    c.enorm[it & 1][ci] = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_SITE);
+}
+
+__global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 {
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.cur;
+    const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t it = ctl.it;
     double quad[1];
-    reduce_partials<1>(part_buf(c, chain, 0), c.nw_n, quad);
+    reduce_partials<1>(c.part_quad + (size_t)chain * c.nw_n, c.nw_n, quad);
     // every lane draws the same tau from the same sub-stream (uniform control flow, no broadcast)
     const double rate = 0.5 * quad[0] + c.tau_rate;
-    Cursor g(sc.key, 0u, ctl.it, STREAM_TAU);
+    Cursor g(sc.key, 0u, it, STREAM_TAU);
     const double tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc.tau = tau;
@@ -319,14 +384,17 @@ __global__ void __launch_bounds__(256) k_eta_init(const Ctx *__restrict__ cp, Ch
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double2 *X0 = c.Xv + (size_t)chain * n;
-        const double y = c.pre[ci] + st * c.uprior[ci];
+        const double om = c.omega_b[it & 1][ci];
+        const double xb = xdot(c.Xt, n, i, sc.beta, c.p);
+        const double b = ((double)c.z[ci] - 0.5) - om * xb;                 // logit.py:213
+        const double y = (b + sqrt(om) * c.enorm[it & 1][ci]) + st * c.uprior[it & 1][ci];  // logit.py:76-78
         c.rhs[ci] = y;
-        const double om = c.omega_b[ci];
         const double2 x0 = X0[i];
         const double d = tau * c.qdiag[i] + om;
         double ax = d * x0.x, az = d * x0.y;
-        const int slice = i >> 6, lane = i & 63;
-        const int base = c.sell_ptr[slice], width = (c.sell_ptr[slice + 1] - base) >> 6;
+        const int lane = i & 63;
+        int base, width;
+        slice_of(c, i, base, width);
         for (int k = 0; k < width; ++k) {
             const int j = c.sell_col[base + k * 64 + lane];
             const double a = tau * c.sell_val[base + k * 64 + lane];
@@ -353,6 +421,12 @@ __device__ __forceinline__ void projection_partials(const Ctx &c, int chain, int
     wave_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n);
 }
 
+// Diagnostic builds (tools/kbench.hip) define OCC_STAMP to record s_memtime at a few points of
+// k_minres; in the product build it expands to nothing.
+#ifndef OCC_STAMP
+#define OCC_STAMP(n)
+#endif
+
 constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known (queen lattice: all)
 
 // One MINRES iteration per launch, pipelined so that every inner product is a DIRECT sum (no
@@ -373,25 +447,46 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 //   sums      ||p_{k-1}||^2, p_{k-1}.g_k, p_{k-1}.p_{k-2}, ||x_{k-2}||^2
 // Iteration j is therefore tested by launch j+3.  All vector loads are issued before the
 // partial-sum reduction so that their latency overlaps it.
-__global__ void __launch_bounds__(256) k_minres(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_launch)
+__global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
 {
+    OCC_STAMP(0)
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.cur;
-    if (ctl.it >= sc.it_stop) return;
-    const int k = k_launch + (int)ctl.koff;  // launch number within THIS solve (continues across replays)
-    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((k - 1) & (NSLOT - 1))]);
-    Slot *out = &slots[(size_t)chain * NSLOT + (k & (NSLOT - 1))];
+    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < n;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    // Loads that do not depend on the solve's state go out first, before any branch: control words,
+    // the slot (indexed by the LAUNCH number: a carried solve finds its slot copied to slot 0 by
+    // k_beta_partial), and this site's neighbour indices/values.
+    const Ctl ctl = sc.ctl[e];
+    const unsigned it_stop = sc.it_stop;
+    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((k_launch - 1) & (NSLOT - 1))]);
+    Slot *out = &slots[(size_t)chain * NSLOT + (k_launch & (NSLOT - 1))];
+    int width = 0, base = 0, lane = i & 63;
+    int col[NPRE];
+    double val[NPRE];
+    double om = 0.0, qd = 0.0;
+    if (act) {
+        slice_of(c, i, base, width);
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk) {
+            col[kk] = i; val[kk] = 0.0;
+            if (kk < width) {
+                col[kk] = c.sell_col[base + kk * 64 + lane];
+                val[kk] = c.sell_val[base + kk * 64 + lane];
+            }
+        }
+        qd = c.qdiag[i];
+    }
+    if (ctl.it >= it_stop) return;
     const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
     if (s.done) {
         if (writer) slot_store(out, s);
         return;
     }
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = k_launch + (int)ctl.koff;  // step within THIS solve (continues across graph replays)
     const size_t co = (size_t)chain * n;
-    const bool act = i < n;
-    const double2 zero2 = make_double2(0.0, 0.0);
     // p_m lives in Pv[m % 3], g_m in Gv[m & 1], w_m in Wv[m & 1]
     const double2 *G1 = c.Gv[(k - 1) & 1] + co;              // g_{k-1}
     const double2 *P2 = c.Pv[(k + 1) % 3] + co;              // p_{k-2}
@@ -400,46 +495,34 @@ __global__ void __launch_bounds__(256) k_minres(const Ctx *__restrict__ cp, Chai
     double2 *Ww = c.Wv[k & 1] + co;                          // holds w_{k-4}, receives w_{k-2}
     const double2 *Wr = c.Wv[(k - 1) & 1] + co;              // w_{k-3}
     double2 g1_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
-    double om = 0.0, qd = 0.0, tau = 0.0;
-    int width = 0, base = 0, lane = 0;
-    int col[NPRE];
-    double val[NPRE];
+    double tau = 0.0;
     double2 ng[NPRE], n2[NPRE], n3[NPRE];
     if (act) {
-        const int slice = i >> 6;
-        lane = i & 63;
-        base = c.sell_ptr[slice];
-        width = (c.sell_ptr[slice + 1] - base) >> 6;
         if (k == 1) p2_i = c.Pv[0][co + i];                  // p_0 (written by k_eta_init) plays p_{k-1}
         if (k >= 2) { g1_i = G1[i]; p2_i = P2[i]; }
         if (k >= 3) { p3_i = P3[i]; x = c.Xv[co + i]; }
         if (k >= 5) w1 = Ww[i];
         if (k >= 4) w2 = Wr[i];
-        om = c.omega_b[co + i];
-        qd = c.qdiag[i];
+        om = c.omega_b[ctl.it & 1][co + i];
         tau = sc.tau;
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk) {
-            col[kk] = i; val[kk] = 0.0; ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
-            if (kk < width) {
-                col[kk] = c.sell_col[base + kk * 64 + lane];
-                val[kk] = c.sell_val[base + kk * 64 + lane];
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < NPRE; ++kk)
+            ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
             if (kk < width) {
                 if (k == 1) n2[kk] = c.Pv[0][co + col[kk]];
                 if (k >= 2) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; }
                 if (k >= 3) n3[kk] = P3[col[kk]];
             }
+        }
     }
+    OCC_STAMP(1)
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     if (k >= 2) {
         double S[4];
-        reduce_partials<4>(part_buf(c, chain, k & 1), c.nw_n, S);
+        reduce_partials<4>(kry_buf(c, chain, k & 1), c.nw_n, S);
         S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3];
     }
+    OCC_STAMP(2)
     const double eps = DBL_EPSILON;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
     if (k >= 4) {  // (a) stopping test of iteration j = k-3 (minres.py, "Estimate various norms ...")
@@ -530,6 +613,7 @@ __global__ void __launch_bounds__(256) k_minres(const Ctx *__restrict__ cp, Chai
         s.alfa = alfa_km1;
     }
     s.itn = k;
+    OCC_STAMP(3)
     if (act) {
         double2 p;  // p_{k-1} at this site
         if (k == 1) {
@@ -575,28 +659,32 @@ __global__ void __launch_bounds__(256) k_minres(const Ctx *__restrict__ cp, Chai
         part[1] = p.x * gx + p.y * gy;
         if (k >= 2) part[2] = p.x * p2_i.x + p.y * p2_i.y;
     }
+    OCC_STAMP(4)
     if (writer) slot_store(out, s);
-    wave_partials<4>(part, part_buf(c, chain, (k + 1) & 1), c.nw_n);
+    wave_partials<4>(part, kry_buf(c, chain, (k + 1) & 1), c.nw_n);
+    OCC_STAMP(5)
 }
 
 template <int P>
-__global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int k_last_launch)
+__global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_launch)
 {
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.cur;
-    // the last Krylov kernel of this launch sequence was step k_last of the solve; its slot is final
-    const int k_last = k_last_launch + (int)ctl.koff;
-    const Slot *fin = &slots[(size_t)chain * NSLOT + (k_last & (NSLOT - 1))];
+    const Ctl ctl = sc.ctl[e];
+    // the last Krylov kernel of this launch sequence wrote slot k_last_launch & 3
+    const Slot *fin = &slots[(size_t)chain * NSLOT + (k_last_launch & (NSLOT - 1))];
     struct { int done, itn, istop; } s = {fin->done, fin->itn, fin->istop};
     const bool skip = ctl.it >= sc.it_stop;
-    const bool stall_new = !skip && !s.done;
+    const bool carry = !skip && !s.done;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         Ctl m = ctl;
-        m.koff = stall_new ? (uint32_t)k_last : 0u;  // carry the solve into the next replay
-        sc.mid = m;
-        if (stall_new) sc.carries += 1ull;
+        m.koff = carry ? (uint32_t)(k_last_launch + (int)ctl.koff) : 0u;  // carry the solve into the next replay
+        sc.mid[e] = m;
+        if (carry) {  // the next replay's first Krylov launch reads slot 0
+            sc.carries += 1ull;
+            if ((k_last_launch & (NSLOT - 1)) != 0) slot_store(&slots[(size_t)chain * NSLOT], slot_load(fin));
+        }
         if (!skip && s.done) {
             sc.minres_itn_last = s.itn;
             sc.krylov_total += (unsigned long long)s.itn;
@@ -605,7 +693,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp
             if (s.istop == 6) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
         }
     }
-    if (skip || stall_new) return;
+    if (skip || carry) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
     double sums[2];
     reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, sums);
@@ -618,7 +706,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp
         const double2 xz = c.Xv[ci];
         const double eta = xz.x + a * xz.y;
         c.eta[ci] = eta;
-        const double om = c.omega_b[ci];
+        const double om = c.omega_b[ctl.it & 1][ci];
         const double tt = ((double)c.z[ci] - 0.5) - om * eta;
         double x[P];
 #pragma unroll
@@ -633,28 +721,37 @@ __global__ void __launch_bounds__(256) k_beta_partial(const Ctx *__restrict__ cp
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
     }
-    wave_partials<nacc(P)>(acc, part_buf(c, chain, 0), c.nw_n);
+    wave_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n);
 }
 
-template <int Q>
-__global__ void __launch_bounds__(256) k_omega_a(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
+// beta ~ N(A^-1 r, A^-1) from the partial sums of k_beta_partial (logit.py:232): one wave per chain.
+__global__ void __launch_bounds__(64) k_beta_draw(OCC_KARGS)
 {
     __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.mid;
+    const Ctl ctl = sc.mid[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const int P = c.p, Q = c.q;
+    reduce_partials_lds(c.part_beta + (size_t)chain * nacc(P) * c.nw_n, nacc(P), c.nw_n, s_red);
+    if (threadIdx.x == 0) {
+        const double *b_prec = c.hyp + Q * Q + Q, *b_pbm = b_prec + P * P;
+        const bool ok = precision_mvnorm_dev(P, s_red, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, s_U, s_work, sc.beta);
+        if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+    }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const int chain = chain_base + blockIdx.y;
+    const ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const uint64_t key = sc.key;
     const uint32_t it = ctl.it;
-    if (blockIdx.x == 0) {  // beta draw: only k_z needs it, one block suffices (logit.py:232)
-        reduce_partials_lds(part_buf(c, chain, 0), nacc(c.p), c.nw_n, s_red);
-        if (threadIdx.x == 0) {
-            const double *b_prec = c.hyp + Q * Q + Q, *b_pbm = b_prec + c.p * c.p;
-            const bool ok = precision_mvnorm_dev(c.p, s_red, b_prec, b_pbm, key, it, STREAM_BETA, s_U, s_work, sc.beta);
-            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
-        }
-    }
     const int R = c.R, r = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[nacc(Q)];
 #pragma unroll
@@ -685,52 +782,67 @@ __global__ void __launch_bounds__(256) k_omega_a(const Ctx *__restrict__ cp, Cha
             for (int a = 0; a < Q; ++a) acc[t++] = w[a] * tt;
         }
     }
-    wave_partials<nacc(Q)>(acc, part_buf(c, chain, 1), c.nw_r);
+    wave_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, c.nw_r);
 }
 
-__global__ void __launch_bounds__(256) k_z(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base)
+// alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one wave per chain.
+__global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
 {
-    __shared__ double s_red[NACC_MAX], s_alpha[MAXC], s_U[MAXC * MAXC], s_work[2 * MAXC];
+    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const Ctx &c = *cp;
-    const int Q = c.q;
-    const int chain = chain_base + blockIdx.y;
+    const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.mid;
-    const bool skip = ctl.koff || ctl.it >= sc.it_stop;
-    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (writer) {
-        Ctl nx = ctl;  // a mid-solve chain keeps its iteration number and its koff
-        if (!skip) nx.it = ctl.it + 1;
-        sc.next = nx;
-    }
-    if (skip) return;
-    const uint64_t key = sc.key;
-    const uint32_t it = ctl.it;
-    reduce_partials_lds(part_buf(c, chain, 1), nacc(Q), c.nw_r, s_red);
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const int Q = c.q;
+    reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, nacc(Q), c.nw_r, s_red);
     if (threadIdx.x == 0) {
         const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
-        const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, key, it, STREAM_ALPHA, s_U, s_work, s_alpha);
-        const double *alpha = s_alpha;
-        if (blockIdx.x == 0) {
-            if (!ok) sc.err = -4;
-            for (int a = 0; a < Q; ++a) sc.alpha[a] = alpha[a];
+        const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
+        if (!ok) sc.err = -4;
+    }
+}
+
+// Last kernel of a launch sequence.  Blocks [0, nb_n): z update of the current iteration (logit.py:234-252),
+// record (alpha, beta, tau) (base.py:238-239), hand the control word to the next sequence.  Blocks
+// [nb_n, 2 nb_n): omega_b of the NEXT iteration, which needs only beta and eta of this one -- one launch,
+// two independent roles, so the two run concurrently without a second stream.
+__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const int chain = chain_base + blockIdx.y;
+    ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.mid[e];
+    const bool skip = ctl.koff || ctl.it >= sc.it_stop;
+    const int nb = c.nb_n;
+    if ((int)blockIdx.x >= nb) {  // role 1
+        if (!skip) omega_b_body(c, sc, chain, ctl.it + 1u, (int)blockIdx.x - nb);
+        return;
+    }
+    const uint32_t it = ctl.it;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Ctl nx = ctl;  // a mid-solve chain keeps its iteration number and its koff
+        if (!skip) nx.it = it + 1;
+        sc.ctl[e ^ 1] = nx;
+        if (!skip) {
             const uint32_t rel = it - sc.it_base;
             if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
-                const int P = c.p;
+                const int P = c.p, Q = c.q;
                 double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
-                for (int a = 0; a < Q; ++a) row[a] = alpha[a];
+                for (int a = 0; a < Q; ++a) row[a] = sc.alpha[a];
                 for (int a = 0; a < P; ++a) row[Q + a] = sc.beta[a];
                 row[Q + P] = sc.tau;
             }
         }
     }
-    __syncthreads();
+    if (skip) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int sidx = c.site_sidx[i];
     const bool not_surveyed = sidx < 0;
     if (!not_surveyed && c.obs_site[sidx]) return;  // detection seen: z stays 1 (base.py:116-118)
     const size_t ci = (size_t)chain * n + i;
+    const int Q = c.q;
     const double num1 = expit(xdot(c.Xt, n, i, sc.beta, c.p) + c.eta[ci]);
     double pr = num1;
     if (!not_surveyed) {
@@ -738,14 +850,14 @@ __global__ void __launch_bounds__(256) k_z(const Ctx *__restrict__ cp, ChainScal
         const int r0 = c.site_ptr[sidx], r1 = c.site_ptr[sidx + 1];
         for (int r = r0; r < r1; ++r) {
             double wa = 0.0;
-            for (int a = 0; a < Q; ++a) wa += c.Wt[(size_t)a * c.R + r] * (-s_alpha[a]);
-            const double e = expit(wa);
-            prod = (r == r0) ? e : prod * e;
+            for (int a = 0; a < Q; ++a) wa += c.Wt[(size_t)a * c.R + r] * (-sc.alpha[a]);
+            const double ex = expit(wa);
+            prod = (r == r0) ? ex : prod * ex;
         }
         const double num = num1 * prod;
         pr = num / ((1.0 - num1) + num);
     }
-    const double u = block_uniform(key, (uint32_t)i, 0, it, STREAM_Z);
+    const double u = block_uniform(sc.key, (uint32_t)i, 0, it, STREAM_Z);
     c.z[ci] = (u < pr) ? 1 : 0;
 }
 

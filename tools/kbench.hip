@@ -11,9 +11,18 @@
 #include <string>
 #include <vector>
 
+__device__ unsigned long long g_stamp[8 * 8192];
+#define OCC_STAMP(n) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if ((threadIdx.x & 63) == 0) g_stamp[(blockIdx.y * gridDim.x * (blockDim.x >> 6) + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + n] = t_; }
 #include "occ_kernels.hpp"
 
 using namespace occ;
+__global__ void k_empty(const Ctx *cp, ChainScalars *scs, Slot *slots, int chain_base, int e, int k) {}
+__global__ void k_ctl_only(const Ctx *cp, ChainScalars *scs, Slot *slots, int chain_base, int e, int k, double *sink)
+{
+    const Ctl ctl = scs[chain_base + blockIdx.y].ctl[e];
+    if (ctl.it == 0xffffffffu) sink[0] = 1.0;
+}
 
 #define CK(x)                                                                       \
     do {                                                                            \
@@ -49,7 +58,7 @@ int main(int argc, char **argv)
     Ctx c{};
     c.n = n; c.S = n; c.R = R; c.p = p; c.q = q; c.C = C;
     c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; c.nw_n = c.nb_n * (tpb / 64); c.nw_r = c.nb_r * (tpb / 64); c.nw_max = std::max(c.nw_n, c.nw_r);
-    c.maxiter = 10LL * n; c.tau_rate = 0.005; c.tau_shape = 0.5 * n;
+    c.maxiter = 10LL * n; c.ell_w = 8; c.tau_rate = 0.005; c.tau_shape = 0.5 * n;
     // queen lattice SELL-64
     const int nslice = (n + 63) / 64;
     std::vector<int> sell_ptr(nslice + 1, 0), sell_col((size_t)nslice * 64 * 8);
@@ -87,14 +96,15 @@ int main(int argc, char **argv)
     c.Xt = dup(Xt); c.Wt = dup(Wt); c.yrow = dup(yrow); c.row_site = dup(row_site);
     c.site_sidx = dup(sidx); c.site_ptr = dup(sptr); c.obs_site = dup(obs); c.hyp = dup(hyp);
     const size_t Cn = (size_t)C * n;
-    c.eta = dalloc<double>(Cn); c.omega_b = dalloc<double>(Cn); c.pre = dalloc<double>(Cn);
-    c.uprior = dalloc<double>(Cn); c.rhs = dalloc<double>(Cn); c.omega_a = dalloc<double>((size_t)C * R);
+    c.eta = dalloc<double>(Cn); c.rhs = dalloc<double>(Cn); c.omega_a = dalloc<double>((size_t)C * R);
+    for (int b = 0; b < 2; ++b) { c.omega_b[b] = dalloc<double>(Cn); c.enorm[b] = dalloc<double>(Cn); c.uprior[b] = dalloc<double>(Cn); }
     c.z = dalloc<uint8_t>(Cn, 1);
     for (int b = 0; b < 3; ++b) c.Pv[b] = dalloc<double2>(Cn);
     for (int b = 0; b < 2; ++b) { c.Gv[b] = dalloc<double2>(Cn); c.Wv[b] = dalloc<double2>(Cn); }
     c.Xv = dalloc<double2>(Cn);
-    c.part = dalloc<double>((size_t)C * 2 * NACC_MAX * c.nw_max);
-    c.part_proj = dalloc<double>((size_t)C * 2 * c.nw_n);
+    c.part_quad = dalloc<double>((size_t)C * c.nw_n); c.part_kry = dalloc<double>((size_t)C * 8 * c.nw_n);
+    c.part_proj = dalloc<double>((size_t)C * 2 * c.nw_n); c.part_beta = dalloc<double>((size_t)C * nacc(p) * c.nw_n);
+    c.part_alpha = dalloc<double>((size_t)C * nacc(q) * c.nw_r);
     c.slots = dalloc<Slot>((size_t)C * NSLOT);
     c.sc = dalloc<ChainScalars>(C);
     c.rec = nullptr;
@@ -113,9 +123,10 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 gs(c.nb_n, C), gr(c.nb_r, C), blk(tpb);
     // a sane mid-solve state
-    hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0);
-    hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0);
-    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, k);
+    hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
+    hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 0);
+    hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
+    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, k);
     CK(hipStreamSynchronize(st));
 
     const bool eager = getenv("KB_EAGER") != nullptr;
@@ -142,10 +153,26 @@ int main(int argc, char **argv)
         printf("%-28s %8.3f us/launch\n", name, 1000.0 * best / reps);
         hipGraphExecDestroy(ge); hipGraphDestroy(g);
     };
+    {
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(8 * 8192);
+        CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp), h.size() * 8));
+        const int nw = c.nw_n * C;
+        double m[6] = {0};
+        for (int w = 0; w < nw; ++w) for (int q2 = 1; q2 < 6; ++q2) m[q2] += (double)(h[w * 8 + q2] - h[w * 8]);
+        printf("k_minres stamps (mean cycles since wave start; NOTE stamps drain the memory queues): loads landed %.0f | sums reduced %.0f | scalars %.0f | vector math %.0f | partials written %.0f\n",
+               m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw);
+    }
     for (int round = 0; round < 2; ++round) {
-        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 5); });
-        time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
-        time_graph("eta_init", [&] { hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0); });
+        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
+        time_graph("empty kernel", [&] { hipLaunchKernelGGL(k_empty, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
+        time_graph("empty kernel 1 block", [&] { hipLaunchKernelGGL(k_empty, dim3(1), blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
+        time_graph("ctl-only kernel", [&] { hipLaunchKernelGGL(k_ctl_only, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5, (double *)c.rhs); });
+        time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
+        time_graph("eta_init", [&] { hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
+        time_graph("noise", [&] { hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 1); });
+        time_graph("omega_a", [&] { hipLaunchKernelGGL(k_omega_a<2>, gr, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
 #ifdef KB_EXTRA
         KB_EXTRA
 #endif
