@@ -33,6 +33,7 @@ struct occ_sampler {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     Ctx ctx{};               // host copy of the descriptor
     Ctx *ctx_dev = nullptr;  // the copy kernels read
+    KryArgs kry{};           // by-value argument block of k_minres
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
@@ -155,7 +156,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_OMEGA_B: hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, OCC_ARGS); break;
-        case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, OCC_ARGS, extra); break;
+        case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_BETA_DRAW: hipLaunchKernelGGL(k_beta_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
@@ -533,6 +534,15 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     std::memset(sc.data(), 0, sizeof(ChainScalars) * sc.size());
     for (int ch = 0; ch < C; ++ch) sc[ch].key = keys[ch];
     HIP_TRY(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
+    {
+        KryArgs &k = s->kry;
+        k.n = c.n; k.nw_n = c.nw_n; k.ell_w = c.ell_w; k.pad = 0; k.maxiter = c.maxiter;
+        k.sell_ptr = c.sell_ptr; k.sell_col = c.sell_col; k.sell_val = c.sell_val; k.qdiag = c.qdiag;
+        k.omega_b[0] = c.omega_b[0]; k.omega_b[1] = c.omega_b[1];
+        for (int b = 0; b < 2; ++b) { k.Gv[b] = c.Gv[b]; k.Wv[b] = c.Wv[b]; }
+        for (int b = 0; b < 3; ++b) k.Pv[b] = c.Pv[b];
+        k.Xv = c.Xv; k.part_kry = c.part_kry; k.part_proj = c.part_proj; k.scs = c.sc; k.slots = c.slots;
+    }
     if ((rc = dev_alloc(s, &s->ctx_dev, 1, false))) return rc;
     HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());

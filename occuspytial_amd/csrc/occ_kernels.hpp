@@ -221,10 +221,7 @@ __device__ __forceinline__ void slice_of(const Ctx &c, int i, int &base, int &wi
     }
 }
 
-__device__ __forceinline__ double *kry_buf(const Ctx &c, int chain, int parity)
-{
-    return c.part_kry + ((size_t)chain * 2 + parity) * ((size_t)4 * c.nw_n);
-}
+
 
 __device__ __forceinline__ double expit(double x)
 {
@@ -410,7 +407,8 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 }
 
 // Sum-to-zero projection partials, taken by the kernel that detects the end of the solve.
-__device__ __forceinline__ void projection_partials(const Ctx &c, int chain, int i)
+template <class A>
+__device__ __forceinline__ void projection_partials(const A &c, int chain, int i)
 {
     double v[2] = {0.0, 0.0};
     if (i < c.n) {
@@ -447,37 +445,88 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 //   sums      ||p_{k-1}||^2, p_{k-1}.g_k, p_{k-1}.p_{k-2}, ||x_{k-2}||^2
 // Iteration j is therefore tested by launch j+3.  All vector loads are issued before the
 // partial-sum reduction so that their latency overlaps it.
-__global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
+// Everything k_minres needs to form its addresses, BY VALUE in the kernel argument block: with the
+// pointers in device memory every launch paid one more dependent (cache-cold) load level.
+struct KryArgs {
+    int n, nw_n, ell_w, pad;
+    long long maxiter;
+    const int *sell_ptr, *sell_col;
+    const double *sell_val, *qdiag;
+    const double *omega_b[2];
+    double2 *Gv[2], *Pv[3], *Wv[2], *Xv;
+    double *part_kry, *part_proj;
+    ChainScalars *scs;
+    Slot *slots;
+};
+
+// Buffers, slot and partial-sum parity are indexed by the LAUNCH number k_launch (a kernel argument),
+// not by the step number of the solve, so that no address depends on a value loaded from memory: the
+// dependent chain of a launch is  kernel arguments -> {control word, slot, partial sums, neighbour
+// indices} -> {own vectors, neighbour gathers}.  A solve carried into the next launch sequence is
+// re-aligned to launch number 1 by k_beta_partial (realign_carried_solve).
+__global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base, int e, int k_launch)
 {
     OCC_STAMP(0)
-    const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.y;
-    ChainScalars &sc = scs[chain];
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const ChainScalars &sc = a.scs[chain];
+    const int n = a.n, i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n;
+    const size_t co = (size_t)chain * n;
     const double2 zero2 = make_double2(0.0, 0.0);
-    // Loads that do not depend on the solve's state go out first, before any branch: control words,
-    // the slot (indexed by the LAUNCH number: a carried solve finds its slot copied to slot 0 by
-    // k_beta_partial), and this site's neighbour indices/values.
+    const int kl = k_launch;
+    // ---- level 1: everything whose address is known from the kernel arguments --------------------
     const Ctl ctl = sc.ctl[e];
     const unsigned it_stop = sc.it_stop;
-    Slot s = slot_load(&slots[(size_t)chain * NSLOT + ((k_launch - 1) & (NSLOT - 1))]);
-    Slot *out = &slots[(size_t)chain * NSLOT + (k_launch & (NSLOT - 1))];
-    int width = 0, base = 0, lane = i & 63;
+    const double tau = sc.tau;
+    Slot s = slot_load(&a.slots[(size_t)chain * NSLOT + ((kl - 1) & (NSLOT - 1))]);
+    Slot *out = &a.slots[(size_t)chain * NSLOT + (kl & (NSLOT - 1))];
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nw_n);
+        const int lane = threadIdx.x & 63;
+        for (int b = lane; b < a.nw_n; b += 64) {
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) S[qi] += part[qi * a.nw_n + b];
+        }
+    }
+    int width = 0, base = 0;
+    const int lane = i & 63;
     int col[NPRE];
     double val[NPRE];
-    double om = 0.0, qd = 0.0;
+    double qd = 0.0, om0 = 0.0, om1 = 0.0;
     if (act) {
-        slice_of(c, i, base, width);
+        const int slice = i >> 6;
+        if (a.ell_w > 0) { width = a.ell_w; base = slice * a.ell_w * 64; }
+        else { base = a.sell_ptr[slice]; width = (a.sell_ptr[slice + 1] - base) >> 6; }
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk) {
             col[kk] = i; val[kk] = 0.0;
             if (kk < width) {
-                col[kk] = c.sell_col[base + kk * 64 + lane];
-                val[kk] = c.sell_val[base + kk * 64 + lane];
+                col[kk] = a.sell_col[base + kk * 64 + lane];
+                val[kk] = a.sell_val[base + kk * 64 + lane];
             }
         }
-        qd = c.qdiag[i];
+        qd = a.qdiag[i];
+        om0 = a.omega_b[0][co + i];
+        om1 = a.omega_b[1][co + i];
+    }
+    // ---- level 2: own vectors and neighbour gathers (addresses from k_launch and col[]) ----------
+    // p_m lives in Pv[m' % 3], g_m in Gv[m' & 1], w_m in Wv[m' & 1] with m' counted in launches
+    const double2 *G1 = a.Gv[(kl - 1) & 1] + co;                  // g_{k-1}
+    const double2 *P2 = a.Pv[(kl + 1) % 3] + co;                  // p_{k-2}
+    const double2 *P3 = a.Pv[kl % 3] + co;                        // p_{k-3}
+    double2 *Pw = a.Pv[(kl + 2) % 3] + co, *Gw = a.Gv[kl & 1] + co;   // p_{k-1}, g_k
+    double2 *Ww = a.Wv[kl & 1] + co;                              // holds w_{k-4}, receives w_{k-2}
+    const double2 *Wr = a.Wv[(kl - 1) & 1] + co;                  // w_{k-3}
+    double2 g1_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
+    double2 ng[NPRE], n2[NPRE], n3[NPRE];
+    if (act) {
+        g1_i = G1[i]; p2_i = P2[i]; p3_i = P3[i]; x = a.Xv[co + i]; w1 = Ww[i]; w2 = Wr[i];
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk) {
+            ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
+            if (kk < width) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; n3[kk] = P3[col[kk]]; }
+        }
     }
     if (ctl.it >= it_stop) return;
     const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -485,42 +534,27 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
         if (writer) slot_store(out, s);
         return;
     }
-    const int k = k_launch + (int)ctl.koff;  // step within THIS solve (continues across graph replays)
-    const size_t co = (size_t)chain * n;
-    // p_m lives in Pv[m % 3], g_m in Gv[m & 1], w_m in Wv[m & 1]
-    const double2 *G1 = c.Gv[(k - 1) & 1] + co;              // g_{k-1}
-    const double2 *P2 = c.Pv[(k + 1) % 3] + co;              // p_{k-2}
-    const double2 *P3 = c.Pv[k % 3] + co;                    // p_{k-3}
-    double2 *Pw = c.Pv[(k + 2) % 3] + co, *Gw = c.Gv[k & 1] + co;   // p_{k-1}, g_k
-    double2 *Ww = c.Wv[k & 1] + co;                          // holds w_{k-4}, receives w_{k-2}
-    const double2 *Wr = c.Wv[(k - 1) & 1] + co;              // w_{k-3}
-    double2 g1_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
-    double tau = 0.0;
-    double2 ng[NPRE], n2[NPRE], n3[NPRE];
-    if (act) {
-        if (k == 1) p2_i = c.Pv[0][co + i];                  // p_0 (written by k_eta_init) plays p_{k-1}
-        if (k >= 2) { g1_i = G1[i]; p2_i = P2[i]; }
-        if (k >= 3) { p3_i = P3[i]; x = c.Xv[co + i]; }
-        if (k >= 5) w1 = Ww[i];
-        if (k >= 4) w2 = Wr[i];
-        om = c.omega_b[ctl.it & 1][co + i];
-        tau = sc.tau;
+    const int k = kl + (int)ctl.koff;  // step within THIS solve (continues across launch sequences)
+    const double om = (ctl.it & 1) ? om1 : om0;
+    // speculative loads of vectors that do not exist yet at the first steps are discarded
+    // (k = 1: p_0, stored by k_eta_init in Pv[0] = this launch's p_{k-1} slot, plays p_{k-1})
+    if (k < 5) w1 = zero2;
+    if (k < 4) w2 = zero2;
+    if (k < 3) {
+        p3_i = zero2;
 #pragma unroll
-        for (int kk = 0; kk < NPRE; ++kk) {
-            ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
-            if (kk < width) {
-                if (k == 1) n2[kk] = c.Pv[0][co + col[kk]];
-                if (k >= 2) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; }
-                if (k >= 3) n3[kk] = P3[col[kk]];
-            }
-        }
+        for (int kk = 0; kk < NPRE; ++kk) n3[kk] = zero2;
+    }
+    if (k == 1 && act) {
+        p2_i = Pw[i];
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk)
+            if (kk < width) n2[kk] = Pw[col[kk]];
     }
     OCC_STAMP(1)
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     if (k >= 2) {
-        double S[4];
-        reduce_partials<4>(kry_buf(c, chain, k & 1), c.nw_n, S);
-        S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3];
+        S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]);
     }
     OCC_STAMP(2)
     const double eps = DBL_EPSILON;
@@ -540,7 +574,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
             const double t1 = 1.0 + test1, t2 = 1.0 + test2;
             if (t2 <= 1.0) istop = 2;
             if (t1 <= 1.0) istop = 1;
-            if ((long long)j >= c.maxiter) istop = 6;
+            if ((long long)j >= a.maxiter) istop = 6;
             if (Acond >= 0.1 / eps) istop = 4;
             if (epsx >= s.beta1) istop = 3;
             if (test2 <= rtol) istop = 2;
@@ -549,7 +583,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
         if (istop != 0) {
             s.istop = istop; s.itn = j; s.done = 1;
             if (writer) slot_store(out, s);
-            projection_partials(c, chain, i);
+            projection_partials(a, chain, i);
             return;
         }
     }
@@ -559,7 +593,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
         if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
             s.done = 1; s.istop = 0; s.itn = 0;
             if (writer) slot_store(out, s);
-            projection_partials(c, chain, i);
+            projection_partials(a, chain, i);
             return;
         }
         const double beta_km1 = sqrt(S0);      // beta_{k-1}
@@ -602,7 +636,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
                 x.x = x.x + phi * w.x;
                 x.y = x.y + phi * w.y;
                 Ww[i] = w;
-                c.Xv[co + i] = x;
+                a.Xv[co + i] = x;
                 part[3] = x.x * x.x + x.y * x.y;
             }
             cb = beta_km1 / beta_km2;
@@ -617,7 +651,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
     if (act) {
         double2 p;  // p_{k-1} at this site
         if (k == 1) {
-            p = p2_i;
+            p = p2_i;  // p_0, already in its place
         } else {
             p.x = (ca * g1_i.x - cb * p3_i.x) - cc * p2_i.x;
             p.y = (ca * g1_i.y - cb * p3_i.y) - cc * p2_i.y;
@@ -628,7 +662,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk)
             if (kk < width) {
-                const double a = tau * val[kk];
+                const double av = tau * val[kk];
                 double2 pj;
                 if (k == 1) {
                     pj = n2[kk];
@@ -636,23 +670,23 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
                     pj.x = (ca * ng[kk].x - cb * n3[kk].x) - cc * n2[kk].x;
                     pj.y = (ca * ng[kk].y - cb * n3[kk].y) - cc * n2[kk].y;
                 }
-                gx += a * pj.x;
-                gy += a * pj.y;
+                gx += av * pj.x;
+                gy += av * pj.y;
             }
         for (int kk = NPRE; kk < width; ++kk) {  // rows longer than the prefetch window
-            const int jn = c.sell_col[base + kk * 64 + lane];
-            const double a = tau * c.sell_val[base + kk * 64 + lane];
+            const int jn = a.sell_col[base + kk * 64 + lane];
+            const double av = tau * a.sell_val[base + kk * 64 + lane];
             double2 pj;
             if (k == 1) {
-                pj = c.Pv[0][co + jn];
+                pj = Pw[jn];
             } else {
                 const double2 gj = G1[jn], q2 = P2[jn];
                 const double2 q3 = (k >= 3) ? P3[jn] : zero2;
                 pj.x = (ca * gj.x - cb * q3.x) - cc * q2.x;
                 pj.y = (ca * gj.y - cb * q3.y) - cc * q2.y;
             }
-            gx += a * pj.x;
-            gy += a * pj.y;
+            gx += av * pj.x;
+            gy += av * pj.y;
         }
         Gw[i] = make_double2(gx, gy);
         part[0] = p.x * p.x + p.y * p.y;
@@ -661,7 +695,7 @@ __global__ void __launch_bounds__(256) k_minres(OCC_KARGS, int k_launch)
     }
     OCC_STAMP(4)
     if (writer) slot_store(out, s);
-    wave_partials<4>(part, kry_buf(c, chain, (k + 1) & 1), c.nw_n);
+    wave_partials<4>(part, a.part_kry + ((size_t)chain * 2 + ((kl + 1) & 1)) * ((size_t)4 * a.nw_n), a.nw_n);
     OCC_STAMP(5)
 }
 
@@ -681,7 +715,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
         Ctl m = ctl;
         m.koff = carry ? (uint32_t)(k_last_launch + (int)ctl.koff) : 0u;  // carry the solve into the next replay
         sc.mid[e] = m;
-        if (carry) {  // the next replay's first Krylov launch reads slot 0
+        if (carry) {  // the next sequence's first Krylov launch reads slot 0
             sc.carries += 1ull;
             if ((k_last_launch & (NSLOT - 1)) != 0) slot_store(&slots[(size_t)chain * NSLOT], slot_load(fin));
         }
@@ -693,8 +727,31 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
             if (s.istop == 6) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
         }
     }
-    if (skip || carry) return;
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (carry) {
+        // Re-align the unfinished solve to launch number 1 of the next sequence: k_minres indexes its
+        // buffers by launch number, so after L launches the live vectors g_k (Gv[L&1]), p_{k-1}, p_{k-2}
+        // (Pv[(L+2)%3], Pv[(L+1)%3]), w_{k-2}, w_{k-3} (Wv[L&1], Wv[(L-1)&1]) and the partial sums
+        // (parity (L+1)&1) move to where launch 1 looks for them: Gv[0], Pv[2], Pv[1], Wv[0], Wv[1], parity 1.
+        const int L = k_last_launch;
+        const size_t co = (size_t)chain * n;
+        if (i < n && (L % 6) != 0) {
+            const double2 g = c.Gv[L & 1][co + i], pa = c.Pv[(L + 2) % 3][co + i], pb = c.Pv[(L + 1) % 3][co + i];
+            const double2 wa = c.Wv[L & 1][co + i], wb = c.Wv[(L - 1) & 1][co + i];
+            c.Gv[0][co + i] = g;
+            c.Pv[2][co + i] = pa;
+            c.Pv[1][co + i] = pb;
+            c.Wv[0][co + i] = wa;
+            c.Wv[1][co + i] = wb;
+        }
+        if (blockIdx.x == 0 && ((L + 1) & 1) != 1) {
+            const double *src = c.part_kry + ((size_t)chain * 2 + 0) * ((size_t)4 * c.nw_n);
+            double *dst = c.part_kry + ((size_t)chain * 2 + 1) * ((size_t)4 * c.nw_n);
+            for (int t = threadIdx.x; t < 4 * c.nw_n; t += blockDim.x) dst[t] = src[t];
+        }
+        return;
+    }
+    if (skip) return;
     double sums[2];
     reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, sums);
     const double a = -sums[0] / sums[1];

@@ -11,9 +11,10 @@
 #include <string>
 #include <vector>
 
-__device__ unsigned long long g_stamp[8 * 8192];
+__device__ unsigned long long g_stamp[24 * 8 * 8192];
+#define KSTAMP_K k_launch
 #define OCC_STAMP(n) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    if ((threadIdx.x & 63) == 0) g_stamp[(blockIdx.y * gridDim.x * (blockDim.x >> 6) + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + n] = t_; }
+    if ((threadIdx.x & 63) == 0) g_stamp[((size_t)(KSTAMP_K % 24) * 8192 + (blockIdx.y * gridDim.x * (blockDim.x >> 6) + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))) * 8 + n] = t_; }
 #include "occ_kernels.hpp"
 
 using namespace occ;
@@ -117,6 +118,12 @@ int main(int argc, char **argv)
     CK(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
 
     Ctx *cp; CK(hipMalloc(&cp, sizeof(Ctx))); CK(hipMemcpy(cp, &c, sizeof(Ctx), hipMemcpyHostToDevice));
+    KryArgs ka{};
+    ka.n = c.n; ka.nw_n = c.nw_n; ka.ell_w = c.ell_w; ka.maxiter = c.maxiter; ka.sell_ptr = c.sell_ptr; ka.sell_col = c.sell_col;
+    ka.sell_val = c.sell_val; ka.qdiag = c.qdiag; ka.omega_b[0] = c.omega_b[0]; ka.omega_b[1] = c.omega_b[1];
+    for (int b = 0; b < 2; ++b) { ka.Gv[b] = c.Gv[b]; ka.Wv[b] = c.Wv[b]; }
+    for (int b = 0; b < 3; ++b) ka.Pv[b] = c.Pv[b];
+    ka.Xv = c.Xv; ka.part_kry = c.part_kry; ka.part_proj = c.part_proj; ka.scs = c.sc; ka.slots = c.slots;
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1;
@@ -126,7 +133,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
     hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 0);
     hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
-    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, k);
+    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, k);
     CK(hipStreamSynchronize(st));
 
     const bool eager = getenv("KB_EAGER") != nullptr;
@@ -153,19 +160,31 @@ int main(int argc, char **argv)
         printf("%-28s %8.3f us/launch\n", name, 1000.0 * best / reps);
         hipGraphExecDestroy(ge); hipGraphDestroy(g);
     };
-    {
-        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5);
+    {   // realistic cold sequence: a whole solve captured in a graph, replayed; stamps per launch number
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
+        for (int k = 1; k <= 12; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, k);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int r = 0; r < 20; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < 50; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h(8 * 8192);
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("solve graph (eta_init + 12 minres): %.2f us per replay (stamped build)\n", 1000.0 * ms / 50);
+        std::vector<unsigned long long> h((size_t)24 * 8 * 8192);
         CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp), h.size() * 8));
         const int nw = c.nw_n * C;
-        double m[6] = {0};
-        for (int w = 0; w < nw; ++w) for (int q2 = 1; q2 < 6; ++q2) m[q2] += (double)(h[w * 8 + q2] - h[w * 8]);
-        printf("k_minres stamps (mean cycles since wave start; NOTE stamps drain the memory queues): loads landed %.0f | sums reduced %.0f | scalars %.0f | vector math %.0f | partials written %.0f\n",
-               m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw);
+        for (int k : {2, 6, 10}) {
+            double m[6] = {0};
+            for (int w = 0; w < nw; ++w) for (int q2 = 1; q2 < 6; ++q2) m[q2] += (double)(h[((size_t)k * 8192 + w) * 8 + q2] - h[((size_t)k * 8192 + w) * 8]);
+            printf("  launch %2d: loads landed %.0f | sums reduced %.0f | scalars %.0f | vector math %.0f | partials written %.0f cycles\n", k, m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw);
+        }
     }
     for (int round = 0; round < 2; ++round) {
-        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
+        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, 5); });
         time_graph("empty kernel", [&] { hipLaunchKernelGGL(k_empty, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("empty kernel 1 block", [&] { hipLaunchKernelGGL(k_empty, dim3(1), blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("ctl-only kernel", [&] { hipLaunchKernelGGL(k_ctl_only, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5, (double *)c.rhs); });
