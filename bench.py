@@ -154,7 +154,7 @@ def main():
         prof = eng.profile(reps=200)
         kmean = stats['krylov_mean']
         # launches on the critical path of one iteration (omega_a, alpha_draw, noise run on the side stream)
-        per_iter = {'eta_init': 1, 'minres': stats['krylov_cap'] + 3, 'beta_partial': 1, 'beta_draw': 1, 'z_ob': 1}
+        per_iter = {'eta_init': 1, 'minres': stats['krylov_cap'] + 3, 'beta_partial': 1, 'z_ob': 1}
         ka = prof['minres']
         sell = sell_entry_count(prob)
         bytes_launch = minres_bytes_per_launch(prob, C, sell)

@@ -118,10 +118,10 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 /* Per-kernel launch time in the mode occ_run uses: for each kernel kind, `reps` back-to-back launches
  * of that ONE kernel are captured into a hipGraph and bracketed by two HIP events on the engine's
  * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.
- * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 beta_draw, 6 omega_a, 7 alpha_draw,
- * 8 z_ob (z update + next iteration's omega_b).
+ * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 omega_a, 6 alpha_draw,
+ * 7 z_ob (beta draw + z update + next iteration's omega_b).
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
-#define OCC_N_KERNEL_KINDS 9
+#define OCC_N_KERNEL_KINDS 8
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
 

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libocc_gibbs.so')
 
 OCC_OK = 0
 OCC_E_BADARG, OCC_E_HIP, OCC_E_MINRES, OCC_E_CHOLESKY, OCC_E_STATE = -1, -2, -3, -4, -5
-N_KERNEL_KINDS = 9
-KERNEL_KINDS = ('omega_b', 'noise', 'eta_init', 'minres', 'beta_partial', 'beta_draw', 'omega_a', 'alpha_draw', 'z_ob')
+N_KERNEL_KINDS = 8
+KERNEL_KINDS = ('omega_b', 'noise', 'eta_init', 'minres', 'beta_partial', 'omega_a', 'alpha_draw', 'z_ob')
 
 
 class OccProblem(C.Structure):

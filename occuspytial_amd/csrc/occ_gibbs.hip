@@ -21,7 +21,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_BETA_DRAW, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB };
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB };
 static_assert(K_Z_OB + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
@@ -132,6 +132,10 @@ KernelEI pick_beta_partial(int p)
         default: return k_beta_partial<8>;
     }
 }
+#define OCC_PICK_P(NAME, p) \
+    ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
+KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
+KernelE pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {
     switch (q) {
@@ -153,15 +157,14 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     const Ctx &c = s->ctx;
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
     switch (kind) {
-        case K_OMEGA_B: hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, OCC_ARGS); break;
+        case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(c.p), gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
-        case K_BETA_DRAW: hipLaunchKernelGGL(k_beta_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
-        default: hipLaunchKernelGGL(k_z_ob, dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
+        default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
     }
 }
 
@@ -232,7 +235,6 @@ int eager_sequence(occ_sampler *s)
     if (rc) return rc;
     s->calib_max = std::max(s->calib_max, k_last - 3);
     launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
-    launch_kind(s, s->stream, K_BETA_DRAW, e);
     launch_kind(s, s->stream, K_Z_OB, e);
     s->parity ^= 1;
     s->eager_iterations += 1;
@@ -264,8 +266,7 @@ int build_graph(occ_sampler *s, int cap)
         launch_kind(s, s->stream, K_ETA_INIT, e);
         for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
         launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
-        launch_kind(s, s->stream, K_BETA_DRAW, e);
-        if (std::getenv("OCC_NO_SIDE_STREAM")) {  // diagnostic: everything on one stream
+            if (std::getenv("OCC_NO_SIDE_STREAM")) {  // diagnostic: everything on one stream
             launch_kind(s, s->stream, K_OMEGA_A, e);
             launch_kind(s, s->stream, K_ALPHA_DRAW, e);
             launch_kind(s, s->stream, K_NOISE, e, 1);
@@ -651,7 +652,11 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     // the count of the last, warm-started solve sizes the captured graph
     int64_t done_min = 0;
     const char *force = std::getenv("OCC_FORCE_KRYLOV_CAP");  // tests
-    if (!s->exec) {
+    if (std::getenv("OCC_EAGER_ONLY")) {  // counter collection cannot follow graph launches: same kernels, eager
+        for (int64_t i = 0; i < n_iter; ++i)
+            if ((rc = eager_sequence(s))) return rc;
+        done_min = n_iter;
+    } else if (!s->exec) {
         const int64_t n_calib = std::min<int64_t>(n_iter, 3);
         s->calib_max = 0;
         for (int64_t i = 0; i < n_calib; ++i) {
@@ -688,7 +693,8 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
             const double var = std::max(0.0, (double)(sq - s->seen_sq) / ds - mean * mean);
             const int want = std::max(4, (int)std::ceil(mean + 2.5 * std::sqrt(var)));
             s->seen_tot = tot; s->seen_sq = sq; s->seen_solves = solves;
-            if (want != s->krylov_cap && (rc = build_graph(s, want))) return rc;
+            // hysteresis: grow at once, shrink only when two launches too many are captured
+            if ((want > s->krylov_cap || want < s->krylov_cap - 1) && (rc = build_graph(s, want))) return rc;
         }
     }
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -890,7 +896,6 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     launch_kind(s, s->stream, K_ETA_INIT, e);
     if ((rc = eager_krylov(s, 1, &k_last))) return rc;
     if ((rc = timed(K_BETA_PARTIAL, k_last))) return rc;
-    if ((rc = timed(K_BETA_DRAW, 0))) return rc;
     // k_z_ob advances the control word of the OTHER parity; launched repeatedly with the same parity
     // it redoes the same z update and omega_b draw
     if ((rc = timed(K_Z_OB, 0))) return rc;

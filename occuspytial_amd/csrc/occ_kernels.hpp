@@ -10,7 +10,7 @@
 // read only alpha and z of iteration t-1, and the next iteration's omega_b reads only beta and eta of
 // iteration t, so (with counter-based variates, results do not depend on execution order):
 //
-//   main stream  k_eta_init -> k_minres x (cap+3) -> k_beta_partial -> k_beta_draw -> k_z_ob
+//   main stream  k_eta_init -> k_minres x (cap+3) -> k_beta_partial -> k_z_ob
 //   side stream  k_omega_a -> k_alpha_draw -> k_noise(t+1)        (joined before k_z_ob)
 //
 //   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials (logit.py:195-204, 208);
@@ -22,12 +22,12 @@
 //   k_minres       one Lanczos/MINRES iteration of the joint 2n system per launch
 //                  (scipy _isolve/minres.py as called at logit.py:87)
 //   k_beta_partial eta = x - (sum x / sum z) z (distributions.pyx:24-39); X' Omega X, X'(k - omega eta)
-//   k_beta_draw    beta ~ N(A^-1 r, A^-1) (logit.py:232, distributions.pyx:42-110), one wave per chain
 //   k_omega_a      omega_a ~ PG(1, w'alpha) for rows of existing sites; W' Omega W, W'(y - 1/2)
 //                  (logit.py:180-193, 219-223)
 //   k_alpha_draw   alpha draw (logit.py:224), one wave per chain
-//   k_z_ob         role 0: z update (logit.py:234-252), record (alpha, beta, tau) (base.py:238-239),
-//                  advance the iteration; role 1 (other half of the grid): omega_b of the NEXT iteration
+//   k_z_ob         beta draw (logit.py:232, every wave); role 0: z update (logit.py:234-252), record
+//                  (alpha, beta, tau) (base.py:238-239), advance the iteration; role 1 (other half of the
+//                  grid): omega_b of the NEXT iteration
 #pragma once
 #include <float.h>
 #include <hip/hip_runtime.h>
@@ -131,7 +131,7 @@ struct Ctx {
     double *part_quad;   // [C][nw_n]            eta'Q eta            k_omega_b -> k_eta_init
     double *part_kry;    // [C][2][4 nw_n]       MINRES sums          k_minres  -> k_minres
     double *part_proj;   // [C][2 nw_n]          sum x, sum z         k_minres  -> k_beta_partial
-    double *part_beta;   // [C][nacc(p) nw_n]    X'OX, X'(k - o eta)  k_beta_partial -> k_beta_draw
+    double *part_beta;   // [C][nacc(p) nw_n]    X'OX, X'(k - o eta)  k_beta_partial -> k_z_ob
     double *part_alpha;  // [C][nacc(q) nw_r]    W'OW, W'(y - 1/2)    k_omega_a -> k_alpha_draw
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
@@ -284,19 +284,82 @@ __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d):
     return ok;
 }
 
+// Same draw with the dimension known at compile time, entirely in registers; executed redundantly by
+// every lane (uniform inputs, uniform control flow), so no broadcast is needed afterwards.
+template <int D>
+__device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)], const double *prec0, const double *pbm,
+                                                     uint64_t key, uint32_t it, uint32_t stream, double (&out)[D])
+{
+    double U[D][D], r[D], o[D];
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = a; b < D; ++b) U[a][b] = acc[t++] + prec0[a * D + b];
+#pragma unroll
+    for (int a = 0; a < D; ++a) r[a] = acc[t++] + pbm[a];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double sj = U[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sj -= U[k][j] * U[k][j];
+        if (!(sj > 0.0)) ok = false;
+        const double ujj = sqrt(sj);
+        U[j][j] = ujj;
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            double v = U[j][i];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= U[k][j] * U[k][i];
+            U[j][i] = v / ujj;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double e = block_normal(key, (uint32_t)k, 0, it, stream);
+#pragma unroll
+        for (int i = k; i < D; ++i) o[i] += U[k][i] * e;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[i] += r[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double v = o[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= U[k][i] * o[k];
+        o[i] = v / U[i][i];
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+        double v = o[i];
+#pragma unroll
+        for (int k = i + 1; k < D; ++k) v -= U[i][k] * o[k];
+        o[i] = v / U[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) out[i] = o[i];
+    return ok;
+}
+
 // =================================================================================================
 #define OCC_KARGS const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int e
 
 // omega_b ~ PG(1, x_i'beta + eta_i) of iteration `it` into omega_b[it & 1], and the partials of eta'Q eta
 // (logit.py:195-204, 208).  `blk` is the block index within the role's own grid.
-__device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int blk)
+template <int P>
+__device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &sc, const double (&beta)[P], int chain, uint32_t it, int blk)
 {
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     double quad[1] = {0.0};
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double *eta = c.eta + (size_t)chain * n;
-        const double xb = xdot(c.Xt, n, i, sc.beta, c.p);
+        double xb = 0.0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
         const double eta_i = eta[i];
         Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
         c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
@@ -314,6 +377,7 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
 
 // Stand-alone omega_b of the CURRENT iteration: only needed when the start values or the state were
 // just set by the host (afterwards k_z_ob's second role has already produced it).
+template <int P>
 __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
 {
     const Ctx &c = *cp;
@@ -321,7 +385,10 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
-    omega_b_body(c, sc, chain, ctl.it, blockIdx.x);
+    double beta[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
+    omega_b_body<P>(c, sc, beta, chain, ctl.it, blockIdx.x);
 }
 
 // Variates of the eta right-hand side that depend only on (key, iteration): the site normals eps_1
@@ -781,24 +848,6 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     wave_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n);
 }
 
-// beta ~ N(A^-1 r, A^-1) from the partial sums of k_beta_partial (logit.py:232): one wave per chain.
-__global__ void __launch_bounds__(64) k_beta_draw(OCC_KARGS)
-{
-    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
-    const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.x;
-    ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.mid[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int P = c.p, Q = c.q;
-    reduce_partials_lds(c.part_beta + (size_t)chain * nacc(P) * c.nw_n, nacc(P), c.nw_n, s_red);
-    if (threadIdx.x == 0) {
-        const double *b_prec = c.hyp + Q * Q + Q, *b_pbm = b_prec + P * P;
-        const bool ok = precision_mvnorm_dev(P, s_red, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, s_U, s_work, sc.beta);
-        if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
-    }
-}
-
 template <int Q>
 __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 {
@@ -860,10 +909,13 @@ __global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
     }
 }
 
-// Last kernel of a launch sequence.  Blocks [0, nb_n): z update of the current iteration (logit.py:234-252),
-// record (alpha, beta, tau) (base.py:238-239), hand the control word to the next sequence.  Blocks
-// [nb_n, 2 nb_n): omega_b of the NEXT iteration, which needs only beta and eta of this one -- one launch,
-// two independent roles, so the two run concurrently without a second stream.
+// Last kernel of a launch sequence.  Every wave first draws beta ~ N(A^-1 r, A^-1) from the partial sums
+// of k_beta_partial (logit.py:232, distributions.pyx:42-110; redundantly, in registers -- cheaper than a
+// kernel of its own).  Blocks [0, nb_n): z update of the current iteration (logit.py:234-252), record
+// (alpha, beta, tau) (base.py:238-239), hand the control word to the next sequence.  Blocks [nb_n, 2 nb_n):
+// omega_b of the NEXT iteration, which needs only beta and eta of this one -- one launch, two independent
+// roles, so the two run concurrently without a second stream.
+template <int P>
 __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
 {
     const Ctx &c = *cp;
@@ -872,27 +924,41 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
     const Ctl ctl = sc.mid[e];
     const bool skip = ctl.koff || ctl.it >= sc.it_stop;
     const int nb = c.nb_n;
-    if ((int)blockIdx.x >= nb) {  // role 1
-        if (!skip) omega_b_body(c, sc, chain, ctl.it + 1u, (int)blockIdx.x - nb);
-        return;
-    }
     const uint32_t it = ctl.it;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (writer) {
         Ctl nx = ctl;  // a mid-solve chain keeps its iteration number and its koff
         if (!skip) nx.it = it + 1;
         sc.ctl[e ^ 1] = nx;
-        if (!skip) {
-            const uint32_t rel = it - sc.it_base;
-            if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
-                const int P = c.p, Q = c.q;
-                double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
-                for (int a = 0; a < Q; ++a) row[a] = sc.alpha[a];
-                for (int a = 0; a < P; ++a) row[Q + a] = sc.beta[a];
-                row[Q + P] = sc.tau;
-            }
-        }
     }
     if (skip) return;
+    double beta[P];
+    {
+        double sums[nacc(P)];
+        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n, sums);
+        const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
+        const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, it, STREAM_BETA, beta);
+        if (writer) {
+            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+#pragma unroll
+            for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
+        }
+    }
+    if ((int)blockIdx.x >= nb) {  // role 1
+        omega_b_body<P>(c, sc, beta, chain, it + 1u, (int)blockIdx.x - nb);
+        return;
+    }
+    if (writer) {
+        const uint32_t rel = it - sc.it_base;
+        if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
+            const int Q = c.q;
+            double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
+            for (int a = 0; a < Q; ++a) row[a] = sc.alpha[a];
+#pragma unroll
+            for (int a = 0; a < P; ++a) row[Q + a] = beta[a];
+            row[Q + P] = sc.tau;
+        }
+    }
     const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int sidx = c.site_sidx[i];
@@ -900,7 +966,10 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
     if (!not_surveyed && c.obs_site[sidx]) return;  // detection seen: z stays 1 (base.py:116-118)
     const size_t ci = (size_t)chain * n + i;
     const int Q = c.q;
-    const double num1 = expit(xdot(c.Xt, n, i, sc.beta, c.p) + c.eta[ci]);
+    double xb = 0.0;
+#pragma unroll
+    for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
+    const double num1 = expit(xb + c.eta[ci]);
     double pr = num1;
     if (!not_surveyed) {
         double prod = 1.0;

@@ -18,6 +18,46 @@ __device__ unsigned long long g_stamp[24 * 8 * 8192];
 #include "occ_kernels.hpp"
 
 using namespace occ;
+
+namespace occ {
+template <int V>
+__device__ inline double pg1_var(Cursor &c, double z)
+{
+    const double Z = 0.5 * fabs(z);
+    const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
+    const double ptail = (V == 1) ? 0.5 / (1.0 + Z) : pg_mass_texpon(Z);
+    for (;;) {
+        double X;
+        if (c.unif() < ptail) X = kPgT + c.expo() / fz;
+        else X = pg_rtigauss(c, Z);
+        if (V == 2) return 0.25 * X;
+        double S = pg_a(0, X);
+        const double Y = c.unif() * S;
+        int n = 0;
+        for (;;) {
+            ++n;
+            if (n & 1) { S -= pg_a(n, X); if (Y <= S) return 0.25 * X; }
+            else { S += pg_a(n, X); if (Y > S) break; }
+        }
+    }
+}
+template <int V>
+__global__ void __launch_bounds__(256) k_pgvar(const Ctx *cp, ChainScalars *scs, double *out)
+{
+    const Ctx &c = *cp;
+    const int chain = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    const ChainScalars &sc = scs[chain];
+    const double xb = xdot(c.Xt, c.n, i, sc.beta, c.p) + c.eta[(size_t)chain * c.n + i];
+    Cursor cur(sc.key, (uint32_t)i, 7u, STREAM_OMEGA_B);
+    double r;
+    if (V == 3) { r = cur.unif() + cur.expo() + cur.unif(); }            // 2 philox blocks + 1 log
+    else if (V == 4) { r = pg_mass_texpon(0.5 * fabs(xb)); }               // mixture weight only
+    else if (V == 5) { r = cur.norm(); }                                   // one Box-Muller normal
+    else r = pg1_var<V>(cur, xb);
+    out[(size_t)chain * c.n + i] = r;
+}
+}
 __global__ void k_empty(const Ctx *cp, ChainScalars *scs, Slot *slots, int chain_base, int e, int k) {}
 __global__ void k_ctl_only(const Ctx *cp, ChainScalars *scs, Slot *slots, int chain_base, int e, int k, double *sink)
 {
@@ -130,7 +170,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 gs(c.nb_n, C), gr(c.nb_r, C), blk(tpb);
     // a sane mid-solve state
-    hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
+    hipLaunchKernelGGL(k_omega_b<2>, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
     hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 0);
     hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
     for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, k);
@@ -188,7 +228,13 @@ int main(int argc, char **argv)
         time_graph("empty kernel", [&] { hipLaunchKernelGGL(k_empty, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("empty kernel 1 block", [&] { hipLaunchKernelGGL(k_empty, dim3(1), blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("ctl-only kernel", [&] { hipLaunchKernelGGL(k_ctl_only, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5, (double *)c.rhs); });
-        time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
+        time_graph("omega_b", [&] { hipLaunchKernelGGL(k_omega_b<2>, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
+        time_graph("PG full (V0)", [&] { hipLaunchKernelGGL(k_pgvar<0>, gs, blk, 0, st, cp, c.sc, c.rhs); });
+        time_graph("PG cheap mixture weight (V1)", [&] { hipLaunchKernelGGL(k_pgvar<1>, gs, blk, 0, st, cp, c.sc, c.rhs); });
+        time_graph("PG no series test (V2)", [&] { hipLaunchKernelGGL(k_pgvar<2>, gs, blk, 0, st, cp, c.sc, c.rhs); });
+        time_graph("2 philox + 1 log (V3)", [&] { hipLaunchKernelGGL(k_pgvar<3>, gs, blk, 0, st, cp, c.sc, c.rhs); });
+        time_graph("mass_texpon only (V4)", [&] { hipLaunchKernelGGL(k_pgvar<4>, gs, blk, 0, st, cp, c.sc, c.rhs); });
+        time_graph("one BM normal (V5)", [&] { hipLaunchKernelGGL(k_pgvar<5>, gs, blk, 0, st, cp, c.sc, c.rhs); });
         time_graph("eta_init", [&] { hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
         time_graph("noise", [&] { hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 1); });
         time_graph("omega_a", [&] { hipLaunchKernelGGL(k_omega_a<2>, gr, blk, 0, st, cp, c.sc, c.slots, 0, 0); });
