@@ -190,8 +190,9 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
-                'timing': 'mean of 200 back-to-back launches captured in a hipGraph, HIP events on the engine stream '
-                          '(kernel duration + one dependent-launch boundary)',
+                'timing': 'HIP events on the engine stream around 200 replays of a captured solve prefix '
+                          '(k_eta_init + k_minres launches 1..8, every launch cache-cold as in the real solve), '
+                          'k_eta_init subtracted; = kernel duration + one dependent-launch boundary',
                 'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},
             },

@@ -117,7 +117,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 
 /* Per-kernel launch time in the mode occ_run uses: for each kernel kind, `reps` back-to-back launches
  * of that ONE kernel are captured into a hipGraph and bracketed by two HIP events on the engine's
- * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.
+ * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.  k_minres is
+ * timed inside a replayed graph of a real solve prefix (k_eta_init + launches 1..8), see occ_gibbs.hip.
  * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 omega_a, 6 alpha_draw,
  * 7 z_ob (beta draw + z update + next iteration's omega_b).
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */

@@ -165,13 +165,35 @@ __device__ __forceinline__ double wave_sum(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
 }
 
-__device__ __forceinline__ int global_wave() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+// XCD-aware workgroup -> (chain, tile) map.  MI355X deals workgroups round-robin over its 8 XCDs (each
+// with a private L2), so with the plain map consecutive tiles of one chain land on 8 different L2s and
+// every neighbour gather of the lattice re-fetches its lines into several of them (measured: fabric
+// reads 2.6x the algorithmic bytes of k_minres).  Here workgroups that share an XCD (equal linear id
+// mod 8) take CONSECUTIVE tiles, so a tile's neighbours sit in the same L2.  The map is a bijection
+// for every grid size; it only changes where a tile runs, never what is computed.
+struct Tile {
+    int chain, blk;
+};
+__device__ __forceinline__ Tile tile_of_block(int chain_base)
+{
+    const unsigned gx = gridDim.x, nwg = gx * gridDim.y;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = lin & 7u;
+    const unsigned first = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    const unsigned id = first + (lin >> 3);
+    Tile t;
+    t.chain = chain_base + (int)(id / gx);
+    t.blk = (int)(id % gx);
+    return t;
+}
+
+__device__ __forceinline__ int global_wave(int blk) { return blk * (blockDim.x >> 6) + (threadIdx.x >> 6); }
 
 // Each wave writes one partial per quantity: out[q * nw + wave].
 template <int NQ>
-__device__ __forceinline__ void wave_partials(const double (&v)[NQ], double *out, int nw)
+__device__ __forceinline__ void wave_partials(const double (&v)[NQ], double *out, int nw, int blk)
 {
-    const int gw = global_wave();
+    const int gw = global_wave(blk);
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         const double r = wave_sum(v[qi]);
@@ -381,14 +403,15 @@ template <int P>
 __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     double beta[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
-    omega_b_body<P>(c, sc, beta, chain, ctl.it, blockIdx.x);
+    omega_b_body<P>(c, sc, beta, chain, ctl.it, blk);
 }
 
 // Variates of the eta right-hand side that depend only on (key, iteration): the site normals eps_1
@@ -398,11 +421,12 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
 __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t it = ctl.it + (uint32_t)ahead;
     const uint64_t key = sc.key;
@@ -427,11 +451,12 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
 __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     const uint32_t it = ctl.it;
     double quad[1];
     reduce_partials<1>(c.part_quad + (size_t)chain * c.nw_n, c.nw_n, quad);
@@ -439,7 +464,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
     const double rate = 0.5 * quad[0] + c.tau_rate;
     Cursor g(sc.key, 0u, it, STREAM_TAU);
     const double tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         sc.tau = tau;
         Slot s = {};
         slot_store(&slots[(size_t)chain * NSLOT], s);
@@ -475,7 +500,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 
 // Sum-to-zero projection partials, taken by the kernel that detects the end of the solve.
 template <class A>
-__device__ __forceinline__ void projection_partials(const A &c, int chain, int i)
+__device__ __forceinline__ void projection_partials(const A &c, int chain, int i, int blk)
 {
     double v[2] = {0.0, 0.0};
     if (i < c.n) {
@@ -483,7 +508,7 @@ __device__ __forceinline__ void projection_partials(const A &c, int chain, int i
         v[0] = x.x;
         v[1] = x.y;
     }
-    wave_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n);
+    wave_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, blk);
 }
 
 // Diagnostic builds (tools/kbench.hip) define OCC_STAMP to record s_memtime at a few points of
@@ -534,9 +559,10 @@ struct KryArgs {
 __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base, int e, int k_launch)
 {
     OCC_STAMP(0)
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = a.scs[chain];
-    const int n = a.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = a.n, i = blk * blockDim.x + threadIdx.x;
     const bool act = i < n;
     const size_t co = (size_t)chain * n;
     const double2 zero2 = make_double2(0.0, 0.0);
@@ -596,7 +622,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         }
     }
     if (ctl.it >= it_stop) return;
-    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
+    const bool writer = (blk == 0 && threadIdx.x == 0);
     if (s.done) {
         if (writer) slot_store(out, s);
         return;
@@ -650,7 +676,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         if (istop != 0) {
             s.istop = istop; s.itn = j; s.done = 1;
             if (writer) slot_store(out, s);
-            projection_partials(a, chain, i);
+            projection_partials(a, chain, i, blk);
             return;
         }
     }
@@ -660,7 +686,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
             s.done = 1; s.istop = 0; s.itn = 0;
             if (writer) slot_store(out, s);
-            projection_partials(a, chain, i);
+            projection_partials(a, chain, i, blk);
             return;
         }
         const double beta_km1 = sqrt(S0);      // beta_{k-1}
@@ -762,7 +788,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     }
     OCC_STAMP(4)
     if (writer) slot_store(out, s);
-    wave_partials<4>(part, a.part_kry + ((size_t)chain * 2 + ((kl + 1) & 1)) * ((size_t)4 * a.nw_n), a.nw_n);
+    wave_partials<4>(part, a.part_kry + ((size_t)chain * 2 + ((kl + 1) & 1)) * ((size_t)4 * a.nw_n), a.nw_n, blk);
     OCC_STAMP(5)
 }
 
@@ -770,7 +796,8 @@ template <int P>
 __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_launch)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     // the last Krylov kernel of this launch sequence wrote slot k_last_launch & 3
@@ -778,7 +805,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     struct { int done, itn, istop; } s = {fin->done, fin->itn, fin->istop};
     const bool skip = ctl.it >= sc.it_stop;
     const bool carry = !skip && !s.done;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         Ctl m = ctl;
         m.koff = carry ? (uint32_t)(k_last_launch + (int)ctl.koff) : 0u;  // carry the solve into the next replay
         sc.mid[e] = m;
@@ -794,7 +821,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
             if (s.istop == 6) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
         }
     }
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (carry) {
         // Re-align the unfinished solve to launch number 1 of the next sequence: k_minres indexes its
         // buffers by launch number, so after L launches the live vectors g_k (Gv[L&1]), p_{k-1}, p_{k-2}
@@ -811,7 +838,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
             c.Wv[0][co + i] = wa;
             c.Wv[1][co + i] = wb;
         }
-        if (blockIdx.x == 0 && ((L + 1) & 1) != 1) {
+        if (blk == 0 && ((L + 1) & 1) != 1) {
             const double *src = c.part_kry + ((size_t)chain * 2 + 0) * ((size_t)4 * c.nw_n);
             double *dst = c.part_kry + ((size_t)chain * 2 + 1) * ((size_t)4 * c.nw_n);
             for (int t = threadIdx.x; t < 4 * c.nw_n; t += blockDim.x) dst[t] = src[t];
@@ -845,20 +872,21 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
     }
-    wave_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n);
+    wave_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n, blk);
 }
 
 template <int Q>
 __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const uint64_t key = sc.key;
     const uint32_t it = ctl.it;
-    const int R = c.R, r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int R = c.R, r = blk * blockDim.x + threadIdx.x;
     double acc[nacc(Q)];
 #pragma unroll
     for (int t = 0; t < nacc(Q); ++t) acc[t] = 0.0;
@@ -888,7 +916,7 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
             for (int a = 0; a < Q; ++a) acc[t++] = w[a] * tt;
         }
     }
-    wave_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, c.nw_r);
+    wave_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, c.nw_r, blk);
 }
 
 // alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one wave per chain.
@@ -919,13 +947,14 @@ template <int P>
 __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
 {
     const Ctx &c = *cp;
-    const int chain = chain_base + blockIdx.y;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.mid[e];
     const bool skip = ctl.koff || ctl.it >= sc.it_stop;
     const int nb = c.nb_n;
     const uint32_t it = ctl.it;
-    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
+    const bool writer = (blk == 0 && threadIdx.x == 0);
     if (writer) {
         Ctl nx = ctl;  // a mid-solve chain keeps its iteration number and its koff
         if (!skip) nx.it = it + 1;
@@ -944,8 +973,8 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
             for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
         }
     }
-    if ((int)blockIdx.x >= nb) {  // role 1
-        omega_b_body<P>(c, sc, beta, chain, it + 1u, (int)blockIdx.x - nb);
+    if (blk >= nb) {  // role 1
+        omega_b_body<P>(c, sc, beta, chain, it + 1u, blk - nb);
         return;
     }
     if (writer) {
@@ -959,7 +988,7 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
             row[Q + P] = sc.tau;
         }
     }
-    const int n = c.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int sidx = c.site_sidx[i];
     const bool not_surveyed = sidx < 0;
