@@ -103,10 +103,23 @@ def main():
     from occuspytial_amd.utils import make_lattice_problem
 
     dist = None
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
+        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl" backend) for the set-up traffic
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        # RCCL prints a version banner on C-level stdout at communicator creation: keep stdout for the
+        # one JSON line by pointing fd 1 at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     # ---- inputs: rank 0 generates, every other rank receives them over RCCL -----------------------
     rows, cols = args.lattice
@@ -114,7 +127,7 @@ def main():
     if rank == 0:
         Q, W, X, y, *_ = make_lattice_problem(rows, cols, visits=args.visits, p=2, q=2, random_state=0)
         prob = FlatProblem(Q, W, X, y)
-    if world > 1:
+    if dist is not None:
         from occuspytial_amd.distributed import broadcast_problem
         prob = broadcast_problem(prob, src=0, device=torch.device('cuda', local_rank))
 

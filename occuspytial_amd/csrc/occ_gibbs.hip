@@ -485,9 +485,6 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
-    c.nw_n = c.nb_n * (tpb / 64);
-    c.nw_r = c.nb_r * (tpb / 64);
-    c.nw_max = std::max(c.nw_n, c.nw_r);
 
     // ---- device memory ------------------------------------------------------------------------------
     if ((rc = upload(s, &c.sell_ptr, sell_ptr))) return rc;
@@ -523,11 +520,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     for (int b = 0; b < 3; ++b)
         if ((rc = dev_alloc(s, &c.Pv[b], Cn))) return rc;
     if ((rc = dev_alloc(s, &c.Xv, Cn))) return rc;
-    if ((rc = dev_alloc(s, &c.part_quad, (size_t)C * c.nw_n))) return rc;
-    if ((rc = dev_alloc(s, &c.part_kry, (size_t)C * 2 * 4 * c.nw_n))) return rc;
-    if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nw_n))) return rc;
-    if ((rc = dev_alloc(s, &c.part_beta, (size_t)C * nacc(p) * c.nw_n))) return rc;
-    if ((rc = dev_alloc(s, &c.part_alpha, (size_t)C * nacc(q) * c.nw_r))) return rc;
+    if ((rc = dev_alloc(s, &c.part_quad, (size_t)C * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_kry, (size_t)C * 2 * 4 * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_proj, (size_t)C * 2 * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_beta, (size_t)C * nacc(p) * c.nb_n))) return rc;
+    if ((rc = dev_alloc(s, &c.part_alpha, (size_t)C * nacc(q) * c.nb_r))) return rc;
     if ((rc = dev_alloc(s, &c.slots, (size_t)C * NSLOT))) return rc;
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
@@ -543,7 +540,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     HIP_TRY(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
     {
         KryArgs &k = s->kry;
-        k.n = c.n; k.nw_n = c.nw_n; k.ell_w = c.ell_w; k.pad = 0; k.maxiter = c.maxiter;
+        k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.pad = 0; k.maxiter = c.maxiter;
         k.sell_ptr = c.sell_ptr; k.sell_col = c.sell_col; k.sell_val = c.sell_val; k.qdiag = c.qdiag;
         k.omega_b[0] = c.omega_b[0]; k.omega_b[1] = c.omega_b[1];
         for (int b = 0; b < 2; ++b) { k.Gv[b] = c.Gv[b]; k.Wv[b] = c.Wv[b]; }

@@ -106,8 +106,7 @@ struct ChainScalars {
 // scalar loads the compiler could not batch -- while a 40-byte argument block is one fetch.
 struct Ctx {
     int n, S, R, p, q, C;
-    int nb_n, nb_r;          // blocks over sites / visit rows
-    int nw_n, nw_r, nw_max;  // waves over sites / visit rows = number of partial sums per quantity
+    int nb_n, nb_r;  // blocks over sites / visit rows = number of partial sums per quantity
     long long maxiter;
     // fixed inputs (shared by all chains)
     int ell_w;  // > 0: every 64-row slice has this width (uniform ELL): slice base is arithmetic, no sell_ptr load
@@ -128,11 +127,11 @@ struct Ctx {
     uint8_t *z;
     double2 *Gv[2], *Pv[3], *Wv[2], *Xv;  // g_m = A p_{m-1}, p_m = r2_m, w_m, x: (x-part, z-part) interleaved
     // per-wave partial sums (one region per producer, so that independent kernels may overlap)
-    double *part_quad;   // [C][nw_n]            eta'Q eta            k_omega_b -> k_eta_init
-    double *part_kry;    // [C][2][4 nw_n]       MINRES sums          k_minres  -> k_minres
-    double *part_proj;   // [C][2 nw_n]          sum x, sum z         k_minres  -> k_beta_partial
-    double *part_beta;   // [C][nacc(p) nw_n]    X'OX, X'(k - o eta)  k_beta_partial -> k_z_ob
-    double *part_alpha;  // [C][nacc(q) nw_r]    W'OW, W'(y - 1/2)    k_omega_a -> k_alpha_draw
+    double *part_quad;   // [C][nb_n]            eta'Q eta            k_omega_b -> k_eta_init
+    double *part_kry;    // [C][2][4 nb_n]       MINRES sums          k_minres  -> k_minres
+    double *part_proj;   // [C][2 nb_n]          sum x, sum z         k_minres  -> k_beta_partial
+    double *part_beta;   // [C][nacc(p) nb_n]    X'OX, X'(k - o eta)  k_beta_partial -> k_z_ob
+    double *part_alpha;  // [C][nacc(q) nb_r]    W'OW, W'(y - 1/2)    k_omega_a -> k_alpha_draw
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
@@ -187,34 +186,65 @@ __device__ __forceinline__ Tile tile_of_block(int chain_base)
     return t;
 }
 
-__device__ __forceinline__ int global_wave(int blk) { return blk * (blockDim.x >> 6) + (threadIdx.x >> 6); }
-
-// Each wave writes one partial per quantity: out[q * nw + wave].
+// Partial sums are kept per BLOCK.  With one wave per block (small problems, where latency rules) this
+// needs no LDS and no barrier at all; with several waves the block combines its waves through LDS (one
+// barrier), so that the number of partials -- which every consumer block re-reads in full -- grows with
+// n / threads-per-block, not with the number of waves.
 template <int NQ>
-__device__ __forceinline__ void wave_partials(const double (&v)[NQ], double *out, int nw, int blk)
+__device__ __forceinline__ void block_partials(const double (&v)[NQ], double *out, int nb, int blk)
 {
-    const int gw = global_wave(blk);
+    __shared__ double s_part[MAX_WAVES * NQ];
+    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double r[NQ];
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        const double r = wave_sum(v[qi]);
-        if ((threadIdx.x & 63) == 0) out[qi * nw + gw] = r;
+    for (int qi = 0; qi < NQ; ++qi) r[qi] = wave_sum(v[qi]);
+    if (nw == 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) out[qi * nb + blk] = r[qi];
+        }
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) s_part[wave * NQ + qi] = r[qi];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NQ) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += s_part[w * NQ + threadIdx.x];
+        out[threadIdx.x * nb + blk] = t;
     }
 }
 
-// Every wave reduces all nw partials of NQ quantities itself (registers only).
+// Every block reduces all nb partials of NQ quantities in the same fixed order (registers only when the
+// block is one wave; otherwise wave 0 reduces and broadcasts through LDS).
 template <int NQ>
-__device__ __forceinline__ void reduce_partials(const double *part, int nw, double (&out)[NQ])
+__device__ __forceinline__ void reduce_partials(const double *part, int nb, double (&out)[NQ])
 {
+    __shared__ double s_tot[NQ];
     const int lane = threadIdx.x & 63;
-    double acc[NQ];
+    const bool one_wave = blockDim.x == 64;
+    if (one_wave || threadIdx.x < 64) {
+        double acc[NQ];
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0;
-    for (int b = lane; b < nw; b += 64) {
+        for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0;
+        for (int b = lane; b < nb; b += 64) {
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) acc[qi] += part[qi * nw + b];
+            for (int qi = 0; qi < NQ; ++qi) acc[qi] += part[qi * nb + b];
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) out[qi] = wave_sum(acc[qi]);
+        if (!one_wave && lane == 0) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) s_tot[qi] = out[qi];
+        }
     }
+    if (!one_wave) {
+        __syncthreads();
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) out[qi] = wave_sum(acc[qi]);
+        for (int qi = 0; qi < NQ; ++qi) out[qi] = s_tot[qi];
+    }
 }
 
 // Runtime quantity count (the p x p / q x q systems): waves share the quantities, results go to LDS.
@@ -392,9 +422,7 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
         for (int k = 0; k < width; ++k) qe += c.sell_val[base + k * 64 + lane] * eta[c.sell_col[base + k * 64 + lane]];
         quad[0] = eta_i * qe;
     }
-    const int gw = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const double r = wave_sum(quad[0]);
-    if ((threadIdx.x & 63) == 0) c.part_quad[(size_t)chain * c.nw_n + gw] = r;
+    block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
 }
 
 // Stand-alone omega_b of the CURRENT iteration: only needed when the start values or the state were
@@ -459,7 +487,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     const uint32_t it = ctl.it;
     double quad[1];
-    reduce_partials<1>(c.part_quad + (size_t)chain * c.nw_n, c.nw_n, quad);
+    reduce_partials<1>(c.part_quad + (size_t)chain * c.nb_n, c.nb_n, quad);
     // every lane draws the same tau from the same sub-stream (uniform control flow, no broadcast)
     const double rate = 0.5 * quad[0] + c.tau_rate;
     Cursor g(sc.key, 0u, it, STREAM_TAU);
@@ -508,7 +536,7 @@ __device__ __forceinline__ void projection_partials(const A &c, int chain, int i
         v[0] = x.x;
         v[1] = x.y;
     }
-    wave_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, blk);
+    block_partials<2>(v, c.part_proj + (size_t)chain * 2 * c.nb_n, c.nb_n, blk);
 }
 
 // Diagnostic builds (tools/kbench.hip) define OCC_STAMP to record s_memtime at a few points of
@@ -540,7 +568,7 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 // Everything k_minres needs to form its addresses, BY VALUE in the kernel argument block: with the
 // pointers in device memory every launch paid one more dependent (cache-cold) load level.
 struct KryArgs {
-    int n, nw_n, ell_w, pad;
+    int n, nb_n, ell_w, pad;
     long long maxiter;
     const int *sell_ptr, *sell_col;
     const double *sell_val, *qdiag;
@@ -573,13 +601,14 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     const double tau = sc.tau;
     Slot s = slot_load(&a.slots[(size_t)chain * NSLOT + ((kl - 1) & (NSLOT - 1))]);
     Slot *out = &a.slots[(size_t)chain * NSLOT + (kl & (NSLOT - 1))];
+    // partial sums of the previous launch: issued now, reduced after the vector loads are in flight
     double S[4] = {0.0, 0.0, 0.0, 0.0};
-    {
-        const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nw_n);
-        const int lane = threadIdx.x & 63;
-        for (int b = lane; b < a.nw_n; b += 64) {
+    if (blockDim.x == 64 || threadIdx.x < 64) {
+        const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nb_n);
+        const int ln = threadIdx.x & 63;
+        for (int b = ln; b < a.nb_n; b += 64) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) S[qi] += part[qi * a.nw_n + b];
+            for (int qi = 0; qi < 4; ++qi) S[qi] += part[qi * a.nb_n + b];
         }
     }
     int width = 0, base = 0;
@@ -646,8 +675,16 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     }
     OCC_STAMP(1)
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
-    if (k >= 2) {
-        S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]);
+    {
+        __shared__ double s_S[4];
+        if (blockDim.x == 64 || threadIdx.x < 64) {
+            S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]);
+            if (blockDim.x != 64 && threadIdx.x == 0) { s_S[0] = S0; s_S[1] = S1; s_S[2] = S2; s_S[3] = xn2; }
+        }
+        if (blockDim.x != 64) {  // wave 0 reduced; the other waves take the totals from LDS
+            __syncthreads();
+            S0 = s_S[0]; S1 = s_S[1]; S2 = s_S[2]; xn2 = s_S[3];
+        }
     }
     OCC_STAMP(2)
     const double eps = DBL_EPSILON;
@@ -788,7 +825,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     }
     OCC_STAMP(4)
     if (writer) slot_store(out, s);
-    wave_partials<4>(part, a.part_kry + ((size_t)chain * 2 + ((kl + 1) & 1)) * ((size_t)4 * a.nw_n), a.nw_n, blk);
+    block_partials<4>(part, a.part_kry + ((size_t)chain * 2 + ((kl + 1) & 1)) * ((size_t)4 * a.nb_n), a.nb_n, blk);
     OCC_STAMP(5)
 }
 
@@ -839,15 +876,15 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
             c.Wv[1][co + i] = wb;
         }
         if (blk == 0 && ((L + 1) & 1) != 1) {
-            const double *src = c.part_kry + ((size_t)chain * 2 + 0) * ((size_t)4 * c.nw_n);
-            double *dst = c.part_kry + ((size_t)chain * 2 + 1) * ((size_t)4 * c.nw_n);
-            for (int t = threadIdx.x; t < 4 * c.nw_n; t += blockDim.x) dst[t] = src[t];
+            const double *src = c.part_kry + ((size_t)chain * 2 + 0) * ((size_t)4 * c.nb_n);
+            double *dst = c.part_kry + ((size_t)chain * 2 + 1) * ((size_t)4 * c.nb_n);
+            for (int t = threadIdx.x; t < 4 * c.nb_n; t += blockDim.x) dst[t] = src[t];
         }
         return;
     }
     if (skip) return;
     double sums[2];
-    reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nw_n, c.nw_n, sums);
+    reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nb_n, c.nb_n, sums);
     const double a = -sums[0] / sums[1];
     double acc[nacc(P)];
 #pragma unroll
@@ -872,7 +909,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
     }
-    wave_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n, blk);
+    block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
 }
 
 template <int Q>
@@ -916,7 +953,7 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
             for (int a = 0; a < Q; ++a) acc[t++] = w[a] * tt;
         }
     }
-    wave_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, c.nw_r, blk);
+    block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
 }
 
 // alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one wave per chain.
@@ -929,7 +966,7 @@ __global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int Q = c.q;
-    reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nw_r, nacc(Q), c.nw_r, s_red);
+    reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
     if (threadIdx.x == 0) {
         const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
         const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
@@ -964,7 +1001,7 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
     double beta[P];
     {
         double sums[nacc(P)];
-        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nw_n, c.nw_n, sums);
+        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);
         const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
         const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, it, STREAM_BETA, beta);
         if (writer) {

@@ -200,3 +200,80 @@ def test_eta_solve_at_baseline_size_equals_the_reference_solver_call():
         assert np.all(z[prob.site_id[prob.obs_site.astype(bool)]] == 1.0)
         assert tau > 0 and np.all(om > 0)
     eng.close()
+
+
+def _lockstep(oracle, prob, start, n_iter, key=KEY):
+    from occuspytial_amd._engine import Engine
+    eng = Engine(prob, [key])
+    orc = oracle.OracleSampler(prob, key)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    for _ in range(n_iter):
+        eng.step()
+        orc.step()
+        _compare_iteration(eng, orc, prob)
+        for name in ('alpha', 'beta', 'tau', 'eta', 'z', 'xz'):
+            eng.set(name, orc.get(name))
+    eng.close()
+
+
+def _random_start(prob, seed):
+    rng = np.random.default_rng(seed)
+    eta = rng.standard_normal(prob.n)
+    return dict(alpha=rng.standard_normal(prob.q), beta=rng.standard_normal(prob.p), tau=0.9, eta=eta - eta.mean())
+
+
+def test_irregular_adjacency_with_long_rows_and_unsurveyed_sites(oracle):
+    """BASELINE config 5 in small: irregular areal graph (non-uniform row lengths, some rows longer than
+    the 8-slot prefetch window of k_minres, so the SELL slice table and the tail loop are exercised),
+    10 visits, three covariates each, 5 % of the units never surveyed."""
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_graph_problem
+    Q, W, X, y, *_ = make_graph_problem(n=700, k=8, visits=10, p=3, q=3, random_state=2)
+    assert np.diff(Q.indptr).max() - 1 > 8
+    for site in range(0, 700, 20):
+        del W[site], y[site]
+    prob = FlatProblem(Q, W, X, y)
+    assert len(prob.not_surveyed) == 35
+    _lockstep(oracle, prob, _random_start(prob, 4), 4)
+
+
+def test_one_covariate_and_eight_covariates(oracle):
+    """Edge sizes of the p x p / q x q systems: p = q = 1 and p = q = 8 (the supported maximum)."""
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    for d in (1, 8):
+        Q, W, X, y, *_ = make_lattice_problem(9, 11, visits=4, p=d, q=d, random_state=d)
+        prob = FlatProblem(Q, W, X, y)
+        _lockstep(oracle, prob, _random_start(prob, d), 3)
+
+
+def test_500x500_lattice_full_size_lockstep(oracle):
+    """BASELINE config 4 at full size: 250 000 sites, 1.25 M visit rows (the reference cannot construct
+    this case: dense eigenfactor).  Two lock-step iterations against the oracle, every conditional."""
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(500, 500, visits=5, p=2, q=2, random_state=0)
+    prob = FlatProblem(Q, W, X, y)
+    assert prob.n == 250_000 and prob.R == 1_250_000
+    _lockstep(oracle, prob, _random_start(prob, 9), 2)
+
+
+def test_eight_chains_of_config3_run_and_differ():
+    """BASELINE config 3's chain count on one device: 8 chains of the 100x100 problem in one batch."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem, chain_generators, default_start
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(100, 100, visits=5, p=2, q=2, random_state=0)
+    prob = FlatProblem(Q, W, X, y)
+    gens = chain_generators(10, 8)
+    starts = [default_start(g, prob) for g in gens]
+    eng = Engine(prob, [int(g.bit_generator.random_raw()) for g in gens])
+    for c, st in enumerate(starts):
+        eng.set_start(c, st['alpha'], st['beta'], st['tau'], st['eta'])
+    a, b, t = eng.run(60, 10)
+    assert a.shape == (8, 50, 2) and np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(t > 0)
+    assert len({round(float(v), 12) for v in t[:, -1]}) == 8
+    for c in range(8):
+        assert abs(eng.get('eta', c).sum()) < 1e-7 * np.abs(eng.get('eta', c)).sum()
+    eng.close()

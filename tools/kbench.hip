@@ -98,7 +98,7 @@ int main(int argc, char **argv)
     const int n = side * side, R = n * V, p = 2, q = 2;
     Ctx c{};
     c.n = n; c.S = n; c.R = R; c.p = p; c.q = q; c.C = C;
-    c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; c.nw_n = c.nb_n * (tpb / 64); c.nw_r = c.nb_r * (tpb / 64); c.nw_max = std::max(c.nw_n, c.nw_r);
+    c.nb_n = (n + tpb - 1) / tpb; c.nb_r = (R + tpb - 1) / tpb; 
     c.maxiter = 10LL * n; c.ell_w = 8; c.tau_rate = 0.005; c.tau_shape = 0.5 * n;
     // queen lattice SELL-64
     const int nslice = (n + 63) / 64;
@@ -143,9 +143,9 @@ int main(int argc, char **argv)
     for (int b = 0; b < 3; ++b) c.Pv[b] = dalloc<double2>(Cn);
     for (int b = 0; b < 2; ++b) { c.Gv[b] = dalloc<double2>(Cn); c.Wv[b] = dalloc<double2>(Cn); }
     c.Xv = dalloc<double2>(Cn);
-    c.part_quad = dalloc<double>((size_t)C * c.nw_n); c.part_kry = dalloc<double>((size_t)C * 8 * c.nw_n);
-    c.part_proj = dalloc<double>((size_t)C * 2 * c.nw_n); c.part_beta = dalloc<double>((size_t)C * nacc(p) * c.nw_n);
-    c.part_alpha = dalloc<double>((size_t)C * nacc(q) * c.nw_r);
+    c.part_quad = dalloc<double>((size_t)C * c.nb_n); c.part_kry = dalloc<double>((size_t)C * 8 * c.nb_n);
+    c.part_proj = dalloc<double>((size_t)C * 2 * c.nb_n); c.part_beta = dalloc<double>((size_t)C * nacc(p) * c.nb_n);
+    c.part_alpha = dalloc<double>((size_t)C * nacc(q) * c.nb_r);
     c.slots = dalloc<Slot>((size_t)C * NSLOT);
     c.sc = dalloc<ChainScalars>(C);
     c.rec = nullptr;
@@ -159,7 +159,7 @@ int main(int argc, char **argv)
 
     Ctx *cp; CK(hipMalloc(&cp, sizeof(Ctx))); CK(hipMemcpy(cp, &c, sizeof(Ctx), hipMemcpyHostToDevice));
     KryArgs ka{};
-    ka.n = c.n; ka.nw_n = c.nw_n; ka.ell_w = c.ell_w; ka.maxiter = c.maxiter; ka.sell_ptr = c.sell_ptr; ka.sell_col = c.sell_col;
+    ka.n = c.n; ka.nb_n = c.nb_n; ka.ell_w = c.ell_w; ka.maxiter = c.maxiter; ka.sell_ptr = c.sell_ptr; ka.sell_col = c.sell_col;
     ka.sell_val = c.sell_val; ka.qdiag = c.qdiag; ka.omega_b[0] = c.omega_b[0]; ka.omega_b[1] = c.omega_b[1];
     for (int b = 0; b < 2; ++b) { ka.Gv[b] = c.Gv[b]; ka.Wv[b] = c.Wv[b]; }
     for (int b = 0; b < 3; ++b) ka.Pv[b] = c.Pv[b];
@@ -216,7 +216,7 @@ int main(int argc, char **argv)
         printf("solve graph (eta_init + 12 minres): %.2f us per replay (stamped build)\n", 1000.0 * ms / 50);
         std::vector<unsigned long long> h((size_t)24 * 8 * 8192);
         CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp), h.size() * 8));
-        const int nw = c.nw_n * C;
+        const int nw = c.nb_n * C;
         for (int k : {2, 6, 10}) {
             double m[6] = {0};
             for (int w = 0; w < nw; ++w) for (int q2 = 1; q2 < 6; ++q2) m[q2] += (double)(h[((size_t)k * 8192 + w) * 8 + q2] - h[((size_t)k * 8192 + w) * 8]);
