@@ -48,6 +48,22 @@ def minres_bytes_per_launch(prob, n_chains, sell_entries):
     return n_chains * prob.n * 168 + prob.n * 8 + sell_entries * 12
 
 
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_pmc_hbm_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied).
+    Counters cannot be read from inside this process; the value is only reported for the workload the
+    pass was taken on, else null."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    if d.get('workload') != workload_key:
+        return None
+    k = d['kernels'].get(kernel)
+    return k['hbm_bytes_per_launch'] if k else None
+
+
 def sell_entry_count(prob):
     """Stored SELL-64 off-diagonal slots (64 x max off-diagonal row length per 64-row slice)."""
     deg = np.diff(prob.Q.indptr) - (prob.Q.diagonal() != 0)
@@ -200,7 +216,9 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_minres',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 4),
+                'traffic': pmc_traffic('occ::k_minres', f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else None,
+                'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)',
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
                 'timing': 'HIP events on the engine stream around 200 replays of a captured solve prefix '
