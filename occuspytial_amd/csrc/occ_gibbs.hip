@@ -353,8 +353,14 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    {   // the main stream carries the critical path (the eta solve): highest priority; the side stream's
+        // Polya-Gamma kernels fill whatever the solve leaves idle
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
+        HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
+        HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
+    }
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));

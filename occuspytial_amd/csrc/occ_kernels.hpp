@@ -478,6 +478,7 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
 
 __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 {
+    __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
@@ -587,6 +588,7 @@ struct KryArgs {
 __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base, int e, int k_launch)
 {
     OCC_STAMP(0)
+    __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of co-resident Polya-Gamma waves of the side stream
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = a.scs[chain];
@@ -832,6 +834,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
 template <int P>
 __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_launch)
 {
+    __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
@@ -983,6 +986,7 @@ __global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
 template <int P>
 __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
 {
+    __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
