@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,8 @@ struct occ_sampler {
     int device = 0;
     hipStream_t stream = nullptr;  // main: eta_init -> minres ... -> beta -> z_ob
     hipStream_t side = nullptr;    // side: omega_a -> alpha_draw -> noise(t+1), forked/joined inside the graph
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool side_enabled = true;   // false: OCC_NO_SIDE_STREAM diagnostic
     Ctx ctx{};               // host copy of the descriptor
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
@@ -42,10 +44,20 @@ struct occ_sampler {
     // start values / state were just set by the host: omega_b and the noise of the current iteration
     // have to be produced stand-alone before the first sequence
     bool need_prologue = true;
-    // graph replay: GRAPH_SLOTS (even) launch sequences per graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // graph replay.  Every captured graph is a LINEAR chain replayed on one of the engine's own two
+    // streams: head[e] = k_eta_init, cap + 3 Krylov launches, k_beta_partial on the main stream;
+    // tail[e] = k_omega_a, k_alpha_draw, k_noise on the side stream; the fork/join between them is two
+    // events per iteration.  (Graphs with parallel branches get runtime-internal streams at every
+    // instantiation; on ROCm 7.2 the second or third such instantiation shares a hardware queue with the
+    // launch stream and every kernel then runs 2-5x slower.  Linear graphs can be re-instantiated freely,
+    // which the adaptive Krylov cap needs.)
+    hipGraph_t head_graph[2] = {nullptr, nullptr}, tail_graph[2] = {nullptr, nullptr};
+    hipGraphExec_t head[2] = {nullptr, nullptr}, tail[2] = {nullptr, nullptr};
+    hipEvent_t ev_z[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
     int krylov_cap = 0;
+    std::vector<std::vector<hipGraphNode_t>> kn;     // Krylov nodes [sequence][launch - 1]
+    std::vector<hipGraphNode_t> bp_nodes;            // k_beta_partial node of each sequence
+    std::vector<int> bp_arg;                         // its k_last_launch argument
     // statistics
     int64_t iterations = 0, graph_launches = 0, eager_iterations = 0, stalls = 0;
     int krylov_last = 0;
@@ -61,14 +73,6 @@ struct occ_sampler {
 };
 
 namespace {
-
-// launch sequences per captured graph (even, so that the parity of the control words is preserved)
-static int graph_slots()
-{
-    static const int v = [] { const char *e = std::getenv("OCC_GRAPH_SLOTS"); int n = e ? std::atoi(e) : 2; return std::max(2, n & ~1); }();
-    return v;
-}
-#define GRAPH_SLOTS graph_slots()
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -247,48 +251,78 @@ int eager_sequence(occ_sampler *s)
     return OCC_OK;
 }
 
-void destroy_graph(occ_sampler *s)
+void destroy_head(occ_sampler *s)
 {
-    if (s->exec) (void)hipGraphExecDestroy(s->exec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
-    s->exec = nullptr;
-    s->graph = nullptr;
+    for (int e = 0; e < 2; ++e) {
+        if (s->head[e]) (void)hipGraphExecDestroy(s->head[e]);
+        if (s->head_graph[e]) (void)hipGraphDestroy(s->head_graph[e]);
+        s->head[e] = nullptr;
+        s->head_graph[e] = nullptr;
+    }
 }
 
-// Capture GRAPH_SLOTS launch sequences.  Per sequence: the side stream forks at the start
-// (omega_a -> alpha_draw -> noise of the next iteration) and joins before k_z_ob; the main stream runs
-// eta_init, `cap` + 3 Krylov launches (iteration j is tested by launch j + 3), beta_partial, beta_draw.
-// A solve that needs more launches is carried into the next sequence by the kernels themselves
-// (Ctl::koff), so `cap` trades empty launches against carried sequences.
+void destroy_graph(occ_sampler *s)
+{
+    destroy_head(s);
+    for (int e = 0; e < 2; ++e) {
+        if (s->tail[e]) (void)hipGraphExecDestroy(s->tail[e]);
+        if (s->tail_graph[e]) (void)hipGraphDestroy(s->tail_graph[e]);
+        s->tail[e] = nullptr;
+        s->tail_graph[e] = nullptr;
+    }
+}
+
+// Capture the per-parity chains.  Iteration j of a solve is tested by launch j + 3, so `cap` iterations
+// need cap + 3 Krylov launches; a solve that needs more is carried into the next sequence by the kernels
+// themselves (Ctl::koff), so `cap` trades empty launches against carried sequences.  Only the head
+// depends on `cap`; the side chains are captured once.
 int build_graph(occ_sampler *s, int cap)
 {
-    destroy_graph(s);
-    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int e = s->parity;
-    for (int slot = 0; slot < GRAPH_SLOTS; ++slot, e ^= 1) {
-        // main chain first, so that the graph executor keeps it on the launch queue (a cross-queue
-        // dependency costs 10-18 us on MI355X; only the side work should pay it)
-        HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+    const bool verbose = std::getenv("OCC_VERBOSE") != nullptr;
+    const auto host_t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    destroy_head(s);
+    for (int e = 0; e < 2; ++e) {
+        HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         launch_kind(s, s->stream, K_ETA_INIT, e);
         for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
         launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
-            if (std::getenv("OCC_NO_SIDE_STREAM")) {  // diagnostic: everything on one stream
-            launch_kind(s, s->stream, K_OMEGA_A, e);
-            launch_kind(s, s->stream, K_ALPHA_DRAW, e);
-            launch_kind(s, s->stream, K_NOISE, e, 1);
-        } else {
-            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-            launch_kind(s, s->side, K_OMEGA_A, e);
-            launch_kind(s, s->side, K_ALPHA_DRAW, e);
-            launch_kind(s, s->side, K_NOISE, e, 1);
-            HIP_TRY(hipEventRecord(s->ev_join, s->side));
-            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
-        }
-        launch_kind(s, s->stream, K_Z_OB, e);
+        HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[e]));
+        HIP_TRY(hipGraphInstantiate(&s->head[e], s->head_graph[e], nullptr, nullptr, 0));
+        if (s->tail[e]) continue;
+        HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
+        launch_kind(s, s->side, K_OMEGA_A, e);
+        launch_kind(s, s->side, K_ALPHA_DRAW, e);
+        launch_kind(s, s->side, K_NOISE, e, 1);
+        HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[e]));
+        HIP_TRY(hipGraphInstantiate(&s->tail[e], s->tail_graph[e], nullptr, nullptr, 0));
     }
-    HIP_TRY(hipStreamEndCapture(s->stream, &s->graph));
-    HIP_TRY(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
     s->krylov_cap = cap;
+    if (verbose) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+        std::fprintf(stderr, "[occ] graphs captured, Krylov cap %d: %.2f ms host time\n", cap, ms);
+    }
+    return OCC_OK;
+}
+
+// Enqueue one launch sequence (one Gibbs iteration of every chain, or a carried solve) without any
+// host synchronisation.  DAG: side chain after the previous k_z_ob; k_z_ob after head and side chain.
+int enqueue_sequence(occ_sampler *s)
+{
+    const int e = s->parity;
+    if (s->side_enabled) {
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_z[e ^ 1], 0));
+        HIP_TRY(hipGraphLaunch(s->tail[e], s->side));
+        HIP_TRY(hipEventRecord(s->ev_side[e], s->side));
+        HIP_TRY(hipGraphLaunch(s->head[e], s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[e], 0));
+    } else {  // diagnostic (OCC_NO_SIDE_STREAM): the same kernels in one stream
+        HIP_TRY(hipGraphLaunch(s->tail[e], s->stream));
+        HIP_TRY(hipGraphLaunch(s->head[e], s->stream));
+    }
+    launch_kind(s, s->stream, K_Z_OB, e);
+    if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[e], s->stream));
+    s->parity ^= 1;
     return OCC_OK;
 }
 
@@ -333,7 +367,7 @@ int occ_destroy(occ_sampler *s)
     destroy_graph(s);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->rec_buf) (void)hipFree(s->rec_buf);
-    for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_fork, s->ev_join})
+    for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -363,8 +397,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     }
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    for (int e = 0; e < 2; ++e) {
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_z[e], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming));
+    }
+    s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
 
     const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q, C = n_chains;
     Ctx &c = s->ctx;
@@ -665,7 +702,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         for (int64_t i = 0; i < n_iter; ++i)
             if ((rc = eager_sequence(s))) return rc;
         done_min = n_iter;
-    } else if (!s->exec) {
+    } else if (!s->head[0]) {
         const int64_t n_calib = std::min<int64_t>(n_iter, 3);
         s->calib_max = 0;
         for (int64_t i = 0; i < n_calib; ++i) {
@@ -679,21 +716,38 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     } else if (s->need_prologue) {
         launch_prologue(s);
     }
+    // the first side chain waits for "the previous k_z_ob": everything enqueued so far
+    if (done_min < n_iter && s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
         // solve into the next sequence; finished chains idle.  No host work inside a batch.
         const int64_t left = n_iter - done_min;
-        const int64_t batch = std::min<int64_t>((left + GRAPH_SLOTS - 1) / GRAPH_SLOTS, s->graph_launches < 64 ? 16 : 128);
-        for (int64_t b = 0; b < batch; ++b) HIP_TRY(hipGraphLaunch(s->exec, s->stream));
+        const int64_t batch = std::min<int64_t>(left, s->graph_launches < 128 ? 32 : 256);
+        const auto hl0 = std::chrono::steady_clock::now();
+        for (int64_t b = 0; b < batch; ++b)
+            if ((rc = enqueue_sequence(s))) return rc;
+        const auto hl1 = std::chrono::steady_clock::now();
         s->graph_launches += batch;
         if ((rc = read_scalars(s, h))) return rc;
+        if (std::getenv("OCC_VERBOSE")) {
+            const auto hl2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[occ] host: %.1f us per sequence to enqueue, %.1f us per sequence until the batch finished\n",
+                         std::chrono::duration<double, std::micro>(hl1 - hl0).count() / batch,
+                         std::chrono::duration<double, std::micro>(hl2 - hl0).count() / batch);
+        }
         if ((rc = check_device_errors(s, h))) return rc;
         done_min = n_iter;
         unsigned long long tot = 0, sq = 0, solves = 0;
         for (int ch = 0; ch < C; ++ch) {
             done_min = std::min<int64_t>(done_min, (int64_t)h[ch].ctl[s->parity].it - (int64_t)h[ch].it_base);
             tot += h[ch].krylov_total; sq += h[ch].krylov_sq_total; solves += h[ch].solves;
+        }
+        if (std::getenv("OCC_VERBOSE")) {
+            unsigned long long car = 0;
+            for (int ch = 0; ch < C; ++ch) car += h[ch].carries;
+            std::fprintf(stderr, "[occ] batch of %lld sequences: done_min %lld / %lld, carries so far %llu, cap %d\n",
+                         (long long)batch, (long long)done_min, (long long)n_iter, car, s->krylov_cap);
         }
         // re-size the captured solve from the solves since the last decision: mean + 2.5 sd
         const unsigned long long ds = solves - s->seen_solves;

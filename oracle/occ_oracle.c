@@ -137,19 +137,64 @@ static double pg_mass_texpon(double Z)
     double qdivp = 4.0 / M_PI * (exp(xb) + exp(xa));
     return 1.0 / (1.0 + qdivp);
 }
-/* inverse-Gaussian(1/Z, 1) truncated to (0, t] */
+/* Standard normal quantile, Wichura (1988) algorithm AS 241, PPND16 (relative accuracy ~1e-16). */
+static double horner8(const double *k, double x)
+{
+    double r = k[7];
+    for (int i = 6; i >= 0; --i) r = r * x + k[i];
+    return r;
+}
+static double ppnd16(double p)
+{
+    static const double a[8] = {3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3,
+                                1.3731693765509461125e4, 4.5921953931549871457e4, 6.7265770927008700853e4,
+                                3.3430575583588128105e4, 2.5090809287301226727e3};
+    static const double b[8] = {1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
+                                2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4,
+                                5.2264952788528545610e3};
+    static const double cc[8] = {1.42343711074968357734, 4.63033784615654529590, 5.76949722146069140550,
+                                 3.64784832476320460504, 1.27045825245236838258, 2.41780725177450611770e-1,
+                                 2.27238449892691845833e-2, 7.74545014278341407640e-4};
+    static const double d[8] = {1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
+                                1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4,
+                                1.05075007164441684324e-9};
+    static const double e[8] = {6.65790464350110377720, 5.46378491116411436990, 1.78482653991729133580,
+                                2.96560571828504891230e-1, 2.65321895265761230930e-2, 1.24266094738807843860e-3,
+                                2.71155556874348757815e-5, 2.01033439929228813265e-7};
+    static const double f[8] = {1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2,
+                                7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7,
+                                2.04426310338993978564e-15};
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        return q * horner8(a, r) / horner8(b, r);
+    }
+    double r = (q < 0.0) ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.0) { r -= 1.6; val = horner8(cc, r) / horner8(d, r); }
+    else { r -= 5.0; val = horner8(e, r) / horner8(f, r); }
+    return (q < 0.0) ? -val : val;
+}
+#define PG_P_LEVY 0.1056497736668553 /* P(N <= -1/sqrt(t)) = Phi(-1.25) */
+
+/* inverse-Gaussian(1/Z, 1) truncated to (0, t].
+ * Z < 1/t: Devroye's scheme -- propose from the mu = infinity member truncated to (0, t] (X = 1/N^2 with
+ * N standard normal, |N| >= 1/sqrt(t)) and accept with probability exp(-Z^2 X / 2).  The truncated
+ * normal tail is drawn by inversion, N = -Phi^-1(U Phi(-1/sqrt t)), instead of the usual pair-of-
+ * exponentials rejection loop: one uniform, no inner loop (on a 64-lane wave the inner loop runs as
+ * long as its unluckiest lane).
+ * Z >= 1/t: Michael-Schucany-Haas draws from IG(1/Z, 1) until one falls in (0, t]. */
 static double pg_rtigauss(cursor_t *c, double Z)
 {
     double X = PG_T + 1.0;
     if (1.0 / PG_T > Z) {
-        double alpha = 0.0, U = 1.0;
-        while (U > alpha) {
-            double E1 = cur_expo(c), E2 = cur_expo(c);
-            while (E1 * E1 > 2.0 * E2 / PG_T) { E1 = cur_expo(c); E2 = cur_expo(c); }
-            X = 1.0 + E1 * PG_T;
-            X = PG_T / (X * X);
-            alpha = exp(-0.5 * Z * Z * X);
-            U = cur_unif(c);
+        for (;;) {
+            const double U1 = cur_unif(c), U2 = cur_unif(c);
+            const double N = -ppnd16(U1 * PG_P_LEVY);
+            X = 1.0 / (N * N);
+            if (X > PG_T) X = PG_T;
+            if (U2 <= exp(-0.5 * Z * Z * X)) break;
         }
     } else {
         double mu = 1.0 / Z;
