@@ -88,8 +88,8 @@ int occ_step(occ_sampler *s);
 /* n_iter iterations of every chain; alpha/beta/tau of iterations >= burnin are recorded:
  * GibbsBase._run's loop (base.py:236-239) for all chains at once (gibbs/parallel.py:38-41).
  * out_alpha: [n_chains][n_iter-burnin][q], out_beta: [..][p], out_tau: [n_chains][n_iter-burnin].
- * After a short calibration the iteration is replayed as a hipGraph (two streams forked and joined
- * inside the graph: omega_a/alpha overlap the eta solve). */
+ * The iteration is replayed from captured hipGraphs on two streams (omega_a/alpha overlap the eta solve,
+ * see DESIGN.md). */
 int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta,
             double *out_tau);
 
@@ -112,6 +112,8 @@ typedef struct occ_stats {
     double krylov_mean;      /* mean MINRES iterations per solve since creation (all chains) */
     double last_run_ms;      /* device time of the last occ_run (HIP events on the engine's stream) */
     int32_t n_blocks_sites, n_blocks_rows, threads_per_block, n_chains;
+    int32_t persistent_solve; /* 1: the eta solve is one persistent launch (k_solve), 0: one launch per MINRES step */
+    int32_t solve_workgroups; /* workgroups per chain of the persistent solve */
 } occ_stats;
 int occ_get_stats(occ_sampler *s, occ_stats *out);
 
@@ -120,9 +122,11 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
  * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.  k_minres is
  * timed inside a replayed graph of a real solve prefix (k_eta_init + launches 1..8), see occ_gibbs.hip.
  * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 omega_a, 6 alpha_draw,
- * 7 z_ob (beta draw + z update + next iteration's omega_b).
+ * 7 z_ob (beta draw + z update + next iteration's omega_b), 8 solve (the persistent eta solve: counts[8] =
+ * steps of the timed solves (the slowest chain's MINRES iterations + 3 per solve), total_us[8] = time of
+ * those whole solves; zero when the engine does not use the persistent solve).
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
-#define OCC_N_KERNEL_KINDS 8
+#define OCC_N_KERNEL_KINDS 9
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
 

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "occ_kernels.hpp"
+#include "occ_solve.hpp"
 
 using namespace occ;
 
@@ -22,8 +22,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB };
-static_assert(K_Z_OB + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_SOLVE };
+static_assert(K_SOLVE + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
 
@@ -33,9 +33,14 @@ struct occ_sampler {
     hipStream_t side = nullptr;    // side: omega_a -> alpha_draw -> noise(t+1), forked/joined inside the graph
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool side_enabled = true;   // false: OCC_NO_SIDE_STREAM diagnostic
+    // fork/join as event wait/record nodes inside the two graphs: two graph launches per iteration and no
+    // graph -> kernel -> graph transitions on the critical path (8-13 us each on MI355X / ROCm 7.2)
+    bool event_nodes = true;
     Ctx ctx{};               // host copy of the descriptor
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
+    SolveArgs solve{};       // ... and of k_solve
+    bool persistent = false; // eta solve as one persistent launch (occ_solve.hpp) instead of one launch per MINRES step
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
@@ -44,20 +49,17 @@ struct occ_sampler {
     // start values / state were just set by the host: omega_b and the noise of the current iteration
     // have to be produced stand-alone before the first sequence
     bool need_prologue = true;
-    // graph replay.  Every captured graph is a LINEAR chain replayed on one of the engine's own two
-    // streams: head[e] = k_eta_init, cap + 3 Krylov launches, k_beta_partial on the main stream;
-    // tail[e] = k_omega_a, k_alpha_draw, k_noise on the side stream; the fork/join between them is two
-    // events per iteration.  (Graphs with parallel branches get runtime-internal streams at every
-    // instantiation; on ROCm 7.2 the second or third such instantiation shares a hardware queue with the
-    // launch stream and every kernel then runs 2-5x slower.  Linear graphs can be re-instantiated freely,
-    // which the adaptive Krylov cap needs.)
+    // graph replay.  Every graph is a LINEAR chain replayed on one of the engine's own two streams:
+    // head[e] = k_eta_init, the eta solve (k_solve, or cap + 3 k_minres launches), k_beta_partial, wait for the
+    // side chain, k_z_ob, record -- on the main stream; tail[e] = wait for the previous k_z_ob, k_omega_a,
+    // k_alpha_draw, k_noise, record -- on the side stream.  (Graphs with parallel branches get
+    // runtime-internal streams at every instantiation; on ROCm 7.2 the second or third such instantiation
+    // shares a hardware queue with the launch stream and every kernel then runs 2-5x slower.  Linear graphs
+    // can be re-instantiated freely, which the adaptive Krylov cap of the k_minres path needs.)
     hipGraph_t head_graph[2] = {nullptr, nullptr}, tail_graph[2] = {nullptr, nullptr};
     hipGraphExec_t head[2] = {nullptr, nullptr}, tail[2] = {nullptr, nullptr};
     hipEvent_t ev_z[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
     int krylov_cap = 0;
-    std::vector<std::vector<hipGraphNode_t>> kn;     // Krylov nodes [sequence][launch - 1]
-    std::vector<hipGraphNode_t> bp_nodes;            // k_beta_partial node of each sequence
-    std::vector<int> bp_arg;                         // its k_last_launch argument
     // statistics
     int64_t iterations = 0, graph_launches = 0, eager_iterations = 0, stalls = 0;
     int krylov_last = 0;
@@ -174,6 +176,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
+        case K_SOLVE: hipLaunchKernelGGL(k_solve, dim3((unsigned)s->solve.nbg, (unsigned)c.C), dim3(SOLVE_WG), 0, st, s->solve, e); break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
     }
 }
@@ -197,6 +200,11 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
     for (size_t c = 0; c < h.size(); ++c) {
         if (h[c].err == OCC_E_MINRES) { s->err = "MINRES solver did not converge!"; return OCC_E_MINRES; }
         if (h[c].err == OCC_E_CHOLESKY) { s->err = "Cholesky factorization/solver failed!"; return OCC_E_CHOLESKY; }
+        if (h[c].err == OCC_E_HIP) {
+            s->err = "persistent eta solve: a barrier among the workgroups of a chain timed out (device over-subscribed); "
+                     "set OCC_NO_PERSISTENT=1 to use one launch per MINRES step";
+            return OCC_E_HIP;
+        }
     }
     return OCC_OK;
 }
@@ -241,9 +249,13 @@ int eager_sequence(occ_sampler *s)
     launch_kind(s, s->stream, K_NOISE, e, 1);
     launch_kind(s, s->stream, K_ETA_INIT, e);
     int k_last = 0;
-    int rc = eager_krylov(s, 1, &k_last);
-    if (rc) return rc;
-    s->calib_max = std::max(s->calib_max, k_last - 3);
+    if (s->persistent) {
+        launch_kind(s, s->stream, K_SOLVE, e);  // leaves the final scalars in slot 0
+    } else {
+        int rc = eager_krylov(s, 1, &k_last);
+        if (rc) return rc;
+        s->calib_max = std::max(s->calib_max, k_last - 3);
+    }
     launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
     launch_kind(s, s->stream, K_Z_OB, e);
     s->parity ^= 1;
@@ -272,6 +284,21 @@ void destroy_graph(occ_sampler *s)
     }
 }
 
+// The last node of a linear graph (the only node nothing depends on).
+int graph_leaf(occ_sampler *s, hipGraph_t graph, hipGraphNode_t *leaf)
+{
+    size_t n = 0;
+    HIP_TRY(hipGraphGetNodes(graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    HIP_TRY(hipGraphGetNodes(graph, nodes.data(), &n));
+    for (hipGraphNode_t nd : nodes) {
+        size_t deps = 0;
+        HIP_TRY(hipGraphNodeGetDependentNodes(nd, nullptr, &deps));
+        if (deps == 0) { *leaf = nd; return OCC_OK; }
+    }
+    return set_error(s, OCC_E_HIP, "captured graph has no leaf node");
+}
+
 // Capture the per-parity chains.  Iteration j of a solve is tested by launch j + 3, so `cap` iterations
 // need cap + 3 Krylov launches; a solve that needs more is carried into the next sequence by the kernels
 // themselves (Ctl::koff), so `cap` trades empty launches against carried sequences.  Only the head
@@ -282,19 +309,50 @@ int build_graph(occ_sampler *s, int cap)
     const auto host_t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
+    int rc;
     for (int e = 0; e < 2; ++e) {
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         launch_kind(s, s->stream, K_ETA_INIT, e);
-        for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
-        launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
+        if (s->persistent) {
+            launch_kind(s, s->stream, K_SOLVE, e);
+            launch_kind(s, s->stream, K_BETA_PARTIAL, e, 0);
+        } else {
+            for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
+            launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
+        }
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[e]));
+        if (s->event_nodes) {  // ... -> wait(side chain of this iteration) -> k_z_ob -> record
+            hipGraphNode_t leaf, wait, rec;
+            if ((rc = graph_leaf(s, s->head_graph[e], &leaf))) return rc;
+            HIP_TRY(hipGraphAddEventWaitNode(&wait, s->head_graph[e], &leaf, 1, s->ev_side[e]));
+            HIP_TRY(hipStreamBeginCaptureToGraph(s->stream, s->head_graph[e], &wait, nullptr, 1, hipStreamCaptureModeThreadLocal));
+            launch_kind(s, s->stream, K_Z_OB, e);
+            hipGraph_t same = nullptr;
+            HIP_TRY(hipStreamEndCapture(s->stream, &same));
+            if ((rc = graph_leaf(s, s->head_graph[e], &leaf))) return rc;
+            HIP_TRY(hipGraphAddEventRecordNode(&rec, s->head_graph[e], &leaf, 1, s->ev_z[e]));
+        }
         HIP_TRY(hipGraphInstantiate(&s->head[e], s->head_graph[e], nullptr, nullptr, 0));
         if (s->tail[e]) continue;
-        HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
-        launch_kind(s, s->side, K_OMEGA_A, e);
-        launch_kind(s, s->side, K_ALPHA_DRAW, e);
-        launch_kind(s, s->side, K_NOISE, e, 1);
-        HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[e]));
+        if (s->event_nodes) {  // wait(previous k_z_ob) -> side chain -> record
+            hipGraphNode_t leaf, wait, rec;
+            HIP_TRY(hipGraphCreate(&s->tail_graph[e], 0));
+            HIP_TRY(hipGraphAddEventWaitNode(&wait, s->tail_graph[e], nullptr, 0, s->ev_z[e ^ 1]));
+            HIP_TRY(hipStreamBeginCaptureToGraph(s->side, s->tail_graph[e], &wait, nullptr, 1, hipStreamCaptureModeThreadLocal));
+            launch_kind(s, s->side, K_OMEGA_A, e);
+            launch_kind(s, s->side, K_ALPHA_DRAW, e);
+            launch_kind(s, s->side, K_NOISE, e, 1);
+            hipGraph_t same = nullptr;
+            HIP_TRY(hipStreamEndCapture(s->side, &same));
+            if ((rc = graph_leaf(s, s->tail_graph[e], &leaf))) return rc;
+            HIP_TRY(hipGraphAddEventRecordNode(&rec, s->tail_graph[e], &leaf, 1, s->ev_side[e]));
+        } else {
+            HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
+            launch_kind(s, s->side, K_OMEGA_A, e);
+            launch_kind(s, s->side, K_ALPHA_DRAW, e);
+            launch_kind(s, s->side, K_NOISE, e, 1);
+            HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[e]));
+        }
         HIP_TRY(hipGraphInstantiate(&s->tail[e], s->tail_graph[e], nullptr, nullptr, 0));
     }
     s->krylov_cap = cap;
@@ -310,6 +368,12 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
+    if (s->event_nodes) {  // the graphs carry their own waits and records
+        HIP_TRY(hipGraphLaunch(s->tail[e], s->side));
+        HIP_TRY(hipGraphLaunch(s->head[e], s->stream));
+        s->parity ^= 1;
+        return OCC_OK;
+    }
     if (s->side_enabled) {
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_z[e ^ 1], 0));
         HIP_TRY(hipGraphLaunch(s->tail[e], s->side));
@@ -402,6 +466,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming));
     }
     s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
+    s->event_nodes = s->side_enabled && std::getenv("OCC_STREAM_EVENTS") == nullptr;  // diagnostic: fork/join by stream calls
 
     const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q, C = n_chains;
     Ctx &c = s->ctx;
@@ -525,6 +590,19 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     // ---- launch geometry: one site (or visit row) per thread; enough blocks to spread over the CUs
     int tpb = 256;
     while (tpb > 64 && ((long long)n * C + tpb - 1) / tpb < 512) tpb >>= 1;
+    // Persistent eta solve (occ_solve.hpp): every workgroup of every chain must be resident at once -- one per
+    // CU, with margin for the side stream's kernels -- and a matrix row must fit the register-resident
+    // neighbour window.  Its partial sums are per 64-site slice, so the other kernels use 64-thread blocks too.
+    {
+        int wmax = 0;
+        for (int sl = 0; sl < nslice; ++sl) wmax = std::max(wmax, (sell_ptr[sl + 1] - sell_ptr[sl]) / 64);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        const int nbg = (n + SOLVE_WG - 1) / SOLVE_WG;
+        s->solve.nbg = nbg;
+        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= prop.multiProcessorCount;
+        if (s->persistent) tpb = 64;
+    }
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
@@ -571,6 +649,12 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if ((rc = dev_alloc(s, &c.slots, (size_t)C * NSLOT))) return rc;
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
+    c.bar = nullptr;
+    if (s->persistent) {
+        if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
+        if ((rc = dev_alloc(s, &s->solve.part, (size_t)C * 2 * c.nb_n * 4))) return rc;
+        s->solve.bar = c.bar;
+    }
 
     // initial occupancy state (base.py:113-119) and chain keys
     std::vector<uint8_t> z0(Cn, 1);
@@ -589,6 +673,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         for (int b = 0; b < 2; ++b) { k.Gv[b] = c.Gv[b]; k.Wv[b] = c.Wv[b]; }
         for (int b = 0; b < 3; ++b) k.Pv[b] = c.Pv[b];
         k.Xv = c.Xv; k.part_kry = c.part_kry; k.part_proj = c.part_proj; k.scs = c.sc; k.slots = c.slots;
+        s->solve.a = k;
     }
     if ((rc = dev_alloc(s, &s->ctx_dev, 1, false))) return rc;
     HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
@@ -702,6 +787,9 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         for (int64_t i = 0; i < n_iter; ++i)
             if ((rc = eager_sequence(s))) return rc;
         done_min = n_iter;
+    } else if (!s->head[0] && s->persistent) {
+        if ((rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
+        if (s->need_prologue) launch_prologue(s);
     } else if (!s->head[0]) {
         const int64_t n_calib = std::min<int64_t>(n_iter, 3);
         s->calib_max = 0;
@@ -751,7 +839,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         }
         // re-size the captured solve from the solves since the last decision: mean + 2.5 sd
         const unsigned long long ds = solves - s->seen_solves;
-        if (!force && ds >= 32 && done_min < n_iter) {
+        if (!force && !s->persistent && ds >= 32 && done_min < n_iter) {
             const double mean = (double)(tot - s->seen_tot) / ds;
             const double var = std::max(0.0, (double)(sq - s->seen_sq) / ds - mean * mean);
             const int want = std::max(4, (int)std::ceil(mean + 2.5 * std::sqrt(var)));
@@ -902,6 +990,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->n_blocks_rows = s->ctx.nb_r;
     out->threads_per_block = s->tpb;
     out->n_chains = s->ctx.C;
+    out->persistent_solve = s->persistent ? 1 : 0;
+    out->solve_workgroups = s->solve.nbg;
     return OCC_OK;
 }
 
@@ -978,6 +1068,42 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         counts[K_MINRES] = (int64_t)reps * KRY_TIMED;
         total_us[K_MINRES] = std::max(0.0, per_replay_us - eta_us) * reps;
     }
+    // the persistent solve: replays of {restore the warm start, k_eta_init, k_solve} minus replays of
+    // {restore the warm start, k_eta_init}; every replay redoes the same solve
+    counts[K_SOLVE] = 0;
+    total_us[K_SOLVE] = 0.0;
+    if (s->persistent) {
+        const size_t xbytes = sizeof(double2) * (size_t)s->ctx.C * s->ctx.n;
+        HIP_TRY(hipMemcpyAsync(s->ctx.Pv[1], s->ctx.Xv, xbytes, hipMemcpyDeviceToDevice, s->stream));  // Pv[1]: scratch here
+        double per_replay_us[2] = {0.0, 0.0};
+        for (int with_solve = 0; with_solve < 2; ++with_solve) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
+            launch_kind(s, s->stream, K_ETA_INIT, e);
+            if (with_solve) launch_kind(s, s->stream, K_SOLVE, e);
+            HIP_TRY(hipStreamEndCapture(s->stream, &graph));
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphLaunch(exec, s->stream));
+            HIP_TRY(hipEventRecord(s->ev0, s->stream));
+            for (int r = 0; r < reps; ++r) HIP_TRY(hipGraphLaunch(exec, s->stream));
+            HIP_TRY(hipEventRecord(s->ev1, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
+            per_replay_us[with_solve] = 1000.0 * ms / reps;
+        }
+        std::vector<Slot> hs((size_t)s->ctx.C * NSLOT);
+        HIP_TRY(hipMemcpy(hs.data(), s->ctx.slots, sizeof(Slot) * hs.size(), hipMemcpyDeviceToHost));
+        int steps = 0;  // the launch lasts as long as its slowest chain: iterations + 3 steps
+        for (int ch = 0; ch < s->ctx.C; ++ch) steps = std::max(steps, hs[(size_t)ch * NSLOT].itn + 3);
+        counts[K_SOLVE] = (int64_t)reps * steps;
+        total_us[K_SOLVE] = std::max(0.0, per_replay_us[1] - per_replay_us[0]) * reps;
+        HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
+    }
     // finish that solve so that the tail kernels have real work
     int k_last = 0;
     launch_kind(s, s->stream, K_ETA_INIT, e);
@@ -990,5 +1116,16 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     s->need_prologue = true;
     return OCC_OK;
 }
+
+#ifdef OCC_SOLVE_STAMPS
+// developer build only: the time stamps of the last k_solve launch (chain 0, workgroup 0)
+int occ_debug_solve_stamps(unsigned long long *out, int capacity)
+{
+    const int n = STAMP_STEPS * STAMP_POINTS;
+    if (capacity < n) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_solve_stamps), sizeof(unsigned long long) * n) != hipSuccess) return -2;
+    return n;
+}
+#endif
 
 }  // extern "C"

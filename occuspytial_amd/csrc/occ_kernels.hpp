@@ -135,6 +135,7 @@ struct Ctx {
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
+    unsigned *bar;      // [C][32] arrival counters of the persistent solve (occ_solve.hpp); null: not used
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -497,6 +498,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
         sc.tau = tau;
         Slot s = {};
         slot_store(&slots[(size_t)chain * NSLOT], s);
+        if (c.bar) c.bar[(size_t)chain * 32] = 0u;  // the coming k_solve counts its barrier arrivals from zero
     }
     const double st = sqrt(tau);
     if (i < n) {
@@ -545,6 +547,126 @@ __device__ __forceinline__ void projection_partials(const A &c, int chain, int i
 #ifndef OCC_STAMP
 #define OCC_STAMP(n)
 #endif
+
+
+// ---- MINRES: the arithmetic shared by the launch-per-iteration kernel (k_minres) and the persistent
+// solve kernel (k_solve, occ_solve.hpp).  Both kernels run the SAME scalar recurrence and the same
+// explicitly contracted vector expressions, so a solve gives the same bits whichever of them ran it.
+struct KryStep {
+    double ca, cb, cc;                     // p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}
+    double sj, oldeps, delta, denom, phi;  // rotation of iteration k-2: w = (sj p_{k-3} - oldeps w_{k-4} - delta w_{k-3}) denom
+    bool rotate;                           // k >= 3: w_{k-2}, x_{k-2} are formed in this step
+    bool stop;                             // the solve ended BEFORE this step (slot final: take the projection sums)
+};
+
+// Step k of a solve (k = 1, 2, ...), given the slot after step k-1 and the sums of step k-1:
+// S0 = ||p_{k-2}||^2, S1 = p_{k-2}.g_{k-1}, S2 = p_{k-2}.p_{k-3}, xn2 = ||x_{k-3}||^2.
+//   (a) k >= 4: stopping test of iteration k-3, exactly scipy's (minres.py, "Estimate various norms")
+//   (b) k >= 2: beta_{k-1}, alfa_{k-1}
+//   (c) k >= 3: rotation of iteration k-2 (needs beta_{k-1})
+__device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+{
+    KryStep st;
+    st.ca = st.cb = st.cc = 0.0;
+    st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
+    st.rotate = false;
+    st.stop = false;
+    const double eps = DBL_EPSILON;
+    if (k >= 4) {  // (a)
+        const int j = k - 3;
+        const double rtol = 1e-5;
+        const double Anorm = sqrt(s.tnorm2);
+        const double ynorm = sqrt(xn2);
+        const double epsx = Anorm * ynorm * eps;
+        const double rnorm = s.phibar;
+        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+        const double test2 = (Anorm == 0.0) ? INFINITY : s.root / Anorm;
+        const double Acond = s.gmax / s.gmin;
+        int istop = s.istop;
+        if (istop == 0) {
+            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+            if (t2 <= 1.0) istop = 2;
+            if (t1 <= 1.0) istop = 1;
+            if ((long long)j >= maxiter) istop = 6;
+            if (Acond >= 0.1 / eps) istop = 4;
+            if (epsx >= s.beta1) istop = 3;
+            if (test2 <= rtol) istop = 2;
+            if (test1 <= rtol) istop = 1;
+        }
+        if (istop != 0) {
+            s.istop = istop; s.itn = j; s.done = 1;
+            st.stop = true;
+            return st;
+        }
+    }
+    if (k >= 2) {  // (b)
+        if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
+            s.done = 1; s.istop = 0; s.itn = 0;
+            st.stop = true;
+            return st;
+        }
+        const double beta_km1 = sqrt(S0);      // beta_{k-1}
+        const double beta_km2 = s.beta;        // beta_{k-2} (k >= 3)
+        double alfa_km1 = S1 / S0;             // (p.g)/beta^2
+        if (k >= 3) alfa_km1 = alfa_km1 - S2 / beta_km2;
+        if (k == 2) {
+            s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
+            s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
+            s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
+        } else {  // (c) rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
+            const int j = k - 2;
+            const double alfa = s.alfa, beta_j = beta_km2, beta_n = beta_km1;
+            s.oldb = beta_j;
+            s.tnorm2 += alfa * alfa + beta_j * beta_j + beta_n * beta_n;
+            if (j == 1 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
+            st.oldeps = s.epsln;
+            st.delta = s.cs * s.dbar + s.sn * alfa;
+            const double gbar = s.sn * s.dbar - s.cs * alfa;
+            s.epsln = s.sn * beta_n;
+            s.dbar = -s.cs * beta_n;
+            s.root = sqrt(gbar * gbar + s.dbar * s.dbar);
+            double gamma = sqrt(gbar * gbar + beta_n * beta_n);
+            gamma = fmax(gamma, eps);
+            s.cs = gbar / gamma;
+            s.sn = beta_n / gamma;
+            st.phi = s.cs * s.phibar;
+            s.phibar = s.sn * s.phibar;
+            st.denom = 1.0 / gamma;
+            s.gmax = fmax(s.gmax, gamma);
+            s.gmin = fmin(s.gmin, gamma);
+            const double zz = s.rhs1 / gamma;
+            s.rhs1 = s.rhs2 - st.delta * zz;
+            s.rhs2 = -s.epsln * zz;
+            st.sj = 1.0 / beta_j;
+            st.rotate = true;
+            st.cb = beta_km1 / beta_km2;
+        }
+        st.ca = 1.0 / beta_km1;
+        st.cc = alfa_km1 / beta_km1;
+        s.beta = beta_km1;
+        s.alfa = alfa_km1;
+    }
+    s.itn = k;
+    return st;
+}
+
+// p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}, contracted the same way wherever it is formed
+__device__ __forceinline__ double2 kry_form_p(const KryStep &st, double2 g, double2 p3, double2 p2)
+{
+    double2 p;
+    p.x = fma(-st.cc, p2.x, fma(-st.cb, p3.x, st.ca * g.x));
+    p.y = fma(-st.cc, p2.y, fma(-st.cb, p3.y, st.ca * g.y));
+    return p;
+}
+// w_j = (v_j - oldeps w_{j-2} - delta w_{j-1}) / gamma with v_j = p_{j-1} / beta_j;  x_j = x_{j-1} + phi w_j
+__device__ __forceinline__ double2 kry_form_w(const KryStep &st, double2 p3, double2 w1, double2 w2)
+{
+    double2 w;
+    w.x = fma(-st.delta, w2.x, fma(-st.oldeps, w1.x, st.sj * p3.x)) * st.denom;
+    w.y = fma(-st.delta, w2.y, fma(-st.oldeps, w1.y, st.sj * p3.y)) * st.denom;
+    return w;
+}
+__device__ __forceinline__ double dot2(double2 a, double2 b) { return fma(a.y, b.y, a.x * b.x); }
 
 constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known (queen lattice: all)
 
@@ -689,104 +811,28 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         }
     }
     OCC_STAMP(2)
-    const double eps = DBL_EPSILON;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
-    if (k >= 4) {  // (a) stopping test of iteration j = k-3 (minres.py, "Estimate various norms ...")
-        const int j = k - 3;
-        const double rtol = 1e-5;
-        const double Anorm = sqrt(s.tnorm2);
-        const double ynorm = sqrt(xn2);
-        const double epsx = Anorm * ynorm * eps;
-        const double rnorm = s.phibar;
-        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
-        const double test2 = (Anorm == 0.0) ? INFINITY : s.root / Anorm;
-        const double Acond = s.gmax / s.gmin;
-        int istop = s.istop;
-        if (istop == 0) {
-            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
-            if (t2 <= 1.0) istop = 2;
-            if (t1 <= 1.0) istop = 1;
-            if ((long long)j >= a.maxiter) istop = 6;
-            if (Acond >= 0.1 / eps) istop = 4;
-            if (epsx >= s.beta1) istop = 3;
-            if (test2 <= rtol) istop = 2;
-            if (test1 <= rtol) istop = 1;
-        }
-        if (istop != 0) {
-            s.istop = istop; s.itn = j; s.done = 1;
-            if (writer) slot_store(out, s);
-            projection_partials(a, chain, i, blk);
-            return;
-        }
+    const KryStep st = minres_scalars(s, k, S0, S1, S2, xn2, a.maxiter);
+    if (st.stop) {
+        if (writer) slot_store(out, s);
+        projection_partials(a, chain, i, blk);
+        return;
     }
-    // coefficients of p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}   (k = 1: p_0 is stored already)
-    double ca = 0.0, cb = 0.0, cc = 0.0;
-    if (k >= 2) {  // (b)
-        if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
-            s.done = 1; s.istop = 0; s.itn = 0;
-            if (writer) slot_store(out, s);
-            projection_partials(a, chain, i, blk);
-            return;
-        }
-        const double beta_km1 = sqrt(S0);      // beta_{k-1}
-        const double beta_km2 = s.beta;        // beta_{k-2} (k >= 3)
-        double alfa_km1 = S1 / S0;             // (p.g)/beta^2
-        if (k >= 3) alfa_km1 = alfa_km1 - S2 / beta_km2;
-        if (k == 2) {
-            s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
-            s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
-            s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
-        } else {  // (c) rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
-            const int j = k - 2;
-            const double alfa = s.alfa, beta_j = beta_km2, beta_n = beta_km1;
-            s.oldb = beta_j;
-            s.tnorm2 += alfa * alfa + beta_j * beta_j + beta_n * beta_n;
-            if (j == 1 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
-            const double oldeps = s.epsln;
-            const double delta = s.cs * s.dbar + s.sn * alfa;
-            const double gbar = s.sn * s.dbar - s.cs * alfa;
-            s.epsln = s.sn * beta_n;
-            s.dbar = -s.cs * beta_n;
-            s.root = sqrt(gbar * gbar + s.dbar * s.dbar);
-            double gamma = sqrt(gbar * gbar + beta_n * beta_n);
-            gamma = fmax(gamma, eps);
-            s.cs = gbar / gamma;
-            s.sn = beta_n / gamma;
-            const double phi = s.cs * s.phibar;
-            s.phibar = s.sn * s.phibar;
-            const double denom = 1.0 / gamma;
-            s.gmax = fmax(s.gmax, gamma);
-            s.gmin = fmin(s.gmin, gamma);
-            const double zz = s.rhs1 / gamma;
-            s.rhs1 = s.rhs2 - delta * zz;
-            s.rhs2 = -s.epsln * zz;
-            if (act) {  // w_j = (v_j - oldeps w_{j-2} - delta w_{j-1}) / gamma, v_j = p_{j-1}/beta_j
-                const double sj = 1.0 / beta_j;
-                double2 w;
-                w.x = (sj * p3_i.x - oldeps * w1.x - delta * w2.x) * denom;
-                w.y = (sj * p3_i.y - oldeps * w1.y - delta * w2.y) * denom;
-                x.x = x.x + phi * w.x;
-                x.y = x.y + phi * w.y;
-                Ww[i] = w;
-                a.Xv[co + i] = x;
-                part[3] = x.x * x.x + x.y * x.y;
-            }
-            cb = beta_km1 / beta_km2;
-        }
-        ca = 1.0 / beta_km1;
-        cc = alfa_km1 / beta_km1;
-        s.beta = beta_km1;
-        s.alfa = alfa_km1;
+    if (st.rotate && act) {
+        const double2 w = kry_form_w(st, p3_i, w1, w2);
+        x.x = fma(st.phi, w.x, x.x);
+        x.y = fma(st.phi, w.y, x.y);
+        Ww[i] = w;
+        a.Xv[co + i] = x;
+        part[3] = dot2(x, x);
     }
-    s.itn = k;
     OCC_STAMP(3)
     if (act) {
         double2 p;  // p_{k-1} at this site
         if (k == 1) {
             p = p2_i;  // p_0, already in its place
         } else {
-            p.x = (ca * g1_i.x - cb * p3_i.x) - cc * p2_i.x;
-            p.y = (ca * g1_i.y - cb * p3_i.y) - cc * p2_i.y;
+            p = kry_form_p(st, g1_i, p3_i, p2_i);
             Pw[i] = p;
         }
         const double d = tau * qd + om;
@@ -795,15 +841,9 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         for (int kk = 0; kk < NPRE; ++kk)
             if (kk < width) {
                 const double av = tau * val[kk];
-                double2 pj;
-                if (k == 1) {
-                    pj = n2[kk];
-                } else {
-                    pj.x = (ca * ng[kk].x - cb * n3[kk].x) - cc * n2[kk].x;
-                    pj.y = (ca * ng[kk].y - cb * n3[kk].y) - cc * n2[kk].y;
-                }
-                gx += av * pj.x;
-                gy += av * pj.y;
+                const double2 pj = (k == 1) ? n2[kk] : kry_form_p(st, ng[kk], n3[kk], n2[kk]);
+                gx = fma(av, pj.x, gx);
+                gy = fma(av, pj.y, gy);
             }
         for (int kk = NPRE; kk < width; ++kk) {  // rows longer than the prefetch window
             const int jn = a.sell_col[base + kk * 64 + lane];
@@ -814,16 +854,15 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
             } else {
                 const double2 gj = G1[jn], q2 = P2[jn];
                 const double2 q3 = (k >= 3) ? P3[jn] : zero2;
-                pj.x = (ca * gj.x - cb * q3.x) - cc * q2.x;
-                pj.y = (ca * gj.y - cb * q3.y) - cc * q2.y;
+                pj = kry_form_p(st, gj, q3, q2);
             }
-            gx += av * pj.x;
-            gy += av * pj.y;
+            gx = fma(av, pj.x, gx);
+            gy = fma(av, pj.y, gy);
         }
         Gw[i] = make_double2(gx, gy);
-        part[0] = p.x * p.x + p.y * p.y;
-        part[1] = p.x * gx + p.y * gy;
-        if (k >= 2) part[2] = p.x * p2_i.x + p.y * p2_i.y;
+        part[0] = dot2(p, p);
+        part[1] = fma(p.y, gy, p.x * gx);
+        if (k >= 2) part[2] = dot2(p, p2_i);
     }
     OCC_STAMP(4)
     if (writer) slot_store(out, s);

@@ -70,14 +70,29 @@ def _compare_iteration(eng, orc, prob, chain=0):
     return worst
 
 
+@pytest.fixture(params=['persistent', 'launch_per_step'])
+def solve_mode(request, monkeypatch):
+    """The eta solve has two implementations of the same arithmetic: one persistent launch (k_solve, taken
+    when all workgroups of all chains fit on the device) and one launch per MINRES step (k_minres)."""
+    if request.param == 'launch_per_step':
+        monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
+    else:
+        monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize('case', ['ref_queen150_ragged', 'ref_queen150_hparams', 'ref_rook400_v3',
                                   'ref_queen400_v3', 'ref_graph300_weighted'])
-def test_lockstep_iterations_match_oracle(oracle, case):
+def test_lockstep_iterations_match_oracle(oracle, case, solve_mode):
     """Six iterations; after each one every conditional's output is compared, then the engine is
     re-seated on the oracle's state so that each iteration is tested from identical inputs."""
     from occuspytial_amd._engine import Engine
     prob, start = _problem_from_golden(case)
     eng = Engine(prob, [KEY])
+    if solve_mode == 'launch_per_step':
+        assert not eng.stats()['persistent_solve']
+    else:  # rows longer than the register-resident neighbour window keep the launch-per-step solve
+        assert eng.stats()['persistent_solve'] == (case != 'ref_graph300_weighted')
     orc = oracle.OracleSampler(prob, KEY)
     eng.set_start(0, **start)
     orc.set_start(**start)
@@ -90,7 +105,7 @@ def test_lockstep_iterations_match_oracle(oracle, case):
     eng.close()
 
 
-def test_free_running_chain_tracks_oracle(oracle):
+def test_free_running_chain_tracks_oracle(oracle, solve_mode):
     """40 iterations without re-seating: recorded alpha/beta/tau stay together."""
     from occuspytial_amd._engine import Engine
     prob, start = _problem_from_golden('ref_queen400_v3')
@@ -146,6 +161,41 @@ def test_batched_chains_equal_single_chain_runs():
     batch.close()
 
 
+@pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40)])
+def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, iters):
+    """k_solve exchanges g between the workgroups of a chain through write-through stores, L1-bypassing
+    loads and a per-chain arrival counter; one stale or torn value would change the bits of eta.  Same
+    scalars, same contractions, same summation order as k_minres: everything must agree exactly,
+    including the number of MINRES iterations of every solve."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(*lattice, visits=3, p=2, q=2, random_state=5)
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY + 7 * c for c in range(chains)]
+    starts = [_random_start(prob, 11 + c) for c in range(chains)]
+    out = {}
+    for mode in ('persistent', 'launch_per_step'):
+        if mode == 'launch_per_step':
+            monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
+        else:
+            monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
+        eng = Engine(prob, keys)
+        assert eng.stats()['persistent_solve'] == (mode == 'persistent')
+        for c in range(chains):
+            eng.set_start(c, **starts[c])
+        rec = eng.run(iters, 0)
+        state = [(eng.get('eta', c), eng.get('xz', c), eng.get('z', c), eng.get('minres_itn', c)) for c in range(chains)]
+        out[mode] = (rec, state, eng.stats()['krylov_mean'])
+        eng.close()
+    for u, v in zip(out['persistent'][0], out['launch_per_step'][0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(out['persistent'][1], out['launch_per_step'][1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+    assert out['persistent'][2] == out['launch_per_step'][2]
+
+
 def test_krylov_cap_overflow_is_resumed_exactly(monkeypatch):
     """A captured graph with too few Krylov steps carries the unfinished solve into the next replay
     (same arithmetic, continued), so results equal an unconstrained run bit for bit."""
@@ -156,7 +206,9 @@ def test_krylov_cap_overflow_is_resumed_exactly(monkeypatch):
         ref.set_start(c, **start)
     A, B, T = ref.run(12, 0)
     monkeypatch.setenv('OCC_FORCE_KRYLOV_CAP', '4')
+    monkeypatch.setenv('OCC_NO_PERSISTENT', '1')   # `ref` above runs the persistent solve: same bits again
     low = Engine(prob, [KEY, KEY + 1])
+    assert not low.stats()['persistent_solve']
     for c in range(2):
         low.set_start(c, **start)
     a, b, t = low.run(12, 0)

@@ -1,0 +1,40 @@
+"""Developer script: where a step of the persistent eta solve (k_solve) spends its time.
+
+    make -C occuspytial_amd/csrc stamps && python tools/solve_stamps.py
+
+Loads tools/libocc_gibbs_stamps.so (built with -DOCC_SOLVE_STAMPS), runs a few hundred iterations of the
+headline workload and prints, for the last solve, the s_memtime deltas between the stamp points of each step
+(chain 0, workgroup 0, thread 0)."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+import occuspytial_amd._lib as L
+L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libocc_gibbs_stamps.so')
+from occuspytial_amd._engine import Engine
+from occuspytial_amd._problem import FlatProblem, chain_generators, default_start
+from occuspytial_amd.utils import make_lattice_problem
+
+chains = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+Q, W, X, y, *_ = make_lattice_problem(100, 100, visits=5, p=2, q=2, random_state=0)
+prob = FlatProblem(Q, W, X, y)
+gens = chain_generators(10, chains)
+eng = Engine(prob, [int(g.bit_generator.random_raw()) for g in gens])
+for i, g in enumerate(gens):
+    st = default_start(g, prob)
+    eng.set_start(i, st['alpha'], st['beta'], st['tau'], st['eta'])
+eng.run(300, 299)
+lib = C.CDLL(L.LIB_PATH)
+STEPS, PTS = 48, 12
+buf = (C.c_ulonglong * (STEPS * PTS))()
+assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
+t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
+itn = int(eng.get('minres_itn', 0))
+names = ['scalars', 'compute+store', 'drain vmcnt', 'syncthreads+atomic', 'poll', 'syncthreads', 'issue loads', 'loads back+sums']
+print('last solve of chain 0: %d iterations; ticks of s_memtime (100 MHz on gfx950?) per segment' % itn)
+print('step ' + ' '.join('%18s' % n for n in names) + '   step total')
+for k in range(2, min(itn + 3, STEPS - 1)):
+    d = [t[k, j + 1] - t[k, j] for j in range(8)]
+    print('%4d ' % k + ' '.join('%18d' % v for v in d) + '   %d' % (t[k + 1, 0] - t[k, 0]))
+eng.close()
