@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libocc_gibbs.so')
 OCC_OK = 0
 OCC_E_BADARG, OCC_E_HIP, OCC_E_MINRES, OCC_E_CHOLESKY, OCC_E_STATE = -1, -2, -3, -4, -5
 N_KERNEL_KINDS = 9
-KERNEL_KINDS = ('omega_b', 'noise', 'eta_init', 'minres', 'beta_partial', 'omega_a', 'alpha_draw', 'z_ob', 'solve')
+KERNEL_KINDS = ('omega_b', 'noise', 'eta_init', 'minres', 'beta_partial', 'omega_a', 'alpha_draw', 'z_ob', 'iter')
 
 
 class OccProblem(C.Structure):
@@ -35,6 +35,7 @@ class OccStats(C.Structure):
         ('krylov_mean', C.c_double), ('last_run_ms', C.c_double),
         ('n_blocks_sites', C.c_int32), ('n_blocks_rows', C.c_int32), ('threads_per_block', C.c_int32),
         ('n_chains', C.c_int32), ('persistent_solve', C.c_int32), ('solve_workgroups', C.c_int32),
+        ('main_stream_cus', C.c_int32),
     ]
 
 

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "occ_solve.hpp"
+#include "occ_iter.hpp"
 
 using namespace occ;
 
@@ -22,8 +22,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_SOLVE };
-static_assert(K_SOLVE + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER };
+static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
 
@@ -39,8 +39,15 @@ struct occ_sampler {
     Ctx ctx{};               // host copy of the descriptor
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
-    SolveArgs solve{};       // ... and of k_solve
-    bool persistent = false; // eta solve as one persistent launch (occ_solve.hpp) instead of one launch per MINRES step
+    IterArgs iter{};         // ... and of k_iter
+    // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;
+    // otherwise one launch per MINRES step on the main stream and omega_a / alpha / noise on the side stream
+    bool persistent = false;
+    // experiment (OCC_FUSED_SIDE=1): omega_a / alpha / noise as extra workgroup roles of k_iter, no side stream.
+    // Slower on MI355X: the roles inherit k_iter's 239 VGPRs, i.e. two waves per SIMD for the Polya-Gamma draws.
+    bool fused_side = false;
+    int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
+    int graph_parity = 0;    // fused mode: sequence parity the captured pair of iterations starts with
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
@@ -176,7 +183,9 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
-        case K_SOLVE: hipLaunchKernelGGL(k_solve, dim3((unsigned)s->solve.nbg, (unsigned)c.C), dim3(SOLVE_WG), 0, st, s->solve, e); break;
+        case K_ITER:
+            hipLaunchKernelGGL(k_iter, dim3((unsigned)(s->iter.nbg + s->iter.nwa + s->iter.nwn), (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e);
+            break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
     }
 }
@@ -244,19 +253,21 @@ int eager_sequence(occ_sampler *s)
 {
     if (s->need_prologue) launch_prologue(s);
     const int e = s->parity;
-    launch_kind(s, s->stream, K_OMEGA_A, e);
-    launch_kind(s, s->stream, K_ALPHA_DRAW, e);
-    launch_kind(s, s->stream, K_NOISE, e, 1);
-    launch_kind(s, s->stream, K_ETA_INIT, e);
-    int k_last = 0;
+    if (!s->fused_side) {
+        launch_kind(s, s->stream, K_OMEGA_A, e);
+        launch_kind(s, s->stream, K_ALPHA_DRAW, e);
+        launch_kind(s, s->stream, K_NOISE, e, 1);
+    }
     if (s->persistent) {
-        launch_kind(s, s->stream, K_SOLVE, e);  // leaves the final scalars in slot 0
+        launch_kind(s, s->stream, K_ITER, e);
     } else {
+        launch_kind(s, s->stream, K_ETA_INIT, e);
+        int k_last = 0;
         int rc = eager_krylov(s, 1, &k_last);
         if (rc) return rc;
         s->calib_max = std::max(s->calib_max, k_last - 3);
+        launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
     }
-    launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
     launch_kind(s, s->stream, K_Z_OB, e);
     s->parity ^= 1;
     s->eager_iterations += 1;
@@ -310,13 +321,24 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
     int rc;
+    if (s->fused_side) {  // two iterations (both parities) in one linear graph: k_iter, k_z_ob, k_iter, k_z_ob
+        HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        for (int t = 0; t < 2; ++t) {
+            launch_kind(s, s->stream, K_ITER, s->parity ^ t);
+            launch_kind(s, s->stream, K_Z_OB, s->parity ^ t);
+        }
+        HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
+        HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
+        s->graph_parity = s->parity;
+        s->krylov_cap = 0;
+        return OCC_OK;
+    }
     for (int e = 0; e < 2; ++e) {
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        launch_kind(s, s->stream, K_ETA_INIT, e);
         if (s->persistent) {
-            launch_kind(s, s->stream, K_SOLVE, e);
-            launch_kind(s, s->stream, K_BETA_PARTIAL, e, 0);
+            launch_kind(s, s->stream, K_ITER, e);
         } else {
+            launch_kind(s, s->stream, K_ETA_INIT, e);
             for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
             launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
         }
@@ -368,6 +390,10 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
+    if (s->fused_side) {  // the graph holds two sequences; the parity is the same again afterwards
+        HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
+        return OCC_OK;
+    }
     if (s->event_nodes) {  // the graphs carry their own waits and records
         HIP_TRY(hipGraphLaunch(s->tail[e], s->side));
         HIP_TRY(hipGraphLaunch(s->head[e], s->stream));
@@ -451,14 +477,6 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
     HIP_TRY(hipSetDevice(s->device));
-    {   // the main stream carries the critical path (the eta solve): highest priority; the side stream's
-        // Polya-Gamma kernels fill whatever the solve leaves idle
-        int prio_low = 0, prio_high = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
-        HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
-        HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
-    }
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     for (int e = 0; e < 2; ++e) {
@@ -536,8 +554,9 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         if (c.ell_w)
             for (int sl = 0; sl <= nslice; ++sl) sell_ptr[sl] = sl * wmax * 64;
     }
-    std::vector<int> sell_col((size_t)sell_ptr[nslice]);
-    std::vector<double> sell_val((size_t)sell_ptr[nslice], 0.0);
+    // 64 spare slots: k_iter reads slot `base + lane` of a slice even when the slice has no off-diagonals
+    std::vector<int> sell_col((size_t)sell_ptr[nslice] + 64, 0);
+    std::vector<double> sell_val((size_t)sell_ptr[nslice] + 64, 0.0);
     for (int sl = 0; sl < nslice; ++sl) {
         const int base = sell_ptr[sl], width = (sell_ptr[sl + 1] - base) / 64;
         for (int lane = 0; lane < 64; ++lane) {
@@ -598,10 +617,43 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         for (int sl = 0; sl < nslice; ++sl) wmax = std::max(wmax, (sell_ptr[sl + 1] - sell_ptr[sl]) / 64);
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-        const int nbg = (n + SOLVE_WG - 1) / SOLVE_WG;
-        s->solve.nbg = nbg;
+        const int nbg = (n + ITER_WG - 1) / ITER_WG;
+        s->iter.nbg = nbg;
+        s->fused_side = false;
+        s->iter.nwa = s->iter.nwn = 0;
         s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= prop.multiProcessorCount;
         if (s->persistent) tpb = 64;
+        if (s->persistent && std::getenv("OCC_FUSED_SIDE")) {
+            s->fused_side = true;
+            s->iter.nwa = std::max(1, (R + ITER_WG - 1) / ITER_WG);
+            s->iter.nwn = nbg;
+        }
+    }
+    // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
+    // same iteration run beside it on the side stream.  With the fused iteration kernel the two streams get
+    // DISJOINT sets of CUs: k_iter's workgroups are latency-bound with one wave per SIMD, and Polya-Gamma waves
+    // sharing their SIMDs (long quarter-rate instructions, another kernel's code in the instruction cache) cost
+    // the solve more than the side work gains from the extra CUs (100x100, 4 chains: 143 -> 127 us per
+    // iteration).  The masks are whole XCDs (32 CUs): the k_iter grid is dealt over the XCDs of its queue.
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        const int ncu = prop.multiProcessorCount;
+        int nmain = ((s->iter.nbg * C + 31) / 32) * 32;
+        if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
+        if (s->persistent && s->side_enabled && nmain >= 32 && nmain <= ncu - 32) {
+            std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()));
+            s->main_cus = nmain;
+        } else {
+            int prio_low = 0, prio_high = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
+            HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
+            HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
+        }
     }
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
@@ -652,8 +704,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     c.bar = nullptr;
     if (s->persistent) {
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
-        if ((rc = dev_alloc(s, &s->solve.part, (size_t)C * 2 * c.nb_n * 4))) return rc;
-        s->solve.bar = c.bar;
+        if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 2 * c.nb_n * 4))) return rc;
+        s->iter.bar = c.bar;
     }
 
     // initial occupancy state (base.py:113-119) and chain keys
@@ -673,9 +725,18 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         for (int b = 0; b < 2; ++b) { k.Gv[b] = c.Gv[b]; k.Wv[b] = c.Wv[b]; }
         for (int b = 0; b < 3; ++b) k.Pv[b] = c.Pv[b];
         k.Xv = c.Xv; k.part_kry = c.part_kry; k.part_proj = c.part_proj; k.scs = c.sc; k.slots = c.slots;
-        s->solve.a = k;
     }
     if ((rc = dev_alloc(s, &s->ctx_dev, 1, false))) return rc;
+    {
+        IterArgs &t = s->iter;
+        t.a = s->kry;
+        t.cp = s->ctx_dev;
+        t.Xt = c.Xt; t.z = c.z;
+        for (int b = 0; b < 2; ++b) { t.enorm[b] = c.enorm[b]; t.uprior[b] = c.uprior[b]; }
+        t.rhs = c.rhs; t.eta = c.eta; t.part_quad = c.part_quad; t.part_beta = c.part_beta;
+        t.tau_rate = c.tau_rate; t.tau_shape = c.tau_shape;
+        t.C = c.C; t.p = c.p; t.q = c.q;
+    }
     HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
     return OCC_OK;
@@ -787,9 +848,22 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         for (int64_t i = 0; i < n_iter; ++i)
             if ((rc = eager_sequence(s))) return rc;
         done_min = n_iter;
-    } else if (!s->head[0] && s->persistent) {
-        if ((rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
+    } else if (s->persistent && !s->fused_side) {
+        if (!s->head[0] && (rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
         if (s->need_prologue) launch_prologue(s);
+    } else if (s->fused_side) {
+        if (s->need_prologue) launch_prologue(s);
+        // the solve is one launch: nothing to calibrate.  The captured pair of iterations starts with one
+        // sequence parity: an odd number of stepped iterations since the capture is realigned by one more step.
+        if (s->head[0] && s->parity != s->graph_parity) {
+            if ((rc = eager_sequence(s))) return rc;
+            done_min = 1;
+        }
+        if (!s->head[0] && n_iter > 1 && (rc = build_graph(s, 0))) return rc;
+        if (n_iter == 1) {
+            if ((rc = eager_sequence(s))) return rc;
+            done_min = 1;
+        }
     } else if (!s->head[0]) {
         const int64_t n_calib = std::min<int64_t>(n_iter, 3);
         s->calib_max = 0;
@@ -805,15 +879,17 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         launch_prologue(s);
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
-    if (done_min < n_iter && s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+    if (done_min < n_iter && s->side_enabled && !s->fused_side) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+    const int64_t seq_per_enqueue = s->fused_side ? 2 : 1;
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
         // solve into the next sequence; finished chains idle.  No host work inside a batch.
         const int64_t left = n_iter - done_min;
-        const int64_t batch = std::min<int64_t>(left, s->graph_launches < 128 ? 32 : 256);
+        int64_t batch = std::min<int64_t>(left, s->graph_launches < 128 ? 32 : 256);
+        batch = (batch + seq_per_enqueue - 1) / seq_per_enqueue * seq_per_enqueue;  // a surplus sequence idles (it_stop)
         const auto hl0 = std::chrono::steady_clock::now();
-        for (int64_t b = 0; b < batch; ++b)
+        for (int64_t b = 0; b < batch; b += seq_per_enqueue)
             if ((rc = enqueue_sequence(s))) return rc;
         const auto hl1 = std::chrono::steady_clock::now();
         s->graph_launches += batch;
@@ -991,7 +1067,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->threads_per_block = s->tpb;
     out->n_chains = s->ctx.C;
     out->persistent_solve = s->persistent ? 1 : 0;
-    out->solve_workgroups = s->solve.nbg;
+    out->solve_workgroups = s->iter.nbg;
+    out->main_stream_cus = s->main_cus;
     return OCC_OK;
 }
 
@@ -1068,21 +1145,20 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         counts[K_MINRES] = (int64_t)reps * KRY_TIMED;
         total_us[K_MINRES] = std::max(0.0, per_replay_us - eta_us) * reps;
     }
-    // the persistent solve: replays of {restore the warm start, k_eta_init, k_solve} minus replays of
-    // {restore the warm start, k_eta_init}; every replay redoes the same solve
-    counts[K_SOLVE] = 0;
-    total_us[K_SOLVE] = 0.0;
+    // the fused iteration kernel: replays of {restore the warm start, k_iter} minus replays of {restore the warm
+    // start}; every replay redoes the same iteration (k_z_ob, which advances it, is not launched)
+    counts[K_ITER] = 0;
+    total_us[K_ITER] = 0.0;
     if (s->persistent) {
         const size_t xbytes = sizeof(double2) * (size_t)s->ctx.C * s->ctx.n;
         HIP_TRY(hipMemcpyAsync(s->ctx.Pv[1], s->ctx.Xv, xbytes, hipMemcpyDeviceToDevice, s->stream));  // Pv[1]: scratch here
         double per_replay_us[2] = {0.0, 0.0};
-        for (int with_solve = 0; with_solve < 2; ++with_solve) {
+        for (int with_iter = 0; with_iter < 2; ++with_iter) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
-            launch_kind(s, s->stream, K_ETA_INIT, e);
-            if (with_solve) launch_kind(s, s->stream, K_SOLVE, e);
+            if (with_iter) launch_kind(s, s->stream, K_ITER, e);
             HIP_TRY(hipStreamEndCapture(s->stream, &graph));
             HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             HIP_TRY(hipGraphLaunch(exec, s->stream));
@@ -1094,14 +1170,14 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             (void)hipGraphExecDestroy(exec);
             (void)hipGraphDestroy(graph);
-            per_replay_us[with_solve] = 1000.0 * ms / reps;
+            per_replay_us[with_iter] = 1000.0 * ms / reps;
         }
         std::vector<Slot> hs((size_t)s->ctx.C * NSLOT);
         HIP_TRY(hipMemcpy(hs.data(), s->ctx.slots, sizeof(Slot) * hs.size(), hipMemcpyDeviceToHost));
-        int steps = 0;  // the launch lasts as long as its slowest chain: iterations + 3 steps
+        int steps = 0;  // the launch lasts as long as its slowest chain: MINRES iterations + 3 steps
         for (int ch = 0; ch < s->ctx.C; ++ch) steps = std::max(steps, hs[(size_t)ch * NSLOT].itn + 3);
-        counts[K_SOLVE] = (int64_t)reps * steps;
-        total_us[K_SOLVE] = std::max(0.0, per_replay_us[1] - per_replay_us[0]) * reps;
+        counts[K_ITER] = (int64_t)reps * steps;
+        total_us[K_ITER] = std::max(0.0, per_replay_us[1] - per_replay_us[0]) * reps;
         HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
     }
     // finish that solve so that the tail kernels have real work

@@ -1,0 +1,473 @@
+// occ_iter.hpp -- one Gibbs iteration of every chain in TWO launches: k_iter, then k_z_ob (gfx950).
+//
+// k_iter fuses, by ROLE of the workgroup (256 threads each; roles are ranges of blockIdx.x):
+//
+//   solve role   nbg workgroups per chain, ALL of them resident at once (the host takes this path only when
+//                they fit one per CU).  Per chain, in order:
+//                  A  tau ~ Gamma (logit.py:206-209), right-hand side of the eta system (logit.py:75-78, 213),
+//                     p_0 = b - A x0 with the warm start x0 (logit.py:71, 82-88)          [k_eta_init]
+//                  B  joint MINRES for [x z] (logit.py:82-92), vectors in registers, one barrier per step AMONG
+//                     THE WORKGROUPS OF THE CHAIN; stopping test on the device             [k_minres x (K + 3)]
+//                  C  eta = x - (sum x / sum z) z (distributions.pyx:24-39), partial sums of beta's system
+//                     (logit.py:226-232)                                                   [k_beta_partial]
+//   omega_a role omega_a ~ PG(1, w'alpha) over the visit rows of existing sites, partial sums of alpha's system
+//                (logit.py:199-204, 216-224); the LAST workgroup of a chain to finish draws alpha  [k_omega_a, k_alpha_draw]
+//   noise role   the variates of the NEXT iteration's right-hand side (logit.py:75-77)    [k_noise]
+//
+// Why one launch: at the headline size (100x100 sites, 4 chains) a k_minres launch moves 7.8 MB -- one
+// microsecond of HBM time -- and costs 5.7-7.3 us of launch boundary and cold dependent loads, the launches
+// per solve have to be guessed when the graph is captured, and every hand-over between the main stream and
+// the side stream (omega_a / alpha / noise ran there) cost 6-16 us of idle critical path.  Here the solve
+// runs exactly the steps it needs, chains do not wait for each other inside the launch, and the side work
+// fills the CUs and issue slots the latency-bound solve leaves idle -- no second stream, no events.
+//
+// Exchange between the workgroups of a chain (solve role): payload stored write-through (sc1), every storing
+// wave drained, one lane adds to the chain's arrival counter and polls it, then every load of exchanged
+// bytes is an sc1 load (per-CU L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs'
+// L2s are not coherent with each other).  Only g = A p (16 B per site) and four partial sums per 64-site
+// slice are exchanged per step: p_{k-2}, p_{k-3} at the NEIGHBOURS of a site stay in the registers of the
+// lane that re-formed them.  The arrival counter is monotonic over the whole run (ChainScalars::bar_base).
+//
+// The arithmetic is that of the stand-alone kernels, through the same functions (minres_scalars, kry_form_*,
+// eta_rhs_site, ...), with partial sums per 64-site slice reduced in the same order: the fused iteration, the
+// launch-per-MINRES-step path and the eager stepping path return the same bits.
+#pragma once
+#include "occ_kernels.hpp"
+
+namespace occ {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter
+constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
+constexpr int BAR_STRIDE = 32;                  // unsigned words per chain in IterArgs::bar (128 B)
+constexpr int BAR_ALPHA = 16;                   // word of the omega_a completion counter (own 64 B half)
+
+// Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
+// chain 0 / workgroup 0; the product build compiles the hooks away.
+#ifdef OCC_SOLVE_STAMPS
+constexpr int STAMP_STEPS = 48, STAMP_POINTS = 12;
+__device__ unsigned long long g_solve_stamps[STAMP_STEPS * STAMP_POINTS];
+#define SOLVE_STAMP(pt)                                                                                  \
+    if (chain == 0 && wg == 0 && threadIdx.x == 0 && k < STAMP_STEPS) g_solve_stamps[k * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
+#define PHASE_STAMP(row, pt)                                                                             \
+    if (chain == 0 && wg == 0 && threadIdx.x == 0) g_solve_stamps[(row) * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
+#else
+#define SOLVE_STAMP(pt)
+#define PHASE_STAMP(row, pt)
+#endif
+
+struct IterArgs {
+    KryArgs a;            // the MINRES descriptor of k_minres (matrix, omega_b, G buffers, x, scalars)
+    const Ctx *cp;        // the full descriptor, for the roles off the critical path
+    // phase A / C inputs and outputs by value (no dependent load through cp on the critical path)
+    const double *Xt;
+    const uint8_t *z;
+    const double *enorm[2], *uprior[2];
+    double *rhs, *eta;
+    const double *part_quad;
+    double *part_beta;
+    double tau_rate, tau_shape;
+    unsigned *bar;        // [C][BAR_STRIDE]
+    double *part;         // [C][2][nb_n][4] partial sums of the running solve, by step parity
+    int nbg, nwa, nwn;    // workgroups per chain: solve, omega_a, noise roles
+    int C, p, q;
+};
+
+__device__ __forceinline__ v4u pack_d2(double2 v)
+{
+    v4u r;
+    r.x = (unsigned)__double2loint(v.x); r.y = (unsigned)__double2hiint(v.x);
+    r.z = (unsigned)__double2loint(v.y); r.w = (unsigned)__double2hiint(v.y);
+    return r;
+}
+__device__ __forceinline__ double2 unpack_d2(v4u r)
+{
+    return make_double2(__hiloint2double((int)r.y, (int)r.x), __hiloint2double((int)r.w, (int)r.z));
+}
+// 16-byte write-through store / L1-bypassing load (aux 16 = sc1)
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, double2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(pack_d2(v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+// Barrier among the workgroups of one chain, in two halves so that work which needs nothing from the other
+// workgroups can run between them.  ARRIVE: every storing wave drains its write-through stores, then one lane
+// adds to the chain's counter.  WAIT: that lane polls until the counter has reached `target` arrivals
+// (compared modulo 2^32); `fail_flag` (LDS) is set when the poll gave up (a workgroup of the chain is not
+// running).
+#define OCC_CHAIN_ARRIVE()                                                                                 \
+    do {                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        __syncthreads();                                                                                   \
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    } while (0)
+#define OCC_CHAIN_WAIT(target_expr, fail_flag)                                                             \
+    do {                                                                                                   \
+        if (threadIdx.x == 0) {                                                                            \
+            const unsigned target_ = (target_expr);                                                        \
+            int fail_ = 0;                                                                                 \
+            unsigned spins_ = 0;                                                                           \
+            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target_) < 0) { \
+                __builtin_amdgcn_s_sleep(1);                                                               \
+                if (++spins_ > ITER_SPIN_LIMIT) { fail_ = 1; break; }                                      \
+            }                                                                                              \
+            fail_flag = fail_;                                                                             \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* compiler only: no load moves above the poll */ \
+    } while (0)
+#define OCC_CHAIN_BARRIER(target_expr, fail_flag)                                                          \
+    do {                                                                                                   \
+        OCC_CHAIN_ARRIVE();                                                                                \
+        OCC_CHAIN_WAIT(target_expr, fail_flag);                                                            \
+    } while (0)
+
+// Partial sums of beta's system for one 64-site slice (k_beta_partial's, per wave).
+template <int P>
+__device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chain, int i, bool act, int slice, bool slice_act,
+                                                    double om, double eta, double zval)
+{
+    const int n = ia.a.n, nb = ia.a.nb_n, lane = threadIdx.x & 63;
+    double acc[nacc(P)];
+#pragma unroll
+    for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
+    if (act) {
+        const double tt = beta_rhs_term(om, eta, zval);
+        double x[P];
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) x[aa] = ia.Xt[(size_t)aa * n + i];
+        int t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) {
+            const double xo = x[aa] * om;
+#pragma unroll
+            for (int bb = aa; bb < P; ++bb) acc[t++] = xo * x[bb];
+        }
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
+    }
+    if (slice_act) {
+        double *out = ia.part_beta + (size_t)chain * nacc(P) * nb;
+#pragma unroll
+        for (int t = 0; t < nacc(P); ++t) {
+            const double r = wave_sum(acc[t]);
+            if (lane == 0) out[t * nb + slice] = r;
+        }
+    }
+}
+
+// omega_a role: 256 visit rows per workgroup, partial sums per 64-row slice (k_omega_a at 64 threads per block).
+template <int Q>
+__device__ __forceinline__ void omega_a_rows(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int wg)
+{
+    const int r = wg * ITER_WG + (int)threadIdx.x, lane = threadIdx.x & 63, slice = r >> 6;
+    double acc[nacc(Q)];
+    omega_a_row<Q>(c, sc, chain, it, r, acc);
+    if (slice < c.nb_r) {
+        double *out = c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r;
+#pragma unroll
+        for (int t = 0; t < nacc(Q); ++t) {
+            const double s = wave_sum(acc[t]);
+            if (lane == 0) out[t * c.nb_r + slice] = s;
+        }
+    }
+}
+
+#define OCC_SWITCH_DIM(d, CALL)                                                                            \
+    switch (d) {                                                                                           \
+        case 1: { constexpr int D = 1; CALL; } break;                                                      \
+        case 2: { constexpr int D = 2; CALL; } break;                                                      \
+        case 3: { constexpr int D = 3; CALL; } break;                                                      \
+        case 4: { constexpr int D = 4; CALL; } break;                                                      \
+        case 5: { constexpr int D = 5; CALL; } break;                                                      \
+        case 6: { constexpr int D = 6; CALL; } break;                                                      \
+        case 7: { constexpr int D = 7; CALL; } break;                                                      \
+        default: { constexpr int D = 8; CALL; } break;                                                     \
+    }
+
+__global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
+{
+    __shared__ int s_flag;
+    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
+    const KryArgs &a = ia.a;
+    // grid = (nbg + nwa + nwn, C): the chain is blockIdx.y (a scalar register: the buffer descriptors below
+    // must be provably wave-uniform, or every buffer access becomes a serialising waterfall loop)
+    const int n_solve = ia.nbg, n_oa = ia.nwa;
+    const int b = (int)blockIdx.x;
+
+    // ================================ omega_a role (+ alpha by the last workgroup of the chain) ==========
+    if (b >= n_solve && b < n_solve + n_oa) {
+        const Ctx &c = *ia.cp;
+        const int chain = (int)blockIdx.y, wg = b - n_solve;
+        ChainScalars &sc = a.scs[chain];
+        const Ctl ctl = sc.ctl[e];
+        if (ctl.koff || ctl.it >= sc.it_stop) return;
+        OCC_SWITCH_DIM(ia.q, omega_a_rows<D>(c, sc, chain, ctl.it, wg));
+        // completion ticket: plain stores above, agent-scope release, one self-resetting counter per chain
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicInc(ia.bar + (size_t)chain * BAR_STRIDE + BAR_ALPHA, (unsigned)ia.nwa - 1u);
+            s_flag = (old == (unsigned)ia.nwa - 1u) ? 1 : 0;
+            if (s_flag) __threadfence();  // acquire: this CU's L1 holds no stale partial sums
+        }
+        __syncthreads();
+        if (!s_flag) return;
+        const int Q = ia.q;
+        reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
+        if (threadIdx.x == 0) {
+            const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
+            const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
+            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+        }
+        return;
+    }
+    // ================================ noise role (k_noise with ahead = 1) ===============================
+    if (b >= n_solve + n_oa) {
+        const Ctx &c = *ia.cp;
+        const int chain = (int)blockIdx.y, wg = b - n_solve - n_oa;
+        const ChainScalars &sc = a.scs[chain];
+        const Ctl ctl = sc.ctl[e];
+        if (ctl.koff || ctl.it >= sc.it_stop) return;
+        const int n = c.n, i = wg * ITER_WG + (int)threadIdx.x;
+        if (i >= n) return;
+        noise_site(c, sc.key, chain, i, ctl.it + 1u);
+        return;
+    }
+
+    // ================================ solve role ========================================================
+    __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of the co-resident Polya-Gamma waves
+    const int chain = (int)blockIdx.y, wg = b;
+    ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    const bool writer = (wg == 0 && threadIdx.x == 0);
+    if (ctl.koff || ctl.it >= sc.it_stop) {  // uniform over the chain's workgroups
+        if (writer) sc.mid[e] = ctl;
+        return;
+    }
+    const uint32_t it = ctl.it;
+    const int n = a.n, i = wg * ITER_WG + (int)threadIdx.x;
+    const bool act = i < n;
+    const int lane = threadIdx.x & 63, slice = i >> 6;
+    const bool slice_act = slice < a.nb_n;  // a slice with at least one site owns a partial sum
+    const size_t co = (size_t)chain * n;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    unsigned *cnt = ia.bar + (size_t)chain * BAR_STRIDE;
+    const unsigned bar_base = sc.bar_base;
+    unsigned nbar = 0;  // barriers passed in this launch
+    const __amdgpu_buffer_rsrc_t gbuf[2] = {
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[0] + co), 0, n * 16, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[1] + co), 0, n * 16, 0x00020000)};
+    double *part_base = ia.part + (size_t)chain * 2 * a.nb_n * 4;
+    const __amdgpu_buffer_rsrc_t pbuf[2] = {
+        __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000)};
+
+    // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
+    PHASE_STAMP(0, 0)
+    double tau;
+    {
+        double q = 0.0;
+        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
+        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bb = b0 + 64 * r;
+                const double t = pq[min(bb, a.nb_n - 1)];
+                v[r] = (bb < a.nb_n) ? t : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += v[r];
+        }
+        q = wave_sum(q);
+        const double rate = 0.5 * q + ia.tau_rate;
+        Cursor gcur(sc.key, 0u, it, STREAM_TAU);
+        tau = (1.0 / rate) * std_gamma(gcur, ia.tau_shape);  // every lane draws the same tau (uniform control flow)
+        if (writer) sc.tau = tau;
+    }
+    PHASE_STAMP(0, 1)
+    // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
+    // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
+    // the site itself with coefficient 0; lanes past the last site read row n-1 and their buffer accesses fall
+    // outside the descriptors' range (loads return 0, stores are dropped).
+    int off[NPRE];      // byte offset of neighbour kk in a [n] double2 array
+    double av[NPRE];    // tau * Q_ij
+    double2 nm1[NPRE], nm2[NPRE], ng[NPRE];
+    const int ic = act ? i : n - 1;             // clamped row for plain loads
+    const int myoff = act ? i * 16 : n * 16;    // byte offset of this site in the exchange buffers
+    int width, base;
+    {
+        const int sl = ic >> 6;
+        if (a.ell_w > 0) { width = a.ell_w; base = sl * a.ell_w * 64; }
+        else { base = a.sell_ptr[sl]; width = (a.sell_ptr[sl + 1] - base) >> 6; }
+    }
+    const size_t ci = co + ic;
+    const double2 *X0 = a.Xv + co;
+    const double om = a.omega_b[it & 1][ci];
+    const double zval = (double)ia.z[ci];
+    const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
+    const double y = eta_rhs_site(om, xb, zval, ia.enorm[it & 1][ci], ia.uprior[it & 1][ci], sqrt(tau));
+    double2 x = X0[ic];
+    const double d = tau * a.qdiag[ic] + om;
+    double2 xn[NPRE];
+#pragma unroll
+    for (int kk = 0; kk < NPRE; ++kk) {
+        const bool has = act && kk < width;
+        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+        const int jraw = a.sell_col[slot];
+        const double vraw = a.sell_val[slot];
+        const int j = has ? jraw : ic;
+        off[kk] = has ? j * 16 : myoff;
+        av[kk] = has ? tau * vraw : 0.0;
+        xn[kk] = X0[j];
+        nm1[kk] = zero2; nm2[kk] = zero2;
+    }
+    double ax = d * x.x, az = d * x.y;
+#pragma unroll
+    for (int kk = 0; kk < NPRE; ++kk) {
+        ax = fma(av[kk], xn[kk].x, ax);
+        az = fma(av[kk], xn[kk].y, az);
+    }
+    const double2 p0 = make_double2(y - ax, 1.0 - az);
+    if (act) ia.rhs[ci] = y;
+    store_sc1(gbuf[0], myoff, p0);
+    PHASE_STAMP(0, 2)
+    ++nbar;
+    OCC_CHAIN_BARRIER(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+    PHASE_STAMP(0, 3)
+    bool failed = s_flag != 0;
+#pragma unroll
+    for (int kk = 0; kk < NPRE; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
+
+    // ---- phase B: MINRES
+    Slot s = {};
+    double2 g = zero2, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
+    double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
+    int k = 1;
+    KryPre pre = minres_pre(s);
+    for (; !failed; ++k) {
+        SOLVE_STAMP(0)
+        const KryStep st = minres_post(s, pre, k, S0, S1, S2, xn2, a.maxiter);
+        if (st.stop) break;
+        SOLVE_STAMP(1)
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        if (st.rotate) {  // w_{k-2}, x_{k-2}
+            const double2 w = kry_form_w(st, pm2, wm2, wm1);
+            x.x = fma(st.phi, w.x, x.x);
+            x.y = fma(st.phi, w.y, x.y);
+            wm2 = wm1;
+            wm1 = w;
+            part[3] = dot2(x, x);
+        }
+        {
+            const double2 p = (k == 1) ? p0 : kry_form_p(st, g, pm2, pm1);  // p_{k-1}
+            double gx = d * p.x, gy = d * p.y;
+#pragma unroll
+            for (int kk = 0; kk < NPRE; ++kk) {
+                const double2 pj = (k == 1) ? ng[kk] : kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
+                gx = fma(av[kk], pj.x, gx);
+                gy = fma(av[kk], pj.y, gy);
+                nm2[kk] = nm1[kk];
+                nm1[kk] = pj;
+            }
+            g = make_double2(gx, gy);
+            part[0] = dot2(p, p);
+            part[1] = fma(p.y, gy, p.x * gx);
+            if (k >= 2) part[2] = dot2(p, pm1);
+            pm2 = pm1;
+            pm1 = p;
+            store_sc1(gbuf[k & 1], myoff, g);
+        }
+        if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
+        if (slice_act) {  // per-slice sums: the granularity (and order) of k_minres at 64 threads per block
+            const double t0 = wave_sum(part[0]), t1 = wave_sum(part[1]), t2 = wave_sum(part[2]), t3 = wave_sum(part[3]);
+            if (lane == 0) store_sc1(pbuf[k & 1], slice * 32, make_double2(t0, t1));
+            if (lane == 1) store_sc1(pbuf[k & 1], slice * 32 + 16, make_double2(t2, t3));
+        }
+        SOLVE_STAMP(2)
+        ++nbar;
+        OCC_CHAIN_ARRIVE();
+        pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
+        OCC_CHAIN_WAIT(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+        SOLVE_STAMP(6)
+        if (s_flag) { failed = true; break; }
+        // ---- everything below reads what other workgroups published in this step: sc1 loads only
+        // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the
+        // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+            double2 lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
+                hi[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32 + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < NPRE; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+        SOLVE_STAMP(7)
+        S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
+        SOLVE_STAMP(8)
+    }
+
+    // ---- phase C: sum-to-zero projection, eta, partial sums of beta's system.  The solve stopped at the top
+    // of step k, uniformly over the chain: buffers of parity k are free (everybody has passed barrier k-1).
+    double proj_a = 0.0;
+    PHASE_STAMP(STAMP_STEPS - 1, 0)
+    if (!failed) {
+        if (slice_act) {
+            const double t0 = wave_sum(act ? x.x : 0.0), t1 = wave_sum(act ? x.y : 0.0);
+            if (lane == 0) store_sc1(pbuf[k & 1], slice * 32, make_double2(t0, t1));
+        }
+        ++nbar;
+        OCC_CHAIN_BARRIER(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+        failed = s_flag != 0;
+    }
+    if (!failed) {
+        double sx = 0.0, sz = 0.0;
+        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+            double2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sx += v[r].x; sz += v[r].y; }
+        }
+        sx = wave_sum(sx);
+        sz = wave_sum(sz);
+        proj_a = -sx / sz;
+        PHASE_STAMP(STAMP_STEPS - 1, 1)
+    } else if (writer) {
+        sc.err = -2;  // OCC_E_HIP: reported by the host as an over-subscribed persistent launch
+        s.done = 1; s.istop = 6; s.itn = k;
+    }
+    double eta = 0.0;
+    if (act) {
+        eta = eta_project(x, proj_a);
+        a.Xv[co + i] = x;
+        ia.eta[co + i] = eta;
+    }
+    OCC_SWITCH_DIM(ia.p, beta_partials_slice<D>(ia, chain, i, act, slice, slice_act, om, eta, zval));
+    if (writer) {
+        slot_store(&a.slots[(size_t)chain * NSLOT], s);
+        Ctl m = ctl;
+        m.koff = 0u;
+        sc.mid[e] = m;
+        sc.bar_base = bar_base + nbar * (unsigned)ia.nbg;
+        sc.minres_itn_last = s.itn;
+        sc.krylov_total += (unsigned long long)s.itn;
+        sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
+        sc.solves += 1ull;
+        if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
+    }
+    PHASE_STAMP(STAMP_STEPS - 1, 2)
+}
+
+}  // namespace occ

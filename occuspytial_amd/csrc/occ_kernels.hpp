@@ -95,6 +95,7 @@ struct ChainScalars {
     uint64_t key;
     Ctl ctl[2], mid[2];
     uint32_t it_stop, it_base, burnin, keep;
+    uint32_t bar_base;         // arrivals counted so far by the chain's barrier counter (occ_iter.hpp), never reset
     int32_t err;               // OCC_E_* raised on device
     int32_t minres_itn_last;
     unsigned long long krylov_total, krylov_sq_total, solves, carries;
@@ -135,7 +136,7 @@ struct Ctx {
     Slot *slots;        // [C][NSLOT]
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
-    unsigned *bar;      // [C][32] arrival counters of the persistent solve (occ_solve.hpp); null: not used
+    unsigned *bar;      // [C][32] barrier / ticket counters of k_iter (occ_iter.hpp); null: not used
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -282,12 +283,23 @@ __device__ __forceinline__ double expit(double x)
     return 1.0 / (1.0 + exp(-x));
 }
 
+// ---- site-level arithmetic shared by the stand-alone kernels and the fused iteration kernel (occ_iter.hpp):
+// written with explicit contractions so that both evaluate the same operations.
 __device__ __forceinline__ double xdot(const double *Xt, int n, int i, const double *coef, int p)
 {
     double acc = 0.0;
-    for (int a = 0; a < p; ++a) acc += Xt[(size_t)a * n + i] * coef[a];
+    for (int a = 0; a < p; ++a) acc = fma(Xt[(size_t)a * n + i], coef[a], acc);
     return acc;
 }
+// right-hand side of the eta system at one site: k - omega x'beta + sqrt(omega) eps_1 + sqrt(tau) u   (logit.py:76-78, 213)
+__device__ __forceinline__ double eta_rhs_site(double om, double xb, double z, double en, double up, double sqrt_tau)
+{
+    const double b = fma(-om, xb, z - 0.5);
+    return fma(sqrt_tau, up, fma(sqrt(om), en, b));
+}
+// eta = x - (sum x / sum z) z at one site (distributions.pyx:24-39) and the right-hand side term of beta's system
+__device__ __forceinline__ double eta_project(double2 xz, double a) { return fma(a, xz.y, xz.x); }
+__device__ __forceinline__ double beta_rhs_term(double om, double eta, double z) { return fma(-om, eta, z - 0.5); }
 
 // distributions.pyx:95-105 on device, executed by ONE thread on small LDS work arrays (runtime
 // dimension d <= MAXC, so no per-dimension template and no register arrays): upper Cholesky U of the
@@ -447,19 +459,9 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
 // (logit.py:75-76) and u = B'eps, the edge form of the prior term E (sqrt(tau) eps_2) (logit.py:66-67,
 // 77; Q = B'B with B the weighted incidence matrix, so u ~ N(0, Q) like E eps_2).  Written for iteration
 // ctl.it + ahead into buffer [(it + ahead) & 1]; runs on the side stream, off the critical path.
-__global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
+__device__ __forceinline__ void noise_site(const Ctx &c, uint64_t key, int chain, int i, uint32_t it)
 {
-    const Ctx &c = *cp;
-    const Tile tile = tile_of_block(chain_base);
-    const int chain = tile.chain, blk = tile.blk;
-    const ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t it = ctl.it + (uint32_t)ahead;
-    const uint64_t key = sc.key;
-    const int lane = i & 63;
+    const int n = c.n, lane = i & 63;
     int base, width;
     slice_of(c, i, base, width);
     double u = 0.0;
@@ -475,6 +477,19 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
     const size_t ci = (size_t)chain * n + i;
     c.uprior[it & 1][ci] = u;
     c.enorm[it & 1][ci] = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_SITE);
+}
+
+__global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
+{
+    const Ctx &c = *cp;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    const ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const int i = blk * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    noise_site(c, sc.key, chain, i, ctl.it + (uint32_t)ahead);
 }
 
 __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
@@ -498,7 +513,6 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
         sc.tau = tau;
         Slot s = {};
         slot_store(&slots[(size_t)chain * NSLOT], s);
-        if (c.bar) c.bar[(size_t)chain * 32] = 0u;  // the coming k_solve counts its barrier arrivals from zero
     }
     const double st = sqrt(tau);
     if (i < n) {
@@ -506,8 +520,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
         const double2 *X0 = c.Xv + (size_t)chain * n;
         const double om = c.omega_b[it & 1][ci];
         const double xb = xdot(c.Xt, n, i, sc.beta, c.p);
-        const double b = ((double)c.z[ci] - 0.5) - om * xb;                 // logit.py:213
-        const double y = (b + sqrt(om) * c.enorm[it & 1][ci]) + st * c.uprior[it & 1][ci];  // logit.py:76-78
+        const double y = eta_rhs_site(om, xb, (double)c.z[ci], c.enorm[it & 1][ci], c.uprior[it & 1][ci], st);
         c.rhs[ci] = y;
         const double2 x0 = X0[i];
         const double d = tau * c.qdiag[i] + om;
@@ -519,8 +532,8 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
             const int j = c.sell_col[base + k * 64 + lane];
             const double a = tau * c.sell_val[base + k * 64 + lane];
             const double2 xj = X0[j];
-            ax += a * xj.x;
-            az += a * xj.y;
+            ax = fma(a, xj.x, ax);
+            az = fma(a, xj.y, az);
         }
         double2 r;
         r.x = y - ax;
@@ -564,7 +577,27 @@ struct KryStep {
 //   (a) k >= 4: stopping test of iteration k-3, exactly scipy's (minres.py, "Estimate various norms")
 //   (b) k >= 2: beta_{k-1}, alfa_{k-1}
 //   (c) k >= 3: rotation of iteration k-2 (needs beta_{k-1})
-__device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+// The step is split in two so that a kernel can take the part that only needs the slot (minres_pre: two of
+// the square roots and half of the divisions) off the critical path -- k_iter runs it while it waits for the
+// other workgroups' sums.  Contractions are explicit: the split does not change a bit of the result.
+struct KryPre {
+    double Anorm, test2, Acond;            // (a)
+    double t_ab, delta, gbar, gbar2, sj;   // (c): t_ab = alfa_j^2 + beta_j^2
+};
+__device__ __forceinline__ KryPre minres_pre(const Slot &s)
+{
+    KryPre q;  // entries that the coming step does not use may be inf / nan (early steps): they are never read
+    q.Anorm = sqrt(s.tnorm2);
+    q.test2 = (q.Anorm == 0.0) ? INFINITY : s.root / q.Anorm;
+    q.Acond = s.gmax / s.gmin;
+    q.t_ab = fma(s.beta, s.beta, s.alfa * s.alfa);
+    q.delta = fma(s.sn, s.alfa, s.cs * s.dbar);
+    q.gbar = fma(-s.cs, s.alfa, s.sn * s.dbar);
+    q.gbar2 = q.gbar * q.gbar;
+    q.sj = 1.0 / s.beta;
+    return q;
+}
+__device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter)
 {
     KryStep st;
     st.ca = st.cb = st.cc = 0.0;
@@ -575,13 +608,13 @@ __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, dou
     if (k >= 4) {  // (a)
         const int j = k - 3;
         const double rtol = 1e-5;
-        const double Anorm = sqrt(s.tnorm2);
+        const double Anorm = q.Anorm;
         const double ynorm = sqrt(xn2);
         const double epsx = Anorm * ynorm * eps;
         const double rnorm = s.phibar;
         const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
-        const double test2 = (Anorm == 0.0) ? INFINITY : s.root / Anorm;
-        const double Acond = s.gmax / s.gmin;
+        const double test2 = q.test2;
+        const double Acond = q.Acond;
         int istop = s.istop;
         if (istop == 0) {
             const double t1 = 1.0 + test1, t2 = 1.0 + test2;
@@ -615,19 +648,18 @@ __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, dou
             s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
         } else {  // (c) rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
             const int j = k - 2;
-            const double alfa = s.alfa, beta_j = beta_km2, beta_n = beta_km1;
+            const double beta_j = beta_km2, beta_n = beta_km1;
             s.oldb = beta_j;
-            s.tnorm2 += alfa * alfa + beta_j * beta_j + beta_n * beta_n;
+            s.tnorm2 += fma(beta_n, beta_n, q.t_ab);
             if (j == 1 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
             st.oldeps = s.epsln;
-            st.delta = s.cs * s.dbar + s.sn * alfa;
-            const double gbar = s.sn * s.dbar - s.cs * alfa;
+            st.delta = q.delta;
             s.epsln = s.sn * beta_n;
             s.dbar = -s.cs * beta_n;
-            s.root = sqrt(gbar * gbar + s.dbar * s.dbar);
-            double gamma = sqrt(gbar * gbar + beta_n * beta_n);
+            s.root = sqrt(fma(s.dbar, s.dbar, q.gbar2));
+            double gamma = sqrt(fma(beta_n, beta_n, q.gbar2));
             gamma = fmax(gamma, eps);
-            s.cs = gbar / gamma;
+            s.cs = q.gbar / gamma;
             s.sn = beta_n / gamma;
             st.phi = s.cs * s.phibar;
             s.phibar = s.sn * s.phibar;
@@ -635,9 +667,9 @@ __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, dou
             s.gmax = fmax(s.gmax, gamma);
             s.gmin = fmin(s.gmin, gamma);
             const double zz = s.rhs1 / gamma;
-            s.rhs1 = s.rhs2 - st.delta * zz;
+            s.rhs1 = fma(-st.delta, zz, s.rhs2);
             s.rhs2 = -s.epsln * zz;
-            st.sj = 1.0 / beta_j;
+            st.sj = q.sj;
             st.rotate = true;
             st.cb = beta_km1 / beta_km2;
         }
@@ -648,6 +680,11 @@ __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, dou
     }
     s.itn = k;
     return st;
+}
+__device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+{
+    const KryPre q = minres_pre(s);
+    return minres_post(s, q, k, S0, S1, S2, xn2, maxiter);
 }
 
 // p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}, contracted the same way wherever it is formed
@@ -934,10 +971,10 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double2 xz = c.Xv[ci];
-        const double eta = xz.x + a * xz.y;
+        const double eta = eta_project(xz, a);
         c.eta[ci] = eta;
         const double om = c.omega_b[ctl.it & 1][ci];
-        const double tt = ((double)c.z[ci] - 0.5) - om * eta;
+        const double tt = beta_rhs_term(om, eta, (double)c.z[ci]);
         double x[P];
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) x[aa] = c.Xt[(size_t)aa * n + i];
@@ -954,19 +991,12 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
 }
 
+// One visit row of the omega_a update: omega_a ~ PG(1, w'alpha) when the site exists (z = 1 or a detection
+// was seen, base.py:116-119), and the row's terms of alpha's system W'Omega W, W'(y - 1/2) (logit.py:216-224).
 template <int Q>
-__global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
+__device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int r, double (&acc)[nacc(Q)])
 {
-    const Ctx &c = *cp;
-    const Tile tile = tile_of_block(chain_base);
-    const int chain = tile.chain, blk = tile.blk;
-    const ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const uint64_t key = sc.key;
-    const uint32_t it = ctl.it;
-    const int R = c.R, r = blk * blockDim.x + threadIdx.x;
-    double acc[nacc(Q)];
+    const int R = c.R;
 #pragma unroll
     for (int t = 0; t < nacc(Q); ++t) acc[t] = 0.0;
     if (r < R) {
@@ -978,9 +1008,9 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 #pragma unroll
             for (int a = 0; a < Q; ++a) {
                 w[a] = c.Wt[(size_t)a * R + r];
-                wa += w[a] * sc.alpha[a];
+                wa = fma(w[a], sc.alpha[a], wa);
             }
-            Cursor cur(key, (uint32_t)r, it, STREAM_OMEGA_A);
+            Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
             const double om = pg1_draw(cur, wa);
             c.omega_a[(size_t)chain * R + r] = om;
             const double tt = (double)c.yrow[r] - 0.5;
@@ -995,6 +1025,19 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
             for (int a = 0; a < Q; ++a) acc[t++] = w[a] * tt;
         }
     }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    const ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    double acc[nacc(Q)];
+    omega_a_row<Q>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
     block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
 }
 

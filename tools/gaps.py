@@ -20,7 +20,7 @@ dur = defaultdict(list); gap_after = defaultdict(list); per_it = []
 for a, b in zip(zi[:-1], zi[1:]):
     seq = ev[a + 1:b + 1]
     per_it.append(ev[b][2] - ev[a][2])
-    main = [e for e in seq if e[0] in ('k_eta_init', 'k_solve', 'k_minres', 'k_beta_partial', 'k_z_ob')]
+    main = [e for e in seq if e[0] in ('k_eta_init', 'k_solve', 'k_iter', 'k_minres', 'k_beta_partial', 'k_z_ob')]
     prev_end = ev[a][2]; prev = 'k_z_ob(prev)'
     for e in main:
         dur[e[0]].append(e[2] - e[1])

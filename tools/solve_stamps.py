@@ -37,4 +37,8 @@ print('step ' + ' '.join('%18s' % n for n in names) + '   step total')
 for k in range(2, min(itn + 3, STEPS - 1)):
     d = [t[k, j + 1] - t[k, j] for j in range(8)]
     print('%4d ' % k + ' '.join('%18d' % v for v in d) + '   %d' % (t[k + 1, 0] - t[k, 0]))
+cyc = lambda a, b: int(b - a)
+print('phase A: tau %d, rhs+p0 %d, barrier %d, to first step %d' % (cyc(t[0,0], t[0,1]), cyc(t[0,1], t[0,2]), cyc(t[0,2], t[0,3]), cyc(t[0,3], t[1,0])))
+L = STEPS - 1
+print('phase C: proj sums+barrier %d, eta+beta partials+stats %d; kernel start to end %d' % (cyc(t[L,0], t[L,1]), cyc(t[L,1], t[L,2]), cyc(t[0,0], t[L,2])))
 eng.close()
