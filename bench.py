@@ -13,10 +13,10 @@ arrays from rank 0; there is no per-iteration collective.  value = chain-iterati
 max-over-ranks wall time of exactly K timed steps.
 
 The JSON line also carries
-  roofline     : the dominant kernel (k_minres, one MINRES iteration of the eta solve): algorithmic
-                 bytes per launch / its mean launch time, measured live right after the timed region
-                 with HIP events on the engine's stream around 200 back-to-back graph-captured launches
-                 (occ_profile);
+  roofline     : the dominant kernel (k_iter: tau, right-hand side, the whole MINRES solve of eta, projection
+                 and beta sums of one iteration, all chains): algorithmic bytes per launch / its mean launch
+                 time, measured live right after the timed region with two HIP events around each of 200
+                 k_iter launches on the engine's main stream while the chains keep running (occ_profile);
   cpu_baseline : the CPU oracle (C restatement of the reference loop, oracle/) timed on one host core
                  for a bounded number of iterations of the same workload (rank 0, N = 1 only).
 """
@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 
 
 def minres_bytes_per_launch(prob, n_chains, sell_entries):
-    """Algorithmic bytes one k_minres launch (one MINRES iteration of the joint system) must move
-    (DESIGN.md "Roofline accounting").
+    """Algorithmic bytes of ONE MINRES step of the joint system for all chains (DESIGN.md "Roofline
+    accounting"): what an implementation that keeps the vectors in HBM must move per step.
 
     per chain and site : reads g_{k-1}, p_{k-2}, p_{k-3}, w_{k-4}, w_{k-3}, x (6 x 16 B) + omega_b (8 B);
                          writes p_{k-1}, g_k, w_{k-2}, x (4 x 16 B)                   -> 168 B
@@ -46,6 +46,21 @@ def minres_bytes_per_launch(prob, n_chains, sell_entries):
     Neighbour gathers hit lines already counted; partial sums are O(blocks).
     """
     return n_chains * prob.n * 168 + prob.n * 8 + sell_entries * 12
+
+
+def iter_bytes_per_launch(prob, n_chains, sell_entries, steps_per_chain):
+    """Algorithmic bytes of one k_iter launch: `steps_per_chain` MINRES steps per chain (mean MINRES
+    iterations + 3, measured) at the per-step figure above, plus the one-off terms of SURVEY 8(d):
+    right-hand side (omega_b, z, X, two noise vectors, warm start read; rhs written) and projection /
+    beta sums (X read again; eta and x written).  k_iter keeps the vectors in registers between steps, so its
+    real HBM traffic (roofline.traffic) is far below this figure: `achieved` is the rate an HBM-resident
+    implementation would need to match its speed."""
+    n, p = prob.n, prob.p
+    per_step_chain = n * 168
+    shared_per_step = n * 8 + sell_entries * 12
+    rhs = n * (8 + 1 + 8 * p + 16 + 32 + 8)
+    tail = n * (8 * p + 8 + 16)
+    return int(n_chains * (steps_per_chain * per_step_chain + rhs + tail) + steps_per_chain * shared_per_step)
 
 
 def pmc_traffic(kernel, workload_key):
@@ -166,6 +181,7 @@ def main():
     # ---- warm-up (includes Krylov calibration and the hipGraph capture), then K timed steps --------
     if args.warmup > 0:
         eng.run(args.warmup, args.warmup - 1)
+    stats_warm = eng.stats()
     barrier()
     t0 = time.perf_counter()
     a, b, t = eng.run(args.steps, args.steps - 1)
@@ -181,12 +197,34 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, live, HIP events on the engine's stream --------------
         prof = eng.profile(reps=200)
-        kmean = stats['krylov_mean']
-        # launches on the critical path of one iteration (omega_a, alpha_draw, noise run on the side stream)
-        per_iter = {'eta_init': 1, 'minres': stats['krylov_cap'] + 3, 'beta_partial': 1, 'z_ob': 1}
-        ka = prof['minres']
+        st1 = eng.stats()
         sell = sell_entry_count(prob)
-        bytes_launch = minres_bytes_per_launch(prob, C, sell)
+        fused = bool(stats['persistent_solve']) and prof['iter']['launches'] > 0
+        if fused:
+            # the timed region itself: every k_iter launch is clocked from inside (first workgroup in to last chain
+            # out, constant-rate device wall clock), and its MINRES iterations are counted on the device
+            d_solves = max(1, stats['solves'] - stats_warm['solves'])
+            steps = (stats['krylov_total'] - stats_warm['krylov_total']) / d_solves + 3.0
+            kname = 'k_iter'
+            ka = {'avg_us': stats['iter_kernel_mean_us'], 'launches': stats['iter_kernel_launches']}
+            bytes_launch = iter_bytes_per_launch(prob, C, sell, steps)
+            per_iter = {'iter': 1, 'z_ob': 1}
+            prof['iter_in_situ_hip_events'] = prof['iter']
+            prof['iter'] = dict(ka, total_us=ka['avg_us'] * ka['launches'])
+            timing = ('every k_iter launch of the TIMED REGION clocked inside the kernel (device wall clock, first '
+                      'workgroup in to last chain out; HIP events cannot bracket a graph node without adding nodes); '
+                      'cross-checks: avg_launch_us_by_kernel.iter_in_situ_hip_events = two HIP events on the main '
+                      'stream around each of 200 further launches, launched one by one after the timed region (the '
+                      'device idles between them: slower), and the rocprofv3 kernel_stats of the same command in '
+                      'profiles/')
+        else:
+            steps = None
+            kname, ka = 'k_minres', prof['minres']
+            bytes_launch = minres_bytes_per_launch(prob, C, sell)
+            per_iter = {'eta_init': 1, 'minres': stats['krylov_cap'] + 3, 'beta_partial': 1, 'z_ob': 1}
+            timing = ('HIP events on the engine stream around 200 replays of a captured solve prefix '
+                      '(k_eta_init + k_minres launches 1..8, every launch cache-cold as in the real solve), '
+                      'k_eta_init subtracted; = kernel duration + one dependent-launch boundary')
         achieved = bytes_launch / (ka['avg_us'] * 1e-6) / 1e9 if ka['avg_us'] > 0 else 0.0
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
         out = {
@@ -210,21 +248,22 @@ def main():
                 'parallelism': f'chains sharded {C}/GPU, no data-path collective',
                 'krylov_iterations_mean': round(stats['krylov_mean'], 2),
                 'krylov_cap': stats['krylov_cap'], 'stalls': stats['stalls'],
+                'fused_iteration_kernel': bool(stats['persistent_solve']), 'main_stream_cus': stats['main_stream_cus'],
                 'threads_per_block': stats['threads_per_block'],
                 'device_ms_last_run': round(stats['last_run_ms'], 3),
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_minres',
+                'bound': 'hbm', 'kernel': kname,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': pmc_traffic('occ::k_minres', f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else None,
+                'traffic': pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else None,
                 'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)',
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
-                'timing': 'HIP events on the engine stream around 200 replays of a captured solve prefix '
-                          '(k_eta_init + k_minres launches 1..8, every launch cache-cold as in the real solve), '
-                          'k_eta_init subtracted; = kernel duration + one dependent-launch boundary',
-                'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['minres'] / total_us, 3) if total_us else None,
+                'timing': timing,
+                'minres_steps_per_launch': round(steps, 2) if steps else None,
+                'algorithmic_bytes_per_minres_step': minres_bytes_per_launch(prob, C, sell),
+                'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['iter' if fused else 'minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},
             },
         }

@@ -110,12 +110,19 @@ typedef struct occ_stats {
     int32_t krylov_cap;      /* Krylov steps captured per eta solve */
     int32_t krylov_last;     /* MINRES iterations of the last eta solve (chain 0) */
     double krylov_mean;      /* mean MINRES iterations per solve since creation (all chains) */
+    int64_t krylov_total;    /* MINRES iterations since creation (all chains) */
+    int64_t solves;          /* eta solves since creation (all chains) */
     double last_run_ms;      /* device time of the last occ_run (HIP events on the engine's stream) */
     int32_t n_blocks_sites, n_blocks_rows, threads_per_block, n_chains;
     int32_t persistent_solve; /* 1: fused iteration kernel with the persistent eta solve (k_iter + k_z_ob per
                                  iteration), 0: one launch per MINRES step, omega_a/alpha/noise on a side stream */
     int32_t solve_workgroups; /* workgroups per chain of the persistent solve */
     int32_t main_stream_cus;  /* > 0: CUs reserved for the main stream (k_iter, k_z_ob); the side stream has the others */
+    int32_t pad_;
+    double profile_minres_iterations; /* mean MINRES iterations per solve over the k_iter launches of the last occ_profile */
+    int64_t iter_kernel_launches;     /* k_iter launches of the last occ_run ... */
+    double iter_kernel_mean_us;       /* ... and their mean duration, first workgroup in to last chain out, by the
+                                         device's constant-rate wall clock read inside the kernel */
 } occ_stats;
 int occ_get_stats(occ_sampler *s, occ_stats *out);
 
@@ -124,9 +131,10 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
  * stream; total_us[kind] / counts[kind] = kernel duration + one dependent-launch boundary.  k_minres is
  * timed inside a replayed graph of a real solve prefix (k_eta_init + launches 1..8), see occ_gibbs.hip.
  * kinds: 0 omega_b, 1 noise, 2 eta_init, 3 minres, 4 beta_partial, 5 omega_a, 6 alpha_draw,
- * 7 z_ob (beta draw + z update + next iteration's omega_b), 8 iter (the fused iteration kernel k_iter: counts[8] =
- * MINRES steps of the timed launches (the slowest chain's iterations + 3 per launch), total_us[8] = time of
- * those whole launches; zero when the engine does not use the fused iteration).
+ * 7 z_ob (beta draw + z update + next iteration's omega_b), 8 iter (the fused iteration kernel k_iter, timed IN SITU
+ * first: `reps` real iterations continue the chains, nothing recorded, two HIP events around every k_iter launch
+ * on the main stream while the side stream runs omega_a / alpha / noise as in occ_run; counts[8] = launches,
+ * total_us[8] = sum of their durations; zero when the engine does not use the fused iteration).
  * The chains are left mid-solve in an unspecified state: call occ_set_start before sampling again. */
 #define OCC_N_KERNEL_KINDS 9
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],

@@ -32,10 +32,11 @@ class OccStats(C.Structure):
     _fields_ = [
         ('iterations', C.c_int64), ('graph_launches', C.c_int64), ('eager_iterations', C.c_int64),
         ('stalls', C.c_int64), ('krylov_cap', C.c_int32), ('krylov_last', C.c_int32),
-        ('krylov_mean', C.c_double), ('last_run_ms', C.c_double),
+        ('krylov_mean', C.c_double), ('krylov_total', C.c_int64), ('solves', C.c_int64), ('last_run_ms', C.c_double),
         ('n_blocks_sites', C.c_int32), ('n_blocks_rows', C.c_int32), ('threads_per_block', C.c_int32),
         ('n_chains', C.c_int32), ('persistent_solve', C.c_int32), ('solve_workgroups', C.c_int32),
-        ('main_stream_cus', C.c_int32),
+        ('main_stream_cus', C.c_int32), ('pad_', C.c_int32), ('profile_minres_iterations', C.c_double),
+        ('iter_kernel_launches', C.c_int64), ('iter_kernel_mean_us', C.c_double),
     ]
 
 

@@ -71,6 +71,7 @@ struct occ_sampler {
     int64_t iterations = 0, graph_launches = 0, eager_iterations = 0, stalls = 0;
     int krylov_last = 0;
     double last_run_ms = 0.0;
+    double profile_minres_iterations = 0.0;
     int calib_max = 0;
     unsigned long long seen_tot = 0, seen_sq = 0, seen_solves = 0;  // counters at the last cap decision
     // record buffer (alpha | beta | tau rows of the current occ_run), kept between runs
@@ -480,8 +481,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     for (int e = 0; e < 2; ++e) {
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_z[e], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_z[e], hipEventDisableTiming | hipEventReleaseToDevice));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming | hipEventReleaseToDevice));
     }
     s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
     s->event_nodes = s->side_enabled && std::getenv("OCC_STREAM_EVENTS") == nullptr;  // diagnostic: fork/join by stream calls
@@ -702,7 +703,10 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
     c.bar = nullptr;
+    c.iter_clock = nullptr;
     if (s->persistent) {
+        if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
+        s->iter.clock = c.iter_clock;
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
         if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 2 * c.nb_n * 4))) return rc;
         s->iter.bar = c.bar;
@@ -837,6 +841,10 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     }
     int rc = set_window(s, n_iter, burnin, keep);
     if (rc) return rc;
+    if (c.iter_clock) {  // k_iter's clock counts this run only
+        const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(c.iter_clock, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    }
     std::vector<ChainScalars> h;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
 
@@ -1061,6 +1069,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->krylov_cap = s->krylov_cap;
     out->krylov_last = h[0].minres_itn_last;
     out->krylov_mean = solves ? (double)tot / (double)solves : 0.0;
+    out->krylov_total = (int64_t)tot;
+    out->solves = (int64_t)solves;
     out->last_run_ms = s->last_run_ms;
     out->n_blocks_sites = s->ctx.nb_n;
     out->n_blocks_rows = s->ctx.nb_r;
@@ -1069,6 +1079,17 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->persistent_solve = s->persistent ? 1 : 0;
     out->solve_workgroups = s->iter.nbg;
     out->main_stream_cus = s->main_cus;
+    out->profile_minres_iterations = s->profile_minres_iterations;
+    out->iter_kernel_launches = 0;
+    out->iter_kernel_mean_us = 0.0;
+    if (s->ctx.iter_clock) {
+        unsigned long long clk[4];
+        HIP_TRY(hipMemcpy(clk, s->ctx.iter_clock, sizeof(clk), hipMemcpyDeviceToHost));
+        int khz = 0;
+        HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device));
+        out->iter_kernel_launches = (int64_t)clk[3];
+        if (clk[3] && khz > 0) out->iter_kernel_mean_us = 1000.0 * (double)clk[2] / (double)khz / (double)clk[3];
+    }
     return OCC_OK;
 }
 
@@ -1103,6 +1124,45 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     HIP_TRY(hipSetDevice(s->device));
     int rc = set_window(s, 1 << 30, 0, 0);  // no chain reaches its stop during the timing loops
     if (rc) return rc;
+    // The fused iteration kernel first, IN SITU: `reps` real iterations continue the chains from where they are
+    // (nothing recorded), the side chain on the side stream as in occ_run, two HIP events around every
+    // k_iter launch on the main stream.  counts[K_ITER] = launches, total_us[K_ITER] = the sum of their durations;
+    // the MINRES iterations they ran show in occ_get_stats (krylov_total, solves) before and after.
+    counts[K_ITER] = 0;
+    total_us[K_ITER] = 0.0;
+    if (s->persistent && !s->fused_side) {
+        std::vector<ChainScalars> h0;
+        if ((rc = read_scalars(s, h0))) return rc;
+        if (s->need_prologue) launch_prologue(s);
+        if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+        for (int r = 0; r < reps; ++r) {
+            const int pe = s->parity;
+            hipStream_t side = s->side_enabled ? s->side : s->stream;
+            if (s->side_enabled) HIP_TRY(hipStreamWaitEvent(side, s->ev_z[pe ^ 1], 0));
+            launch_kind(s, side, K_OMEGA_A, pe);
+            launch_kind(s, side, K_ALPHA_DRAW, pe);
+            launch_kind(s, side, K_NOISE, pe, 1);
+            if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
+            HIP_TRY(hipEventRecord(s->ev0, s->stream));
+            launch_kind(s, s->stream, K_ITER, pe);
+            HIP_TRY(hipEventRecord(s->ev1, s->stream));
+            if (s->side_enabled) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
+            launch_kind(s, s->stream, K_Z_OB, pe);
+            if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
+            s->parity ^= 1;
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+            total_us[K_ITER] += 1000.0 * ms;
+        }
+        counts[K_ITER] = reps;
+        std::vector<ChainScalars> h;
+        if ((rc = read_scalars(s, h))) return rc;
+        if ((rc = check_device_errors(s, h))) return rc;
+        unsigned long long dt = 0, ds = 0;
+        for (size_t ch = 0; ch < h.size(); ++ch) { dt += h[ch].krylov_total - h0[ch].krylov_total; ds += h[ch].solves - h0[ch].solves; }
+        s->profile_minres_iterations = ds ? (double)dt / (double)ds : 0.0;
+    }
     const int e = s->parity;
     double us = 0.0;
     auto timed = [&](int kind, int extra) -> int {
@@ -1144,41 +1204,6 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         const double eta_us = total_us[K_ETA_INIT] / counts[K_ETA_INIT];
         counts[K_MINRES] = (int64_t)reps * KRY_TIMED;
         total_us[K_MINRES] = std::max(0.0, per_replay_us - eta_us) * reps;
-    }
-    // the fused iteration kernel: replays of {restore the warm start, k_iter} minus replays of {restore the warm
-    // start}; every replay redoes the same iteration (k_z_ob, which advances it, is not launched)
-    counts[K_ITER] = 0;
-    total_us[K_ITER] = 0.0;
-    if (s->persistent) {
-        const size_t xbytes = sizeof(double2) * (size_t)s->ctx.C * s->ctx.n;
-        HIP_TRY(hipMemcpyAsync(s->ctx.Pv[1], s->ctx.Xv, xbytes, hipMemcpyDeviceToDevice, s->stream));  // Pv[1]: scratch here
-        double per_replay_us[2] = {0.0, 0.0};
-        for (int with_iter = 0; with_iter < 2; ++with_iter) {
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-            HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
-            if (with_iter) launch_kind(s, s->stream, K_ITER, e);
-            HIP_TRY(hipStreamEndCapture(s->stream, &graph));
-            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_TRY(hipGraphLaunch(exec, s->stream));
-            HIP_TRY(hipEventRecord(s->ev0, s->stream));
-            for (int r = 0; r < reps; ++r) HIP_TRY(hipGraphLaunch(exec, s->stream));
-            HIP_TRY(hipEventRecord(s->ev1, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-            (void)hipGraphExecDestroy(exec);
-            (void)hipGraphDestroy(graph);
-            per_replay_us[with_iter] = 1000.0 * ms / reps;
-        }
-        std::vector<Slot> hs((size_t)s->ctx.C * NSLOT);
-        HIP_TRY(hipMemcpy(hs.data(), s->ctx.slots, sizeof(Slot) * hs.size(), hipMemcpyDeviceToHost));
-        int steps = 0;  // the launch lasts as long as its slowest chain: MINRES iterations + 3 steps
-        for (int ch = 0; ch < s->ctx.C; ++ch) steps = std::max(steps, hs[(size_t)ch * NSLOT].itn + 3);
-        counts[K_ITER] = (int64_t)reps * steps;
-        total_us[K_ITER] = std::max(0.0, per_replay_us[1] - per_replay_us[0]) * reps;
-        HIP_TRY(hipMemcpyAsync(s->ctx.Xv, s->ctx.Pv[1], xbytes, hipMemcpyDeviceToDevice, s->stream));
     }
     // finish that solve so that the tail kernels have real work
     int k_last = 0;

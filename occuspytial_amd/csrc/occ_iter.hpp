@@ -69,6 +69,7 @@ struct IterArgs {
     double *part_beta;
     double tau_rate, tau_shape;
     unsigned *bar;        // [C][BAR_STRIDE]
+    unsigned long long *clock;  // Ctx::iter_clock
     double *part;         // [C][2][nb_n][4] partial sums of the running solve, by step parity
     int nbg, nwa, nwn;    // workgroups per chain: solve, omega_a, noise roles
     int C, p, q;
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
         if (writer) sc.mid[e] = ctl;
         return;
     }
+    const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
     const uint32_t it = ctl.it;
     const int n = a.n, i = wg * ITER_WG + (int)threadIdx.x;
     const bool act = i < n;
@@ -466,6 +468,8 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
         sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
         sc.solves += 1ull;
         if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
+        atomicMin(ia.clock, clk0);
+        atomicMax(ia.clock + 1, (unsigned long long)wall_clock64());
     }
     PHASE_STAMP(STAMP_STEPS - 1, 2)
 }

@@ -137,6 +137,10 @@ struct Ctx {
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
     unsigned *bar;      // [C][32] barrier / ticket counters of k_iter (occ_iter.hpp); null: not used
+    // k_iter's own clock (constant-rate wall clock): {earliest start, latest end} of the running launch over
+    // its chains, and {sum of launch durations, launches} since the last occ_run began.  k_iter's chain
+    // writers fill the first pair, k_z_ob (the next kernel) folds it into the second.
+    unsigned long long *iter_clock;
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -1082,6 +1086,12 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
         Ctl nx = ctl;  // a mid-solve chain keeps its iteration number and its koff
         if (!skip) nx.it = it + 1;
         sc.ctl[e ^ 1] = nx;
+        if (chain == chain_base && c.iter_clock != nullptr && c.iter_clock[1] != 0ull) {
+            c.iter_clock[2] += c.iter_clock[1] - c.iter_clock[0];
+            c.iter_clock[3] += 1ull;
+            c.iter_clock[0] = ~0ull;
+            c.iter_clock[1] = 0ull;
+        }
     }
     if (skip) return;
     double beta[P];
