@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER };
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER, K_GATE /* internal: not a profiled kind */ };
 static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
@@ -47,6 +47,10 @@ struct occ_sampler {
     // Slower on MI355X: the roles inherit k_iter's 239 VGPRs, i.e. two waves per SIMD for the Polya-Gamma draws.
     bool fused_side = false;
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
+    // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
+    // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
+    // (prologue, timing loops).
+    bool flag_sync = false, launch_sync = true;
     int graph_parity = 0;    // fused mode: sequence parity the captured pair of iterations starts with
     int tpb = 256;
     std::vector<void *> allocs;
@@ -155,7 +159,7 @@ KernelEI pick_beta_partial(int p)
 #define OCC_PICK_P(NAME, p) \
     ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
-KernelE pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
+KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {
     switch (q) {
@@ -178,22 +182,24 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
     switch (kind) {
         case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(c.p), gs, blk, 0, st, OCC_ARGS); break;
-        case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra); break;
+        case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0); break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
-        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS); break;
+        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
+        case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_ITER:
-            hipLaunchKernelGGL(k_iter, dim3((unsigned)(s->iter.nbg + s->iter.nwa + s->iter.nwn), (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e);
+            hipLaunchKernelGGL(k_iter, dim3((unsigned)(s->iter.nbg + s->iter.nwa + s->iter.nwn), (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
-        default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS); break;
+        default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
     }
 }
 
 int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
 {
     h.resize(s->ctx.C);
+    if (s->flag_sync && s->side) HIP_TRY(hipStreamSynchronize(s->side));  // its last k_noise is not waited for by the main stream
     HIP_TRY(hipMemcpyAsync(h.data(), s->ctx.sc, sizeof(ChainScalars) * h.size(), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return OCC_OK;
@@ -211,8 +217,9 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
         if (h[c].err == OCC_E_MINRES) { s->err = "MINRES solver did not converge!"; return OCC_E_MINRES; }
         if (h[c].err == OCC_E_CHOLESKY) { s->err = "Cholesky factorization/solver failed!"; return OCC_E_CHOLESKY; }
         if (h[c].err == OCC_E_HIP) {
-            s->err = "persistent eta solve: a barrier among the workgroups of a chain timed out (device over-subscribed); "
-                     "set OCC_NO_PERSISTENT=1 to use one launch per MINRES step";
+            s->err = "a device-side wait timed out (a barrier among the workgroups of a chain in k_iter, or a hand-over "
+                     "between the two streams): the device is over-subscribed or its queues are being serialised; "
+                     "OCC_EVENT_SYNC=1 hands over through events, OCC_NO_PERSISTENT=1 uses one launch per MINRES step";
             return OCC_E_HIP;
         }
     }
@@ -223,7 +230,7 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
 void launch_prologue(occ_sampler *s)
 {
     launch_kind(s, s->stream, K_OMEGA_B, s->parity);
-    launch_kind(s, s->stream, K_NOISE, s->parity, 0);
+    launch_kind(s, s->stream, K_NOISE, s->parity, 0);  // ahead = 0: outside the sequence counting
     s->need_prologue = false;
 }
 
@@ -254,6 +261,8 @@ int eager_sequence(occ_sampler *s)
 {
     if (s->need_prologue) launch_prologue(s);
     const int e = s->parity;
+    // one stream, reference order: stream order is the synchronisation, the hand-over counters stay untouched
+    struct NoSync { occ_sampler *s; bool old; explicit NoSync(occ_sampler *p) : s(p), old(p->launch_sync) { s->launch_sync = false; } ~NoSync() { s->launch_sync = old; } } no_sync(s);
     if (!s->fused_side) {
         launch_kind(s, s->stream, K_OMEGA_A, e);
         launch_kind(s, s->stream, K_ALPHA_DRAW, e);
@@ -334,6 +343,29 @@ int build_graph(occ_sampler *s, int cap)
         s->krylov_cap = 0;
         return OCC_OK;
     }
+    if (s->flag_sync) {
+        // two sequences (both parities) per graph and stream, no event nodes: the kernels hand over through
+        // the device counters of Ctx::sync
+        HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        for (int t = 0; t < 2; ++t) {
+            launch_kind(s, s->stream, K_ITER, s->parity ^ t);
+            launch_kind(s, s->stream, K_Z_OB, s->parity ^ t);
+        }
+        HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
+        HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
+        HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
+        for (int t = 0; t < 2; ++t) {
+            launch_kind(s, s->side, K_GATE, 0);
+            launch_kind(s, s->side, K_OMEGA_A, s->parity ^ t);
+            launch_kind(s, s->side, K_ALPHA_DRAW, s->parity ^ t);
+            launch_kind(s, s->side, K_NOISE, s->parity ^ t, 1);
+        }
+        HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[0]));
+        HIP_TRY(hipGraphInstantiate(&s->tail[0], s->tail_graph[0], nullptr, nullptr, 0));
+        s->graph_parity = s->parity;
+        s->krylov_cap = 0;
+        return OCC_OK;
+    }
     for (int e = 0; e < 2; ++e) {
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         if (s->persistent) {
@@ -392,6 +424,11 @@ int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
     if (s->fused_side) {  // the graph holds two sequences; the parity is the same again afterwards
+        HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
+        return OCC_OK;
+    }
+    if (s->flag_sync) {  // two sequences on each stream
+        HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
         return OCC_OK;
     }
@@ -648,6 +685,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             HIP_TRY(hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()));
             HIP_TRY(hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()));
             s->main_cus = nmain;
+            s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
         } else {
             int prio_low = 0, prio_high = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -704,6 +742,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     c.rec = nullptr;
     c.bar = nullptr;
     c.iter_clock = nullptr;
+    c.sync = nullptr;
+    if (s->flag_sync) {
+        if ((rc = dev_alloc(s, &c.sync, (size_t)SYNC_WORDS))) return rc;
+        s->iter.sync = c.sync;
+    }
     if (s->persistent) {
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
         s->iter.clock = c.iter_clock;
@@ -856,10 +899,10 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         for (int64_t i = 0; i < n_iter; ++i)
             if ((rc = eager_sequence(s))) return rc;
         done_min = n_iter;
-    } else if (s->persistent && !s->fused_side) {
+    } else if (s->persistent && !s->fused_side && !s->flag_sync) {
         if (!s->head[0] && (rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
         if (s->need_prologue) launch_prologue(s);
-    } else if (s->fused_side) {
+    } else if (s->fused_side || s->flag_sync) {
         if (s->need_prologue) launch_prologue(s);
         // the solve is one launch: nothing to calibrate.  The captured pair of iterations starts with one
         // sequence parity: an odd number of stepped iterations since the capture is realigned by one more step.
@@ -887,8 +930,8 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         launch_prologue(s);
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
-    if (done_min < n_iter && s->side_enabled && !s->fused_side) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
-    const int64_t seq_per_enqueue = s->fused_side ? 2 : 1;
+    if (done_min < n_iter && s->side_enabled && !s->fused_side && !s->flag_sync) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+    const int64_t seq_per_enqueue = (s->fused_side || s->flag_sync) ? 2 : 1;
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
@@ -1134,27 +1177,36 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         std::vector<ChainScalars> h0;
         if ((rc = read_scalars(s, h0))) return rc;
         if (s->need_prologue) launch_prologue(s);
-        if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+        // hand-overs as in occ_run: device counters, or stream events; OCC_EAGER_ONLY (counter collection
+        // serialises kernels): everything on the main stream in the reference's order, no hand-overs at all
+        const bool one_stream = std::getenv("OCC_EAGER_ONLY") != nullptr || !s->side_enabled;
+        const bool flags = s->flag_sync && !one_stream;
+        const bool ev = !flags && !one_stream;
+        const bool old_sync = s->launch_sync;
+        s->launch_sync = flags;
+        if (ev) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
         for (int r = 0; r < reps; ++r) {
             const int pe = s->parity;
-            hipStream_t side = s->side_enabled ? s->side : s->stream;
-            if (s->side_enabled) HIP_TRY(hipStreamWaitEvent(side, s->ev_z[pe ^ 1], 0));
+            hipStream_t side = one_stream ? s->stream : s->side;
+            if (ev) HIP_TRY(hipStreamWaitEvent(side, s->ev_z[pe ^ 1], 0));
+            if (flags) launch_kind(s, side, K_GATE, 0);
             launch_kind(s, side, K_OMEGA_A, pe);
             launch_kind(s, side, K_ALPHA_DRAW, pe);
             launch_kind(s, side, K_NOISE, pe, 1);
-            if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
+            if (ev) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
             HIP_TRY(hipEventRecord(s->ev0, s->stream));
             launch_kind(s, s->stream, K_ITER, pe);
             HIP_TRY(hipEventRecord(s->ev1, s->stream));
-            if (s->side_enabled) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
+            if (ev) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
             launch_kind(s, s->stream, K_Z_OB, pe);
-            if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
+            if (ev) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
             s->parity ^= 1;
             HIP_TRY(hipStreamSynchronize(s->stream));
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             total_us[K_ITER] += 1000.0 * ms;
         }
+        s->launch_sync = old_sync;
         counts[K_ITER] = reps;
         std::vector<ChainScalars> h;
         if ((rc = read_scalars(s, h))) return rc;
@@ -1165,6 +1217,8 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     }
     const int e = s->parity;
     double us = 0.0;
+    // the kernels below are replayed out of sequence: no waits, no counter updates
+    struct NoSync { occ_sampler *s; explicit NoSync(occ_sampler *p) : s(p) { s->launch_sync = false; } ~NoSync() { s->launch_sync = true; } } no_sync(s);
     auto timed = [&](int kind, int extra) -> int {
         int r = time_kernel_graph(s, kind, reps, e, extra, &us);
         counts[kind] = reps;

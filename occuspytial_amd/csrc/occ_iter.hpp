@@ -70,6 +70,7 @@ struct IterArgs {
     double tau_rate, tau_shape;
     unsigned *bar;        // [C][BAR_STRIDE]
     unsigned long long *clock;  // Ctx::iter_clock
+    unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
     double *part;         // [C][2][nb_n][4] partial sums of the running solve, by step parity
     int nbg, nwa, nwn;    // workgroups per chain: solve, omega_a, noise roles
     int C, p, q;
@@ -191,9 +192,9 @@ __device__ __forceinline__ void omega_a_rows(const Ctx &c, const ChainScalars &s
         default: { constexpr int D = 8; CALL; } break;                                                     \
     }
 
-__global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
+__global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int sync_on)
 {
-    __shared__ int s_flag;
+    __shared__ int s_flag, s_noise_ok;
     __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const KryArgs &a = ia.a;
     // grid = (nbg + nwa + nwn, C): the chain is blockIdx.y (a scalar register: the buffer descriptors below
@@ -244,6 +245,9 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
     // ================================ solve role ========================================================
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of the co-resident Polya-Gamma waves
     const int chain = (int)blockIdx.y, wg = b;
+    // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
+    // before anything can return or wait.
+    if (sync_on && ia.sync != nullptr && wg == 0 && chain == 0 && threadIdx.x == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ]);
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     const bool writer = (wg == 0 && threadIdx.x == 0);
@@ -252,6 +256,13 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
         return;
     }
     const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
+    // the noise of this iteration comes from the side stream's previous sequence: one lane starts waiting for it
+    // now (normally it has been there for a whole iteration); the workgroup looks at the result before phase A's loads
+    const bool synced = sync_on && ia.sync != nullptr;
+    if (synced && threadIdx.x == 0) {
+        const unsigned j = ia.sync[SYNC_MAIN_SEQ];          // this sequence's number (k_z_ob left it)
+        s_noise_ok = sync_wait(ia.sync + SYNC_NOISE, j) ? 1 : 0;
+    }
     const uint32_t it = ctl.it;
     const int n = a.n, i = wg * ITER_WG + (int)threadIdx.x;
     const bool act = i < n;
@@ -314,7 +325,17 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e)
     const double om = a.omega_b[it & 1][ci];
     const double zval = (double)ia.z[ci];
     const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
-    const double y = eta_rhs_site(om, xb, zval, ia.enorm[it & 1][ci], ia.uprior[it & 1][ci], sqrt(tau));
+    double en, up;
+    if (synced) {
+        __syncthreads();
+        if (!s_noise_ok && writer) sc.err = -2;
+        en = load_agent(&ia.enorm[it & 1][ci]);
+        up = load_agent(&ia.uprior[it & 1][ci]);
+    } else {
+        en = ia.enorm[it & 1][ci];
+        up = ia.uprior[it & 1][ci];
+    }
+    const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
     double2 x = X0[ic];
     const double d = tau * a.qdiag[ic] + om;
     double2 xn[NPRE];

@@ -141,6 +141,10 @@ struct Ctx {
     // its chains, and {sum of launch durations, launches} since the last occ_run began.  k_iter's chain
     // writers fill the first pair, k_z_ob (the next kernel) folds it into the second.
     unsigned long long *iter_clock;
+    // Hand-overs between the main and the side stream by device-side sequence counters instead of events
+    // (only when the two streams own disjoint sets of CUs, so that a workgroup spinning on one of them can
+    // never keep the producer it waits for off the device); null: not used.  See "Stream hand-overs" below.
+    unsigned *sync;
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -413,6 +417,56 @@ __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)
     return ok;
 }
 
+
+// ---- Stream hand-overs without events ---------------------------------------------------------------
+// Launch sequence number j (one Gibbs iteration of every chain) is  k_iter(j), k_z_ob(j)  on the main stream
+// and  k_gate(j), k_omega_a(j), k_alpha_draw(j), k_noise(j)  on the side stream.  A kernel never announces its
+// own completion: the FIRST thread of the NEXT kernel of the same stream does (stream order and the
+// kernel-boundary release make that exact and free -- no tickets, no fences, no write-through stores):
+//   sync[SYNC_MAIN]   = j  set by k_iter(j):  k_z_ob(j-1) is complete     k_gate(j) waits for >= j   (z, control words)
+//   sync[SYNC_NOISE]  = j  set by k_gate(j):  k_noise(j-1) is complete    k_iter(j) waits for >= j   (noise of j)
+//   sync[SYNC_ALPHA]  = j+1 set by k_noise(j): k_alpha_draw(j) is complete k_z_ob(j) waits for >= j+1 (alpha of j)
+// Every kernel sets before it waits, so the two streams cannot wait for each other.  Each stream counts its
+// own sequences in a word only it touches (SYNC_MAIN_SEQ: k_z_ob increments; SYNC_SIDE_SEQ: k_noise).
+// Consumers that wait inside a running kernel (k_iter, k_z_ob) read the data with L1-bypassing agent-scope
+// loads; kernels launched after k_gate rely on the kernel boundary.  Waits are bounded.
+enum : int { SYNC_MAIN = 0, SYNC_ALPHA = 16, SYNC_NOISE = 32, SYNC_MAIN_SEQ = 48, SYNC_SIDE_SEQ = 52, SYNC_WORDS = 64 };
+constexpr unsigned SYNC_SPIN_LIMIT = 1u << 21;
+
+__device__ __forceinline__ unsigned sync_read(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sync_set(unsigned *p, unsigned v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane: wait until *p has reached `target` (modulo 2^32); false when the wait gave up
+__device__ __forceinline__ bool sync_wait(const unsigned *p, unsigned target)
+{
+    unsigned spins = 0;
+    while ((int)(sync_read(p) - target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > SYNC_SPIN_LIMIT) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ double load_agent(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// First kernel of a side-stream sequence: one lane announces that the previous k_noise is complete, then waits
+// until the main stream has finished the previous sequence.
+__global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs)
+{
+    const Ctx &c = *cp;
+    if (c.sync == nullptr || threadIdx.x != 0) return;
+    const unsigned j = c.sync[SYNC_SIDE_SEQ];
+    sync_set(c.sync + SYNC_NOISE, j);
+    if (!sync_wait(c.sync + SYNC_MAIN, j)) scs[0].err = -2;
+}
+
 // =================================================================================================
 #define OCC_KARGS const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int e
 
@@ -483,12 +537,17 @@ __device__ __forceinline__ void noise_site(const Ctx &c, uint64_t key, int chain
     c.enorm[it & 1][ci] = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_SITE);
 }
 
-__global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead)
+__global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on)
 {
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
+    if (sync_on && c.sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const unsigned j = c.sync[SYNC_SIDE_SEQ];
+        sync_set(c.sync + SYNC_ALPHA, j + 1u);  // k_alpha_draw of this sequence, the previous kernel of the stream, is complete
+        c.sync[SYNC_SIDE_SEQ] = j + 1u;         // read next by k_gate, the next kernel of the stream
+    }
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int i = blk * blockDim.x + threadIdx.x;
@@ -1046,21 +1105,23 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 }
 
 // alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one wave per chain.
-__global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
+__global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS, int sync_on)
 {
     __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int Q = c.q;
-    reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
-    if (threadIdx.x == 0) {
-        const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
-        const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
-        if (!ok) sc.err = -4;
+    if (!(ctl.koff || ctl.it >= sc.it_stop)) {
+        const int Q = c.q;
+        reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
+        if (threadIdx.x == 0) {
+            const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
+            const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
+            if (!ok) sc.err = -4;
+        }
     }
+    (void)sync_on;  // its completion is announced by k_noise, the next kernel of the stream
 }
 
 // Last kernel of a launch sequence.  Every wave first draws beta ~ N(A^-1 r, A^-1) from the partial sums
@@ -1070,10 +1131,9 @@ __global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS)
 // omega_b of the NEXT iteration, which needs only beta and eta of this one -- one launch, two independent
 // roles, so the two run concurrently without a second stream.
 template <int P>
-__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
+__device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool synced, unsigned seq)
 {
-    __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
-    const Ctx &c = *cp;
+    __shared__ int s_wait_ok;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
@@ -1092,6 +1152,7 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
             c.iter_clock[0] = ~0ull;
             c.iter_clock[1] = 0ull;
         }
+        if (chain == chain_base && synced) c.sync[SYNC_MAIN_SEQ] = seq + 1u;  // read next by k_iter, the next kernel of the stream
     }
     if (skip) return;
     double beta[P];
@@ -1110,12 +1171,26 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
         omega_b_body<P>(c, sc, beta, chain, it + 1u, blk - nb);
         return;
     }
+    // role 0 needs alpha of THIS iteration, drawn on the side stream
+    const int Q = c.q;
+    double alpha[MAXC];
+    if (synced) {
+        if (threadIdx.x == 0) s_wait_ok = sync_wait(c.sync + SYNC_ALPHA, seq + 1u) ? 1 : 0;
+        __syncthreads();
+        if (!s_wait_ok && writer) sc.err = -2;
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a) alpha[a] = (a < Q) ? load_agent(&sc.alpha[a]) : 0.0;
+    } else {
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a) alpha[a] = (a < Q) ? sc.alpha[a] : 0.0;
+    }
     if (writer) {
         const uint32_t rel = it - sc.it_base;
         if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
-            const int Q = c.q;
             double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
-            for (int a = 0; a < Q; ++a) row[a] = sc.alpha[a];
+#pragma unroll
+            for (int a = 0; a < MAXC; ++a)
+                if (a < Q) row[a] = alpha[a];
 #pragma unroll
             for (int a = 0; a < P; ++a) row[Q + a] = beta[a];
             row[Q + P] = sc.tau;
@@ -1127,7 +1202,6 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
     const bool not_surveyed = sidx < 0;
     if (!not_surveyed && c.obs_site[sidx]) return;  // detection seen: z stays 1 (base.py:116-118)
     const size_t ci = (size_t)chain * n + i;
-    const int Q = c.q;
     double xb = 0.0;
 #pragma unroll
     for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
@@ -1138,7 +1212,9 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
         const int r0 = c.site_ptr[sidx], r1 = c.site_ptr[sidx + 1];
         for (int r = r0; r < r1; ++r) {
             double wa = 0.0;
-            for (int a = 0; a < Q; ++a) wa += c.Wt[(size_t)a * c.R + r] * (-sc.alpha[a]);
+#pragma unroll
+            for (int a = 0; a < MAXC; ++a)
+                if (a < Q) wa += c.Wt[(size_t)a * c.R + r] * (-alpha[a]);
             const double ex = expit(wa);
             prod = (r == r0) ? ex : prod * ex;
         }
@@ -1147,6 +1223,17 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS)
     }
     const double u = block_uniform(sc.key, (uint32_t)i, 0, it, STREAM_Z);
     c.z[ci] = (u < pr) ? 1 : 0;
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int sync_on)
+{
+    __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
+    const Ctx &c = *cp;
+    const bool synced = sync_on && c.sync != nullptr;
+    // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
+    const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
+    z_ob_body<P>(c, scs, chain_base, e, synced, seq);
 }
 
 }  // namespace occ
