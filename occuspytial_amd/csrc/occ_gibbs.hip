@@ -672,14 +672,15 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     // DISJOINT sets of CUs: k_iter's workgroups are latency-bound with one wave per SIMD, and Polya-Gamma waves
     // sharing their SIMDs (long quarter-rate instructions, another kernel's code in the instruction cache) cost
     // the solve more than the side work gains from the extra CUs (100x100, 4 chains: 143 -> 127 us per
-    // iteration).  The masks are whole XCDs (32 CUs): the k_iter grid is dealt over the XCDs of its queue.
+    // iteration).  A mask of N bits enables N CUs spread evenly over the 8 XCDs (tools/xcc_probe3.hip), and the
+    // k_iter grid is dealt round-robin over the XCDs: a multiple of 8 keeps one workgroup per CU.
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         const int ncu = prop.multiProcessorCount;
-        int nmain = ((s->iter.nbg * C + 31) / 32) * 32;
+        int nmain = ((s->iter.nbg * C + 7) / 8) * 8;
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
-        if (s->persistent && s->side_enabled && nmain >= 32 && nmain <= ncu - 32) {
+        if (s->persistent && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
             HIP_TRY(hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()));
