@@ -647,9 +647,9 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     // ---- launch geometry: one site (or visit row) per thread; enough blocks to spread over the CUs
     int tpb = 256;
     while (tpb > 64 && ((long long)n * C + tpb - 1) / tpb < 512) tpb >>= 1;
-    // Persistent eta solve (occ_solve.hpp): every workgroup of every chain must be resident at once -- one per
-    // CU, with margin for the side stream's kernels -- and a matrix row must fit the register-resident
-    // neighbour window.  Its partial sums are per 64-site slice, so the other kernels use 64-thread blocks too.
+    // Fused iteration kernel (occ_iter.hpp): every workgroup of every chain must be resident at once (at most two
+    // per CU) and a matrix row must fit the register-resident neighbour window.  Its partial sums are per
+    // 64-site slice, so the other kernels use 64-thread blocks too.
     {
         int wmax = 0;
         for (int sl = 0; sl < nslice; ++sl) wmax = std::max(wmax, (sell_ptr[sl + 1] - sell_ptr[sl]) / 64);
@@ -659,7 +659,10 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         s->iter.nbg = nbg;
         s->fused_side = false;
         s->iter.nwa = s->iter.nwn = 0;
-        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= prop.multiProcessorCount;
+        // (k_iter's 240 VGPRs allow two of its workgroups per CU: 8 chains at 100x100 run 210 us per iteration that way
+        // against 251 us with one launch per MINRES step)
+        const int wg_per_cu = std::getenv("OCC_ITER_WG_PER_CU") ? std::atoi(std::getenv("OCC_ITER_WG_PER_CU")) : 2;
+        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         if (s->persistent) tpb = 64;
         if (s->persistent && std::getenv("OCC_FUSED_SIDE")) {
             s->fused_side = true;
@@ -678,7 +681,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         const int ncu = prop.multiProcessorCount;
-        int nmain = ((s->iter.nbg * C + 7) / 8) * 8;
+        // at least 5/8 of the device for the main stream: k_z_ob's Polya-Gamma draws run there too
+        int nmain = std::max(((s->iter.nbg * C + 7) / 8) * 8, (ncu * 5 / 64) * 8);
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
         if (s->persistent && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
