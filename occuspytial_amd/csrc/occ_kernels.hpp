@@ -239,9 +239,26 @@ __device__ __forceinline__ void reduce_partials(const double *part, int nb, doub
         double acc[NQ];
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0;
-        for (int b = lane; b < nb; b += 64) {
+        // several rounds of loads in flight at a time (a plain "load, add" loop waits for every round trip in
+        // turn); the sums are accumulated in the same order as ever, rounds past the end add an exact 0
+        constexpr int R = NQ <= 8 ? 4 : (NQ <= 20 ? 2 : 1);  // registers: R * NQ doubles
+        for (int b0 = lane; b0 < nb; b0 += 64 * R) {
+            double v[R][NQ];
 #pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) acc[qi] += part[qi * nb + b];
+            for (int r = 0; r < R; ++r) {
+                const int b = b0 + 64 * r;
+                const int bc = min(b, nb - 1);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const double t = part[qi * nb + bc];
+                    v[r][qi] = (b < nb) ? t : 0.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) acc[qi] += v[r][qi];
+            }
         }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) out[qi] = wave_sum(acc[qi]);
