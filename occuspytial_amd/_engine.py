@@ -42,6 +42,7 @@ class Engine:
         self._h = h
         self._lib = lib
         self.device = int(device)
+        self.keys = [int(v) & (2 ** 64 - 1) for v in keys]
 
     def close(self):
         if getattr(self, '_h', None):
@@ -62,6 +63,35 @@ class Engine:
             raise ValueError('one key per chain is required')
         karr = (C.c_uint64 * self.n_chains)(*[int(v) & (2 ** 64 - 1) for v in keys])
         self._check(self._lib.occ_set_keys(self._h, karr))
+        self.keys = [int(v) & (2 ** 64 - 1) for v in keys]
+
+    # ---- checkpoint / resume (the reference has none) -------------------------------------
+    CHECKPOINT_FIELDS = ('alpha', 'beta', 'tau', 'eta', 'z', 'xz')
+
+    def checkpoint(self):
+        """Everything a chain needs to continue exactly where it is: the state the next iteration reads
+        (alpha, beta, tau, eta, z, the MINRES warm start xz), its iteration number and its Philox key.
+        Variates are functions of (key, iteration, index), so a restored chain reproduces the
+        uninterrupted one bit for bit; omega_b and the noise of the coming iteration are recomputed."""
+        out = {'n_chains': np.int64(self.n_chains), 'keys': np.array(self.keys, dtype=np.uint64),
+               'iter': np.array([int(self.get('iter', c)) for c in range(self.n_chains)], dtype=np.int64),
+               'shape': np.array([self.prob.n, self.prob.p, self.prob.q, self.prob.R], dtype=np.int64)}
+        for name in self.CHECKPOINT_FIELDS:
+            out[name] = np.stack([np.atleast_1d(self.get(name, c)) for c in range(self.n_chains)])
+        return out
+
+    def restore(self, ckpt):
+        """Inverse of :meth:`checkpoint` (same problem, same number of chains)."""
+        if int(ckpt['n_chains']) != self.n_chains:
+            raise ValueError('checkpoint holds %d chains, this engine %d' % (int(ckpt['n_chains']), self.n_chains))
+        if list(np.asarray(ckpt['shape'])) != [self.prob.n, self.prob.p, self.prob.q, self.prob.R]:
+            raise ValueError('checkpoint belongs to a problem of different size')
+        self.set_keys([int(k) for k in np.asarray(ckpt['keys'])])
+        for c in range(self.n_chains):
+            self.set_start(c, ckpt['alpha'][c], ckpt['beta'][c], float(np.asarray(ckpt['tau'][c]).ravel()[0]), ckpt['eta'][c])
+            self.set('z', ckpt['z'][c], c)
+            self.set('xz', ckpt['xz'][c], c)
+            self.set('iter', float(ckpt['iter'][c]), c)
 
     def set_start(self, chain, alpha, beta, tau, eta):
         a = np.ascontiguousarray(alpha, dtype=np.float64)

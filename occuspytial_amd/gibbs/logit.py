@@ -93,6 +93,51 @@ class LogitICARGibbs(GibbsBase):
         eng.step()
         self._pull_state(eng, 0)
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def checkpoint(self, path=None):
+        """State of every chain of the last :meth:`sample` call, sufficient to continue each of them exactly
+        (``Engine.checkpoint``).  Returns a dict of arrays; ``path`` additionally writes it as ``.npz``."""
+        eng = self.__dict__.get('_engine')
+        if eng is None:
+            raise RuntimeError('nothing to checkpoint: call sample() first')
+        ckpt = eng.checkpoint()
+        if path is not None:
+            np.savez(path, **ckpt)
+        return ckpt
+
+    def resume(self, checkpoint, size, progressbar=True):
+        """Continue the chains of ``checkpoint`` (a dict from :meth:`checkpoint` or the path of its ``.npz``)
+        for ``size`` more iterations on this sampler's problem.  Returns a ``PosteriorParameter`` of the new
+        draws; every chain's ``Chain`` is the continuation (use ``Chain.expand`` / ``append`` to join them to
+        earlier draws).  The result equals the tail of an uninterrupted run bit for bit."""
+        from ..posterior import PosteriorParameter
+        from tqdm.auto import tqdm
+        if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, '__fspath__'):
+            with np.load(checkpoint) as f:
+                checkpoint = {k: f[k] for k in f.files}
+        if size < 1:
+            raise ValueError('size must be a positive integer')
+        C = int(checkpoint['n_chains'])
+        self.__dict__['_stepping'] = False
+        eng = self._get_engine([int(k) for k in np.asarray(checkpoint['keys'])])
+        eng.restore(checkpoint)
+        alpha = np.zeros((C, size, self._problem.q))
+        beta = np.zeros((C, size, self._problem.p))
+        tau = np.zeros((C, size))
+        bar = tqdm(total=size, disable=not progressbar)
+        chunk = size if not progressbar else max(1, min(size, max(16, size // 25)))
+        done = 0
+        while done < size:
+            step = min(chunk, size - done)
+            alpha[:, done:done + step], beta[:, done:done + step], tau[:, done:done + step] = eng.run(step, 0)
+            done += step
+            bar.update(step)
+        bar.close()
+        chains = [Chain._from_arrays({'alpha': alpha[c], 'beta': beta[c], 'tau': tau[c]}) for c in range(C)]
+        self.chain = chains[0]
+        self._pull_state(eng, 0)
+        return PosteriorParameter(*chains)
+
     # ------------------------------------------------------------------ batched chains
     def _run_chains(self, samplers, size, burnin=0, start=None, progressbar=True):
         """All chains of one ``sample`` call as one device batch.

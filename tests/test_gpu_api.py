@@ -117,3 +117,26 @@ def test_posterior_agrees_with_oracle_chains_in_distribution(data, oracle):
         se = np.hypot(dg.mcse_mean(gpu), dg.mcse_mean(cpu))
         assert abs(gpu.mean() - cpu.mean()) < 4 * se
     assert checked >= 2
+
+
+def test_checkpoint_resume_continues_every_chain_exactly(data, tmp_path):
+    """SURVEY 8(f)-4 (the reference has no checkpoint): a chain restored from (alpha, beta, tau, eta, z, warm
+    start, iteration number, key) on a fresh sampler reproduces the uninterrupted run bit for bit."""
+    from occuspytial_amd import LogitICARGibbs
+    whole = LogitICARGibbs(*data, random_state=21).sample(50, chains=3, progressbar=False)
+    first = LogitICARGibbs(*data, random_state=21)
+    head = first.sample(20, chains=3, progressbar=False)
+    path = tmp_path / 'chains.npz'
+    ckpt = first.checkpoint(path)
+    assert ckpt['eta'].shape == (3, 150) and list(ckpt['iter']) == [20, 20, 20]
+    for k in ('alpha', 'beta', 'tau'):
+        assert np.array_equal(head[k], whole[k][:, :20])
+    fresh = LogitICARGibbs(*data, random_state=99)            # another object, another seed: everything comes from the file
+    tail = fresh.resume(str(path), 30, progressbar=False)
+    for k in ('alpha', 'beta', 'tau'):
+        assert np.array_equal(tail[k], whole[k][:, 20:])
+    assert len(fresh.chain) == 30
+    with pytest.raises(ValueError, match='different size'):
+        bad = dict(ckpt)
+        bad['shape'] = ckpt['shape'] + 1
+        fresh.resume(bad, 5, progressbar=False)
