@@ -43,9 +43,6 @@ struct occ_sampler {
     // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;
     // otherwise one launch per MINRES step on the main stream and omega_a / alpha / noise on the side stream
     bool persistent = false;
-    // experiment (OCC_FUSED_SIDE=1): omega_a / alpha / noise as extra workgroup roles of k_iter, no side stream.
-    // Slower on MI355X: the roles inherit k_iter's 239 VGPRs, i.e. two waves per SIMD for the Polya-Gamma draws.
-    bool fused_side = false;
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -190,7 +187,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_ITER:
-            hipLaunchKernelGGL(k_iter, dim3((unsigned)(s->iter.nbg + s->iter.nwa + s->iter.nwn), (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            hipLaunchKernelGGL(k_iter, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
     }
@@ -263,11 +260,9 @@ int eager_sequence(occ_sampler *s)
     const int e = s->parity;
     // one stream, reference order: stream order is the synchronisation, the hand-over counters stay untouched
     struct NoSync { occ_sampler *s; bool old; explicit NoSync(occ_sampler *p) : s(p), old(p->launch_sync) { s->launch_sync = false; } ~NoSync() { s->launch_sync = old; } } no_sync(s);
-    if (!s->fused_side) {
-        launch_kind(s, s->stream, K_OMEGA_A, e);
-        launch_kind(s, s->stream, K_ALPHA_DRAW, e);
-        launch_kind(s, s->stream, K_NOISE, e, 1);
-    }
+    launch_kind(s, s->stream, K_OMEGA_A, e);
+    launch_kind(s, s->stream, K_ALPHA_DRAW, e);
+    launch_kind(s, s->stream, K_NOISE, e, 1);
     if (s->persistent) {
         launch_kind(s, s->stream, K_ITER, e);
     } else {
@@ -331,18 +326,6 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
     int rc;
-    if (s->fused_side) {  // two iterations (both parities) in one linear graph: k_iter, k_z_ob, k_iter, k_z_ob
-        HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        for (int t = 0; t < 2; ++t) {
-            launch_kind(s, s->stream, K_ITER, s->parity ^ t);
-            launch_kind(s, s->stream, K_Z_OB, s->parity ^ t);
-        }
-        HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
-        HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
-        s->graph_parity = s->parity;
-        s->krylov_cap = 0;
-        return OCC_OK;
-    }
     if (s->flag_sync) {
         // two sequences (both parities) per graph and stream, no event nodes: the kernels hand over through
         // the device counters of Ctx::sync
@@ -423,10 +406,6 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
-    if (s->fused_side) {  // the graph holds two sequences; the parity is the same again afterwards
-        HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
-        return OCC_OK;
-    }
     if (s->flag_sync) {  // two sequences on each stream
         HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
@@ -657,18 +636,11 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         const int nbg = (n + ITER_WG - 1) / ITER_WG;
         s->iter.nbg = nbg;
-        s->fused_side = false;
-        s->iter.nwa = s->iter.nwn = 0;
         // (k_iter's 240 VGPRs allow two of its workgroups per CU: 8 chains at 100x100 run 210 us per iteration that way
         // against 251 us with one launch per MINRES step)
         const int wg_per_cu = std::getenv("OCC_ITER_WG_PER_CU") ? std::atoi(std::getenv("OCC_ITER_WG_PER_CU")) : 2;
         s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         if (s->persistent) tpb = 64;
-        if (s->persistent && std::getenv("OCC_FUSED_SIDE")) {
-            s->fused_side = true;
-            s->iter.nwa = std::max(1, (R + ITER_WG - 1) / ITER_WG);
-            s->iter.nwn = nbg;
-        }
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
     // same iteration run beside it on the side stream.  With the fused iteration kernel the two streams get
@@ -782,7 +754,6 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     {
         IterArgs &t = s->iter;
         t.a = s->kry;
-        t.cp = s->ctx_dev;
         t.Xt = c.Xt; t.z = c.z;
         for (int b = 0; b < 2; ++b) { t.enorm[b] = c.enorm[b]; t.uprior[b] = c.uprior[b]; }
         t.rhs = c.rhs; t.eta = c.eta; t.part_quad = c.part_quad; t.part_beta = c.part_beta;
@@ -904,10 +875,10 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         for (int64_t i = 0; i < n_iter; ++i)
             if ((rc = eager_sequence(s))) return rc;
         done_min = n_iter;
-    } else if (s->persistent && !s->fused_side && !s->flag_sync) {
+    } else if (s->persistent && !s->flag_sync) {
         if (!s->head[0] && (rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
         if (s->need_prologue) launch_prologue(s);
-    } else if (s->fused_side || s->flag_sync) {
+    } else if (s->flag_sync) {
         if (s->need_prologue) launch_prologue(s);
         // the solve is one launch: nothing to calibrate.  The captured pair of iterations starts with one
         // sequence parity: an odd number of stepped iterations since the capture is realigned by one more step.
@@ -935,8 +906,8 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         launch_prologue(s);
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
-    if (done_min < n_iter && s->side_enabled && !s->fused_side && !s->flag_sync) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
-    const int64_t seq_per_enqueue = (s->fused_side || s->flag_sync) ? 2 : 1;
+    if (done_min < n_iter && s->side_enabled && !s->flag_sync) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+    const int64_t seq_per_enqueue = s->flag_sync ? 2 : 1;
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
@@ -1178,7 +1149,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     // the MINRES iterations they ran show in occ_get_stats (krylov_total, solves) before and after.
     counts[K_ITER] = 0;
     total_us[K_ITER] = 0.0;
-    if (s->persistent && !s->fused_side) {
+    if (s->persistent) {
         std::vector<ChainScalars> h0;
         if ((rc = read_scalars(s, h0))) return rc;
         if (s->need_prologue) launch_prologue(s);

@@ -1,35 +1,30 @@
-// occ_iter.hpp -- one Gibbs iteration of every chain in TWO launches: k_iter, then k_z_ob (gfx950).
+// occ_iter.hpp -- k_iter: the critical path of one Gibbs iteration of every chain in ONE persistent launch (gfx950).
 //
-// k_iter fuses, by ROLE of the workgroup (256 threads each; roles are ranges of blockIdx.x):
-//
-//   solve role   nbg workgroups per chain, ALL of them resident at once (the host takes this path only when
-//                they fit one per CU).  Per chain, in order:
-//                  A  tau ~ Gamma (logit.py:206-209), right-hand side of the eta system (logit.py:75-78, 213),
-//                     p_0 = b - A x0 with the warm start x0 (logit.py:71, 82-88)          [k_eta_init]
-//                  B  joint MINRES for [x z] (logit.py:82-92), vectors in registers, one barrier per step AMONG
-//                     THE WORKGROUPS OF THE CHAIN; stopping test on the device             [k_minres x (K + 3)]
-//                  C  eta = x - (sum x / sum z) z (distributions.pyx:24-39), partial sums of beta's system
-//                     (logit.py:226-232)                                                   [k_beta_partial]
-//   omega_a role omega_a ~ PG(1, w'alpha) over the visit rows of existing sites, partial sums of alpha's system
-//                (logit.py:199-204, 216-224); the LAST workgroup of a chain to finish draws alpha  [k_omega_a, k_alpha_draw]
-//   noise role   the variates of the NEXT iteration's right-hand side (logit.py:75-77)    [k_noise]
+// nbg workgroups of 256 threads per chain (one site per thread), ALL of them resident at once (the host takes this
+// path only when they fit at most two per CU).  Per chain, in order:
+//   A  tau ~ Gamma (logit.py:206-209), right-hand side of the eta system (logit.py:75-78, 213),
+//      p_0 = b - A x0 with the warm start x0 (logit.py:71, 82-88)                         [k_eta_init]
+//   B  joint MINRES for [x z] (logit.py:82-92), vectors in registers, one barrier per step AMONG THE WORKGROUPS
+//      OF THE CHAIN; stopping test on the device                                           [k_minres x (K + 3)]
+//   C  eta = x - (sum x / sum z) z (distributions.pyx:24-39), partial sums of beta's system
+//      (logit.py:226-232)                                                                  [k_beta_partial]
+// (in brackets: the stand-alone kernels of occ_kernels.hpp that do the same work with one launch per step; they
+// remain the path for problems k_iter does not fit and the independent implementation it is tested against).
 //
 // Why one launch: at the headline size (100x100 sites, 4 chains) a k_minres launch moves 7.8 MB -- one
-// microsecond of HBM time -- and costs 5.7-7.3 us of launch boundary and cold dependent loads, the launches
-// per solve have to be guessed when the graph is captured, and every hand-over between the main stream and
-// the side stream (omega_a / alpha / noise ran there) cost 6-16 us of idle critical path.  Here the solve
-// runs exactly the steps it needs, chains do not wait for each other inside the launch, and the side work
-// fills the CUs and issue slots the latency-bound solve leaves idle -- no second stream, no events.
+// microsecond of HBM time -- and costs 5.7-7.3 us of launch boundary and cold dependent loads, and the launches
+// per solve have to be guessed when the graph is captured.  Here the solve runs exactly the steps it needs and
+// chains do not wait for each other inside the launch.
 //
-// Exchange between the workgroups of a chain (solve role): payload stored write-through (sc1), every storing
-// wave drained, one lane adds to the chain's arrival counter and polls it, then every load of exchanged
-// bytes is an sc1 load (per-CU L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs'
-// L2s are not coherent with each other).  Only g = A p (16 B per site) and four partial sums per 64-site
-// slice are exchanged per step: p_{k-2}, p_{k-3} at the NEIGHBOURS of a site stay in the registers of the
-// lane that re-formed them.  The arrival counter is monotonic over the whole run (ChainScalars::bar_base).
+// Exchange between the workgroups of a chain: payload stored write-through (sc1), every storing wave drained,
+// one lane adds to the chain's arrival counter and polls it, then every load of exchanged bytes is an sc1 load
+// (per-CU L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs' L2s are not coherent with
+// each other).  Only g = A p (16 B per site) and four partial sums per 64-site slice are exchanged per step:
+// p_{k-2}, p_{k-3} at the NEIGHBOURS of a site stay in the registers of the lane that re-formed them.  The arrival
+// counter is monotonic over the whole run (ChainScalars::bar_base).
 //
-// The arithmetic is that of the stand-alone kernels, through the same functions (minres_scalars, kry_form_*,
-// eta_rhs_site, ...), with partial sums per 64-site slice reduced in the same order: the fused iteration, the
+// The arithmetic is that of the stand-alone kernels, through the same functions (minres_pre/post, kry_form_*,
+// eta_rhs_site, ...), with partial sums per 64-site slice reduced in the same order: k_iter, the
 // launch-per-MINRES-step path and the eager stepping path return the same bits.
 #pragma once
 #include "occ_kernels.hpp"
@@ -41,7 +36,6 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
 constexpr int BAR_STRIDE = 32;                  // unsigned words per chain in IterArgs::bar (128 B)
-constexpr int BAR_ALPHA = 16;                   // word of the omega_a completion counter (own 64 B half)
 
 // Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
 // chain 0 / workgroup 0; the product build compiles the hooks away.
@@ -59,7 +53,6 @@ __device__ unsigned long long g_solve_stamps[STAMP_STEPS * STAMP_POINTS];
 
 struct IterArgs {
     KryArgs a;            // the MINRES descriptor of k_minres (matrix, omega_b, G buffers, x, scalars)
-    const Ctx *cp;        // the full descriptor, for the roles off the critical path
     // phase A / C inputs and outputs by value (no dependent load through cp on the critical path)
     const double *Xt;
     const uint8_t *z;
@@ -72,7 +65,7 @@ struct IterArgs {
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
     double *part;         // [C][2][nb_n][4] partial sums of the running solve, by step parity
-    int nbg, nwa, nwn;    // workgroups per chain: solve, omega_a, noise roles
+    int nbg;              // workgroups per chain
     int C, p, q;
 };
 
@@ -163,23 +156,6 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
     }
 }
 
-// omega_a role: 256 visit rows per workgroup, partial sums per 64-row slice (k_omega_a at 64 threads per block).
-template <int Q>
-__device__ __forceinline__ void omega_a_rows(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int wg)
-{
-    const int r = wg * ITER_WG + (int)threadIdx.x, lane = threadIdx.x & 63, slice = r >> 6;
-    double acc[nacc(Q)];
-    omega_a_row<Q>(c, sc, chain, it, r, acc);
-    if (slice < c.nb_r) {
-        double *out = c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r;
-#pragma unroll
-        for (int t = 0; t < nacc(Q); ++t) {
-            const double s = wave_sum(acc[t]);
-            if (lane == 0) out[t * c.nb_r + slice] = s;
-        }
-    }
-}
-
 #define OCC_SWITCH_DIM(d, CALL)                                                                            \
     switch (d) {                                                                                           \
         case 1: { constexpr int D = 1; CALL; } break;                                                      \
@@ -195,56 +171,11 @@ __device__ __forceinline__ void omega_a_rows(const Ctx &c, const ChainScalars &s
 __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int sync_on)
 {
     __shared__ int s_flag, s_noise_ok;
-    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
     const KryArgs &a = ia.a;
-    // grid = (nbg + nwa + nwn, C): the chain is blockIdx.y (a scalar register: the buffer descriptors below
-    // must be provably wave-uniform, or every buffer access becomes a serialising waterfall loop)
-    const int n_solve = ia.nbg, n_oa = ia.nwa;
-    const int b = (int)blockIdx.x;
-
-    // ================================ omega_a role (+ alpha by the last workgroup of the chain) ==========
-    if (b >= n_solve && b < n_solve + n_oa) {
-        const Ctx &c = *ia.cp;
-        const int chain = (int)blockIdx.y, wg = b - n_solve;
-        ChainScalars &sc = a.scs[chain];
-        const Ctl ctl = sc.ctl[e];
-        if (ctl.koff || ctl.it >= sc.it_stop) return;
-        OCC_SWITCH_DIM(ia.q, omega_a_rows<D>(c, sc, chain, ctl.it, wg));
-        // completion ticket: plain stores above, agent-scope release, one self-resetting counter per chain
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = atomicInc(ia.bar + (size_t)chain * BAR_STRIDE + BAR_ALPHA, (unsigned)ia.nwa - 1u);
-            s_flag = (old == (unsigned)ia.nwa - 1u) ? 1 : 0;
-            if (s_flag) __threadfence();  // acquire: this CU's L1 holds no stale partial sums
-        }
-        __syncthreads();
-        if (!s_flag) return;
-        const int Q = ia.q;
-        reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
-        if (threadIdx.x == 0) {
-            const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
-            const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
-            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
-        }
-        return;
-    }
-    // ================================ noise role (k_noise with ahead = 1) ===============================
-    if (b >= n_solve + n_oa) {
-        const Ctx &c = *ia.cp;
-        const int chain = (int)blockIdx.y, wg = b - n_solve - n_oa;
-        const ChainScalars &sc = a.scs[chain];
-        const Ctl ctl = sc.ctl[e];
-        if (ctl.koff || ctl.it >= sc.it_stop) return;
-        const int n = c.n, i = wg * ITER_WG + (int)threadIdx.x;
-        if (i >= n) return;
-        noise_site(c, sc.key, chain, i, ctl.it + 1u);
-        return;
-    }
-
-    // ================================ solve role ========================================================
-    __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of the co-resident Polya-Gamma waves
-    const int chain = (int)blockIdx.y, wg = b;
+    // grid = (nbg, C): the chain is blockIdx.y (a scalar register: the buffer descriptors below must be provably
+    // wave-uniform, or every buffer access becomes a serialising waterfall loop)
+    const int chain = (int)blockIdx.y, wg = (int)blockIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
     // before anything can return or wait.
     if (sync_on && ia.sync != nullptr && wg == 0 && chain == 0 && threadIdx.x == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ]);
