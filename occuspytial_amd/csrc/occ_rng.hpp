@@ -101,8 +101,10 @@ __device__ __forceinline__ double pg_a(int n, double x)
 {
     const double K = (n + 0.5) * kPi;
     if (x > kPgT) return K * exp(-0.5 * K * K * x);
-    const double e = -1.5 * (log(0.5 * kPi) + log(x)) + log(K) - 2.0 * (n + 0.5) * (n + 0.5) / x;
-    return exp(e);
+    // K (2/(pi x))^(3/2) exp(-2 (n + 1/2)^2 / x): one reciprocal, one square root, one exp (no logarithms)
+    const double rx = 1.0 / x;
+    const double v = (2.0 / kPi) * rx;
+    return K * (v * sqrt(v)) * exp(-2.0 * (n + 0.5) * (n + 0.5) * rx);
 }
 __device__ __forceinline__ double log_phi(double x) { return log(0.5 * erfc(-x * kSqrtHalf)); }
 
@@ -111,6 +113,12 @@ __device__ __forceinline__ double pg_mass_texpon(double Z)
     const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
     const double b = sqrt(1.0 / kPgT) * (kPgT * Z - 1.0);
     const double a = -sqrt(1.0 / kPgT) * (kPgT * Z + 1.0);
+    if (Z < 20.0) {  // everything is in range: q/p directly (two erfc, two exp), no logarithms
+        const double pb = 0.5 * erfc(-b * kSqrtHalf), pa = 0.5 * erfc(-a * kSqrtHalf);
+        const double ez = exp(Z);
+        const double qdivp = (4.0 / kPi) * fz * exp(fz * kPgT) * (pb / ez + ez * pa);
+        return 1.0 / (1.0 + qdivp);
+    }
     const double x0 = log(fz) + fz * kPgT;
     const double xb = x0 - Z + log_phi(b);
     const double xa = x0 + Z + log_phi(a);

@@ -120,8 +120,10 @@ static double pg_a(int n, double x)
 {
     double K = (n + 0.5) * M_PI;
     if (x > PG_T) return K * exp(-0.5 * K * K * x);
-    double e = -1.5 * (log(0.5 * M_PI) + log(x)) + log(K) - 2.0 * (n + 0.5) * (n + 0.5) / x;
-    return exp(e);
+    /* K (2/(pi x))^(3/2) exp(-2 (n + 1/2)^2 / x), written without logarithms (the device does the same) */
+    double rx = 1.0 / x;
+    double v = (2.0 / M_PI) * rx;
+    return K * (v * sqrt(v)) * exp(-2.0 * (n + 0.5) * (n + 0.5) * rx);
 }
 static double log_phi(double x) { return log(0.5 * erfc(-x * M_SQRT1_2)); }
 
@@ -131,6 +133,12 @@ static double pg_mass_texpon(double Z)
     double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
     double b = sqrt(1.0 / PG_T) * (PG_T * Z - 1.0);
     double a = -sqrt(1.0 / PG_T) * (PG_T * Z + 1.0);
+    if (Z < 20.0) { /* everything is in range: q/p directly, no logarithms (the device does the same) */
+        double pb = 0.5 * erfc(-b * M_SQRT1_2), pa = 0.5 * erfc(-a * M_SQRT1_2);
+        double ez = exp(Z);
+        double qdivp = (4.0 / M_PI) * fz * exp(fz * PG_T) * (pb / ez + ez * pa);
+        return 1.0 / (1.0 + qdivp);
+    }
     double x0 = log(fz) + fz * PG_T;
     double xb = x0 - Z + log_phi(b);
     double xa = x0 + Z + log_phi(a);
