@@ -196,6 +196,43 @@ def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, latti
     assert out['persistent'][2] == out['launch_per_step'][2]
 
 
+@pytest.mark.parametrize('env', [{'OCC_EVENT_SYNC': '1'}, {'OCC_EVENT_SYNC': '1', 'OCC_STREAM_EVENTS': '1'}, {'OCC_CU_SPLIT': '0'},
+                                 {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EAGER_ONLY': '1'},
+                                 {'OCC_NO_PERSISTENT': '1', 'OCC_STREAM_EVENTS': '1'}, {'OCC_NO_PERSISTENT': '1', 'OCC_NO_SIDE_STREAM': '1'}])
+def test_every_scheduling_mode_gives_the_same_chains(monkeypatch, env):
+    """How an iteration is scheduled -- hand-overs by device counters (default), by event nodes, by stream
+    events, without the CU partition, on one stream, launched eagerly, fused kernel or one launch per MINRES
+    step -- never changes a bit of the result."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(30, 40, visits=3, p=2, q=2, random_state=2)
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY, KEY + 11]
+    starts = [_random_start(prob, 3 + c) for c in range(2)]
+
+    def run():
+        eng = Engine(prob, keys)
+        for c in range(2):
+            eng.set_start(c, **starts[c])
+        rec = eng.run(33, 4)     # odd number of iterations: the graph holds two per replay
+        rec2 = eng.run(10, 0)    # and a second call continues the same chains
+        eta = [eng.get('eta', c) for c in range(2)]
+        eng.close()
+        return rec, rec2, eta
+
+    for k in ('OCC_EVENT_SYNC', 'OCC_STREAM_EVENTS', 'OCC_CU_SPLIT', 'OCC_NO_SIDE_STREAM', 'OCC_EAGER_ONLY', 'OCC_NO_PERSISTENT'):
+        monkeypatch.delenv(k, raising=False)
+    ref = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = run()
+    for u, v in zip(ref[0] + ref[1], alt[0] + alt[1]):
+        assert np.array_equal(u, v)
+    for u, v in zip(ref[2], alt[2]):
+        assert np.array_equal(u, v)
+
+
 def test_krylov_cap_overflow_is_resumed_exactly(monkeypatch):
     """A captured graph with too few Krylov steps carries the unfinished solve into the next replay
     (same arithmetic, continued), so results equal an unconstrained run bit for bit."""
