@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
     // before anything can return or wait.
-    if (sync_on && ia.sync != nullptr && wg == 0 && chain == 0 && threadIdx.x == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ]);
+    if (sync_on && ia.sync != nullptr && wg == 0 && chain == 0 && threadIdx.x == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ + e]);
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     const bool writer = (wg == 0 && threadIdx.x == 0);
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     // now (normally it has been there for a whole iteration); the workgroup looks at the result before phase A's loads
     const bool synced = sync_on && ia.sync != nullptr;
     if (synced && threadIdx.x == 0) {
-        const unsigned j = ia.sync[SYNC_MAIN_SEQ];          // this sequence's number (k_z_ob left it)
+        const unsigned j = ia.sync[SYNC_MAIN_SEQ + e];      // this sequence's number (the previous sequence left it)
         s_noise_ok = sync_wait(ia.sync + SYNC_NOISE, j) ? 1 : 0;
     }
     const uint32_t it = ctl.it;

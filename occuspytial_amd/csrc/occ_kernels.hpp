@@ -444,7 +444,9 @@ __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)
 //   sync[SYNC_NOISE]  = j  set by k_gate(j):  k_noise(j-1) is complete    k_iter(j) waits for >= j   (noise of j)
 //   sync[SYNC_ALPHA]  = j+1 set by k_noise(j): k_alpha_draw(j) is complete k_z_ob(j) waits for >= j+1 (alpha of j)
 // Every kernel sets before it waits, so the two streams cannot wait for each other.  Each stream counts its
-// own sequences in a word only it touches (SYNC_MAIN_SEQ: k_z_ob increments; SYNC_SIDE_SEQ: k_noise).
+// own sequences in words only it touches (SYNC_MAIN_SEQ + parity of the sequence: the last kernel of a main-stream
+// sequence writes the word of the NEXT sequence's parity, so no kernel reads a word that is written while it runs;
+// SYNC_SIDE_SEQ: written by k_noise, read by k_gate).
 // Consumers that wait inside a running kernel (k_iter, k_z_ob) read the data with L1-bypassing agent-scope
 // loads; kernels launched after k_gate rely on the kernel boundary.  Waits are bounded.
 enum : int { SYNC_MAIN = 0, SYNC_ALPHA = 16, SYNC_NOISE = 32, SYNC_MAIN_SEQ = 48, SYNC_SIDE_SEQ = 52, SYNC_WORDS = 64 };
@@ -507,7 +509,7 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
         int base, width;
         slice_of(c, i, base, width);
         double qe = c.qdiag[i] * eta_i;
-        for (int k = 0; k < width; ++k) qe += c.sell_val[base + k * 64 + lane] * eta[c.sell_col[base + k * 64 + lane]];
+        for (int k = 0; k < width; ++k) qe = fma(c.sell_val[base + k * 64 + lane], eta[c.sell_col[base + k * 64 + lane]], qe);
         quad[0] = eta_i * qe;
     }
     block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
@@ -1147,6 +1149,54 @@ __global__ void __launch_bounds__(64) k_alpha_draw(OCC_KARGS, int sync_on)
 // (alpha, beta, tau) (base.py:238-239), hand the control word to the next sequence.  Blocks [nb_n, 2 nb_n):
 // omega_b of the NEXT iteration, which needs only beta and eta of this one -- one launch, two independent
 // roles, so the two run concurrently without a second stream.
+// The z update of one site (logit.py:234-252) and the record of one iteration (base.py:238-239): shared by k_z_ob
+// and by the last phase of k_iter (occ_iter.hpp), contractions explicit so that both evaluate the same operations.
+template <int P>
+__device__ __forceinline__ void z_update_site(const Ctx &c, uint64_t key, int chain, int i, uint32_t it, const double (&beta)[P],
+                                              const double (&alpha)[MAXC], double eta_i)
+{
+    const int sidx = c.site_sidx[i];
+    const bool not_surveyed = sidx < 0;
+    if (!not_surveyed && c.obs_site[sidx]) return;  // detection seen: z stays 1 (base.py:116-118)
+    const int n = c.n, Q = c.q;
+    double xb = 0.0;
+#pragma unroll
+    for (int a = 0; a < P; ++a) xb = fma(c.Xt[(size_t)a * n + i], beta[a], xb);
+    const double num1 = expit(xb + eta_i);
+    double pr = num1;
+    if (!not_surveyed) {
+        double prod = 1.0;
+        const int r0 = c.site_ptr[sidx], r1 = c.site_ptr[sidx + 1];
+        for (int r = r0; r < r1; ++r) {
+            double wa = 0.0;
+#pragma unroll
+            for (int a = 0; a < MAXC; ++a)
+                if (a < Q) wa = fma(c.Wt[(size_t)a * c.R + r], -alpha[a], wa);
+            const double ex = expit(wa);
+            prod = (r == r0) ? ex : prod * ex;
+        }
+        const double num = num1 * prod;
+        pr = num / ((1.0 - num1) + num);
+    }
+    const double u = block_uniform(key, (uint32_t)i, 0, it, STREAM_Z);
+    c.z[(size_t)chain * n + i] = (u < pr) ? 1 : 0;
+}
+template <int P>
+__device__ __forceinline__ void record_draws(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, const double (&alpha)[MAXC],
+                                             const double (&beta)[P], double tau)
+{
+    const uint32_t rel = it - sc.it_base;
+    if (c.rec == nullptr || rel < sc.burnin || rel - sc.burnin >= sc.keep) return;
+    const int Q = c.q;
+    double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
+#pragma unroll
+    for (int a = 0; a < MAXC; ++a)
+        if (a < Q) row[a] = alpha[a];
+#pragma unroll
+    for (int a = 0; a < P; ++a) row[Q + a] = beta[a];
+    row[Q + P] = tau;
+}
+
 template <int P>
 __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool synced, unsigned seq)
 {
@@ -1169,7 +1219,8 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
             c.iter_clock[0] = ~0ull;
             c.iter_clock[1] = 0ull;
         }
-        if (chain == chain_base && synced) c.sync[SYNC_MAIN_SEQ] = seq + 1u;  // read next by k_iter, the next kernel of the stream
+        // the next sequence has the other parity: its kernels read the word this sequence's kernels do not
+        if (chain == chain_base && synced) c.sync[SYNC_MAIN_SEQ + (e ^ 1)] = seq + 1u;
     }
     if (skip) return;
     double beta[P];
@@ -1201,45 +1252,10 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
 #pragma unroll
         for (int a = 0; a < MAXC; ++a) alpha[a] = (a < Q) ? sc.alpha[a] : 0.0;
     }
-    if (writer) {
-        const uint32_t rel = it - sc.it_base;
-        if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
-            double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
-#pragma unroll
-            for (int a = 0; a < MAXC; ++a)
-                if (a < Q) row[a] = alpha[a];
-#pragma unroll
-            for (int a = 0; a < P; ++a) row[Q + a] = beta[a];
-            row[Q + P] = sc.tau;
-        }
-    }
+    if (writer) record_draws<P>(c, sc, chain, it, alpha, beta, sc.tau);
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int sidx = c.site_sidx[i];
-    const bool not_surveyed = sidx < 0;
-    if (!not_surveyed && c.obs_site[sidx]) return;  // detection seen: z stays 1 (base.py:116-118)
-    const size_t ci = (size_t)chain * n + i;
-    double xb = 0.0;
-#pragma unroll
-    for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
-    const double num1 = expit(xb + c.eta[ci]);
-    double pr = num1;
-    if (!not_surveyed) {
-        double prod = 1.0;
-        const int r0 = c.site_ptr[sidx], r1 = c.site_ptr[sidx + 1];
-        for (int r = r0; r < r1; ++r) {
-            double wa = 0.0;
-#pragma unroll
-            for (int a = 0; a < MAXC; ++a)
-                if (a < Q) wa += c.Wt[(size_t)a * c.R + r] * (-alpha[a]);
-            const double ex = expit(wa);
-            prod = (r == r0) ? ex : prod * ex;
-        }
-        const double num = num1 * prod;
-        pr = num / ((1.0 - num1) + num);
-    }
-    const double u = block_uniform(sc.key, (uint32_t)i, 0, it, STREAM_Z);
-    c.z[ci] = (u < pr) ? 1 : 0;
+    z_update_site<P>(c, sc.key, chain, i, it, beta, alpha, c.eta[(size_t)chain * n + i]);
 }
 
 template <int P>
