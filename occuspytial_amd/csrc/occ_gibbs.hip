@@ -184,7 +184,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
-        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
+        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_ITER:
             hipLaunchKernelGGL(k_iter, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);

@@ -15,7 +15,7 @@ def short(n):
 ev = [(short(r['Kernel_Name']), int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '')) for r in rows]
 # last 200 iterations: anchor on k_z_ob
 zi = [i for i, e in enumerate(ev) if e[0] == 'k_z_ob']
-zi = zi[-201:]
+zi = zi[-min(201, len(zi)):]
 dur = defaultdict(list); gap_after = defaultdict(list); per_it = []
 for a, b in zip(zi[:-1], zi[1:]):
     seq = ev[a + 1:b + 1]
