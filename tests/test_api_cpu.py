@@ -268,3 +268,36 @@ def test_too_many_covariates_is_an_error(small):
     Xbig = np.hstack([X, np.ones((X.shape[0], 7))])
     with pytest.raises(ValueError, match='at most 8'):
         LogitICARGibbs(Q, W, Xbig, y)
+
+
+def test_distribution_helpers_match_the_reference_functions():
+    """``occuspytial_amd.distributions`` against outputs of the reference's Cython functions (tests/golden/
+    native_helpers.npz, made by calling them with a cloned generator)."""
+    from occuspytial_amd.distributions import ensure_sums_to_zero, precision_mvnorm
+    from .conftest import load_golden
+    g = load_golden('native_helpers')
+
+    class Replay:  # hands out the variates the reference consumed
+        def __init__(self, eps):
+            self.eps = eps
+
+        def standard_normal(self, n):
+            assert n == self.eps.size
+            return self.eps
+
+    import numpy.random as npr
+    real_default_rng = npr.default_rng
+    for d in range(1, 9):
+        prec = np.array(g[f'mvn{d}_prec'], dtype=float)
+        npr.default_rng = lambda rs: rs          # a Generator is passed through unaltered, as numpy does
+        try:
+            draw = precision_mvnorm(g[f'mvn{d}_b'], prec, Replay(g[f'mvn{d}_eps']))
+        finally:
+            npr.default_rng = real_default_rng
+        assert np.allclose(draw, g[f'mvn{d}_draw'], rtol=1e-11, atol=1e-13)
+        assert np.allclose(np.tril(prec), np.tril(g[f'mvn{d}_prec_after']), rtol=1e-12, atol=1e-13)
+    out = np.empty_like(g['proj_x'])
+    ensure_sums_to_zero(g['proj_x'], g['proj_z'], out)
+    assert np.allclose(out, g['proj_out'], rtol=0, atol=1e-14)
+    with pytest.raises(RuntimeError, match='Cholesky factorization/solver failed!'):
+        precision_mvnorm(np.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]), 1)
