@@ -590,6 +590,46 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         }
     }
 
+    // ---- diagonal form, when the off-diagonals lie on at most NPRE diagonals with one value each (lattices) -----
+    std::vector<int> dia_off;
+    std::vector<double> dia_val;
+    std::vector<uint8_t> dia_mask;
+    {
+        std::vector<long long> offs;
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i)
+            for (int k = indptr[i]; k < indptr[i + 1] && ok; ++k) {
+                if (indices[k] == i) continue;
+                const long long d = (long long)indices[k] - i;
+                size_t t = 0;
+                while (t < offs.size() && offs[t] != d) ++t;
+                if (t == offs.size()) {
+                    if (offs.size() == (size_t)NPRE) { ok = false; break; }
+                    offs.push_back(d);
+                    dia_val.push_back(qdata[k]);
+                } else if (dia_val[t] != qdata[k]) ok = false;
+            }
+        if (ok && !offs.empty()) {
+            std::vector<size_t> order(offs.size());
+            for (size_t t = 0; t < order.size(); ++t) order[t] = t;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return offs[a] < offs[b]; });  // CSR column order
+            std::vector<double> v2;
+            for (size_t t : order) { dia_off.push_back((int)offs[t]); v2.push_back(dia_val[t]); }
+            dia_val = v2;
+            dia_mask.assign((size_t)n, 0);
+            for (int i = 0; i < n; ++i)
+                for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+                    if (indices[k] == i) continue;
+                    const int d = indices[k] - i;
+                    for (size_t t = 0; t < dia_off.size(); ++t)
+                        if (dia_off[t] == d) dia_mask[i] |= (uint8_t)(1u << t);
+                }
+        } else {
+            dia_val.clear();
+        }
+    }
+    const uint8_t *dia_mask_dev = nullptr;
+
     // ---- design matrices as structure-of-arrays; ragged visits; index sets (base.py:112-152) -----
     std::vector<double> Xt((size_t)n * p), Wt((size_t)R * q);
     for (int i = 0; i < n; ++i)
@@ -680,6 +720,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if ((rc = upload(s, &c.sell_col, sell_col))) return rc;
     if ((rc = upload(s, &c.sell_val, sell_val))) return rc;
     if ((rc = upload(s, &c.qdiag, qdiag))) return rc;
+    if (!dia_off.empty() && (rc = upload(s, &dia_mask_dev, dia_mask))) return rc;
     if ((rc = upload(s, &c.Xt, Xt))) return rc;
     if ((rc = upload(s, &c.Wt, Wt))) return rc;
     if ((rc = upload(s, &c.yrow, yrow))) return rc;
@@ -743,7 +784,14 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     HIP_TRY(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
     {
         KryArgs &k = s->kry;
-        k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.pad = 0; k.maxiter = c.maxiter;
+        k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.maxiter = c.maxiter;
+        k.dia_n = 0;
+        k.dia_mask = nullptr;
+        if (!dia_off.empty() && !std::getenv("OCC_NO_DIA")) {
+            k.dia_n = (int)dia_off.size();
+            for (size_t d = 0; d < dia_off.size(); ++d) { k.dia_off[d] = dia_off[d]; k.dia_val[d] = dia_val[d]; }
+            k.dia_mask = dia_mask_dev;
+        }
         k.sell_ptr = c.sell_ptr; k.sell_col = c.sell_col; k.sell_val = c.sell_val; k.qdiag = c.qdiag;
         k.omega_b[0] = c.omega_b[0]; k.omega_b[1] = c.omega_b[1];
         for (int b = 0; b < 2; ++b) { k.Gv[b] = c.Gv[b]; k.Wv[b] = c.Wv[b]; }

@@ -821,7 +821,12 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 // Everything k_minres needs to form its addresses, BY VALUE in the kernel argument block: with the
 // pointers in device memory every launch paid one more dependent (cache-cold) load level.
 struct KryArgs {
-    int n, nb_n, ell_w, pad;
+    int n, nb_n, ell_w, dia_n;  // dia_n > 0: the off-diagonals lie on dia_n <= NPRE diagonals with one value each (any
+                                // unweighted lattice): column = row + dia_off[k] where bit k of dia_mask[row] is set --
+                                // one byte per row instead of 12 bytes per stored slot
+    int dia_off[8];
+    double dia_val[8];
+    const uint8_t *dia_mask;
     long long maxiter;
     const int *sell_ptr, *sell_col;
     const double *sell_val, *qdiag;
@@ -860,9 +865,25 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     if (blockDim.x == 64 || threadIdx.x < 64) {
         const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nb_n);
         const int ln = threadIdx.x & 63;
-        for (int b = ln; b < a.nb_n; b += 64) {
+        // four rounds of loads in flight (a plain "load, add" loop waits for every round trip in turn: 15 of them at
+        // 500x500); the sums are accumulated in the same order, rounds past the end add an exact 0
+        for (int b0 = ln; b0 < a.nb_n; b0 += 256) {
+            double v[4][4];
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) S[qi] += part[qi * a.nb_n + b];
+            for (int r = 0; r < 4; ++r) {
+                const int b = b0 + 64 * r;
+                const int bc = min(b, a.nb_n - 1);
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const double t = part[qi * a.nb_n + bc];
+                    v[r][qi] = (b < a.nb_n) ? t : 0.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) S[qi] += v[r][qi];
+            }
         }
     }
     int width = 0, base = 0;
@@ -872,14 +893,25 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     double qd = 0.0, om0 = 0.0, om1 = 0.0;
     if (act) {
         const int slice = i >> 6;
-        if (a.ell_w > 0) { width = a.ell_w; base = slice * a.ell_w * 64; }
-        else { base = a.sell_ptr[slice]; width = (a.sell_ptr[slice + 1] - base) >> 6; }
+        if (a.dia_n > 0) {
+            width = a.dia_n;
+            const unsigned m = a.dia_mask[i];
 #pragma unroll
-        for (int kk = 0; kk < NPRE; ++kk) {
-            col[kk] = i; val[kk] = 0.0;
-            if (kk < width) {
-                col[kk] = a.sell_col[base + kk * 64 + lane];
-                val[kk] = a.sell_val[base + kk * 64 + lane];
+            for (int kk = 0; kk < NPRE; ++kk) {
+                const bool on = kk < width && ((m >> kk) & 1u);
+                col[kk] = on ? i + a.dia_off[kk] : i;
+                val[kk] = on ? a.dia_val[kk] : 0.0;
+            }
+        } else {
+            if (a.ell_w > 0) { width = a.ell_w; base = slice * a.ell_w * 64; }
+            else { base = a.sell_ptr[slice]; width = (a.sell_ptr[slice + 1] - base) >> 6; }
+#pragma unroll
+            for (int kk = 0; kk < NPRE; ++kk) {
+                col[kk] = i; val[kk] = 0.0;
+                if (kk < width) {
+                    col[kk] = a.sell_col[base + kk * 64 + lane];
+                    val[kk] = a.sell_val[base + kk * 64 + lane];
+                }
             }
         }
         qd = a.qdiag[i];
