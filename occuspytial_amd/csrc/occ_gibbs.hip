@@ -43,6 +43,7 @@ struct occ_sampler {
     // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;
     // otherwise one launch per MINRES step on the main stream and omega_a / alpha / noise on the side stream
     bool persistent = false;
+    int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -187,7 +188,8 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_ITER:
-            hipLaunchKernelGGL(k_iter, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            if (s->iter_window == 8) hipLaunchKernelGGL(k_iter<8>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else hipLaunchKernelGGL(k_iter<16>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
     }
@@ -678,8 +680,9 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         s->iter.nbg = nbg;
         // (k_iter's 240 VGPRs allow two of its workgroups per CU: 8 chains at 100x100 run 210 us per iteration that way
         // against 251 us with one launch per MINRES step)
-        const int wg_per_cu = std::getenv("OCC_ITER_WG_PER_CU") ? std::atoi(std::getenv("OCC_ITER_WG_PER_CU")) : 2;
-        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= NPRE && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
+        s->iter_window = wmax <= 8 ? 8 : 16;
+        const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
+        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= 16 && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         if (s->persistent) tpb = 64;
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the

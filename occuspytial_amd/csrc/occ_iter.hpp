@@ -168,6 +168,8 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
         default: { constexpr int D = 8; CALL; } break;                                                     \
     }
 
+// NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU)
+template <int NW>
 __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int sync_on)
 {
     __shared__ int s_flag, s_noise_ok;
@@ -240,9 +242,9 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
     // the site itself with coefficient 0; lanes past the last site read row n-1 and their buffer accesses fall
     // outside the descriptors' range (loads return 0, stores are dropped).
-    int off[NPRE];      // byte offset of neighbour kk in a [n] double2 array
-    double av[NPRE];    // tau * Q_ij
-    double2 nm1[NPRE], nm2[NPRE], ng[NPRE];
+    int off[NW];      // byte offset of neighbour kk in a [n] double2 array
+    double av[NW];    // tau * Q_ij
+    double2 nm1[NW], nm2[NW], ng[NW];
     const int ic = act ? i : n - 1;             // clamped row for plain loads
     const int myoff = act ? i * 16 : n * 16;    // byte offset of this site in the exchange buffers
     int width, base;
@@ -269,9 +271,9 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
     double2 x = X0[ic];
     const double d = tau * a.qdiag[ic] + om;
-    double2 xn[NPRE];
+    double2 xn[NW];
 #pragma unroll
-    for (int kk = 0; kk < NPRE; ++kk) {
+    for (int kk = 0; kk < NW; ++kk) {
         const bool has = act && kk < width;
         const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
         const int jraw = a.sell_col[slot];
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     }
     double ax = d * x.x, az = d * x.y;
 #pragma unroll
-    for (int kk = 0; kk < NPRE; ++kk) {
+    for (int kk = 0; kk < NW; ++kk) {
         ax = fma(av[kk], xn[kk].x, ax);
         az = fma(av[kk], xn[kk].y, az);
     }
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     PHASE_STAMP(0, 3)
     bool failed = s_flag != 0;
 #pragma unroll
-    for (int kk = 0; kk < NPRE; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
+    for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
 
     // ---- phase B: MINRES
     Slot s = {};
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
             const double2 p = (k == 1) ? p0 : kry_form_p(st, g, pm2, pm1);  // p_{k-1}
             double gx = d * p.x, gy = d * p.y;
 #pragma unroll
-            for (int kk = 0; kk < NPRE; ++kk) {
+            for (int kk = 0; kk < NW; ++kk) {
                 const double2 pj = (k == 1) ? ng[kk] : kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
                 gx = fma(av[kk], pj.x, gx);
                 gy = fma(av[kk], pj.y, gy);
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
             for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
         }
 #pragma unroll
-        for (int kk = 0; kk < NPRE; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
         SOLVE_STAMP(7)
         S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
         SOLVE_STAMP(8)

@@ -91,8 +91,8 @@ def test_lockstep_iterations_match_oracle(oracle, case, solve_mode):
     eng = Engine(prob, [KEY])
     if solve_mode == 'launch_per_step':
         assert not eng.stats()['persistent_solve']
-    else:  # rows longer than the register-resident neighbour window keep the launch-per-step solve
-        assert eng.stats()['persistent_solve'] == (case != 'ref_graph300_weighted')
+    else:  # (ref_graph300_weighted has rows of more than 8 off-diagonals: the 16-wide window of k_iter)
+        assert eng.stats()['persistent_solve']
     orc = oracle.OracleSampler(prob, KEY)
     eng.set_start(0, **start)
     orc.set_start(**start)
@@ -233,6 +233,37 @@ def test_every_scheduling_mode_gives_the_same_chains(monkeypatch, env):
         assert np.array_equal(u, v)
 
 
+def test_wide_rows_fused_kernel_is_bit_identical_to_launch_per_step(monkeypatch):
+    """Rows of 9-16 off-diagonals take k_iter's 16-wide neighbour window (one workgroup per CU): same bits as the
+    launch-per-step path, whose k_minres handles the slots past its 8-wide prefetch window in a tail loop."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_graph_problem
+    Q, W, X, y, *_ = make_graph_problem(n=1500, k=8, visits=4, p=2, q=2, random_state=7)
+    assert 8 < np.diff(Q.indptr).max() - 1 <= 16
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY + 3 * c for c in range(3)]
+    starts = [_random_start(prob, 20 + c) for c in range(3)]
+    out = {}
+    for mode in ('persistent', 'launch_per_step'):
+        if mode == 'launch_per_step':
+            monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
+        else:
+            monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
+        eng = Engine(prob, keys)
+        assert eng.stats()['persistent_solve'] == (mode == 'persistent')
+        for c in range(3):
+            eng.set_start(c, **starts[c])
+        rec = eng.run(40, 0)
+        out[mode] = (rec, [(eng.get('eta', c), eng.get('z', c), eng.get('minres_itn', c)) for c in range(3)])
+        eng.close()
+    for u, v in zip(out['persistent'][0], out['launch_per_step'][0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(out['persistent'][1], out['launch_per_step'][1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+
+
 def test_krylov_cap_overflow_is_resumed_exactly(monkeypatch):
     """A captured graph with too few Krylov steps carries the unfinished solve into the next replay
     (same arithmetic, continued), so results equal an unconstrained run bit for bit."""
@@ -314,10 +345,10 @@ def _random_start(prob, seed):
     return dict(alpha=rng.standard_normal(prob.q), beta=rng.standard_normal(prob.p), tau=0.9, eta=eta - eta.mean())
 
 
-def test_irregular_adjacency_with_long_rows_and_unsurveyed_sites(oracle):
+def test_irregular_adjacency_with_long_rows_and_unsurveyed_sites(oracle, solve_mode):
     """BASELINE config 5 in small: irregular areal graph (non-uniform row lengths, some rows longer than
-    the 8-slot prefetch window of k_minres, so the SELL slice table and the tail loop are exercised),
-    10 visits, three covariates each, 5 % of the units never surveyed."""
+    8 off-diagonals: the 16-wide neighbour window of k_iter, or -- launch-per-step -- the SELL slice table and the
+    tail loop of k_minres), 10 visits, three covariates each, 5 % of the units never surveyed."""
     from occuspytial_amd._problem import FlatProblem
     from occuspytial_amd.utils import make_graph_problem
     Q, W, X, y, *_ = make_graph_problem(n=700, k=8, visits=10, p=3, q=3, random_state=2)
