@@ -9,6 +9,7 @@ and scipy are used here and nowhere on the per-iteration path.
 """
 import numpy as np
 from scipy import sparse
+from scipy.linalg import solve_triangular
 
 MAX_COVARIATES = 8  # compile-time limit of the register-resident p x p / q x q accumulators
 
@@ -74,6 +75,42 @@ class FlatProblem:
         self.z0[self.site_id] = self.obs_site
 
         self._set_hyperparams(hparams)
+        self.rsr = None   # set by enable_rsr(): the reduced-rank model of LogitRSRGibbs
+
+    # ---- reduced-rank spatial effects (reference gibbs/logit.py:413-460) --------------------------------
+    def enable_rsr(self, r=0.5, q=None, default_tau_shape=True):
+        """Moran-operator basis ``K`` (n x m) of the reference's ``_configure_rsr``, the reduced precision
+        ``K'QK`` and its eigenfactor ``E`` (``E E' = K'QK``, ``_EtaRSRPosterior.__init__``).  ``q`` fixes the
+        number of columns, else eigenvalues ``>= r`` are kept.  Dense n x n linear algebra on the host, once."""
+        X = self.X
+        chol = np.linalg.cholesky(X.T @ X)
+        zi = solve_triangular(chol, np.eye(self.p), lower=True)
+        XTX_i = solve_triangular(chol, zi, lower=True, trans=1)
+        P = -np.linalg.multi_dot([X, XTX_i, X.T])
+        P[np.diag_indices_from(P)] += 1
+        A = self.Q.copy()
+        A.data = -A.data
+        A.setdiag(0)
+        omega = self.n * (P.T @ A @ P) / A.sum()
+        w, v = np.linalg.eigh(omega)
+        if q:
+            m = int(q)
+        else:
+            if not 0 <= r <= 1:
+                raise ValueError('Threshold value needs to be in [0, 1]')
+            m = int(w[w >= r].size)
+            if not m:
+                raise ValueError('The Moran Operator Matrix of the data has no positive '
+                                 'eigenvalues. Set threshold to a lower value')
+        K = np.ascontiguousarray(v[:, -m:])
+        Qr = np.ascontiguousarray(K.T @ (self.Q @ K))
+        s, u = np.linalg.eigh(Qr)
+        E = np.ascontiguousarray(u * np.sqrt(np.clip(s, 0.0, None)))
+        self.rsr = {'K': K, 'Q': Qr, 'E': E, 'dim': m}
+        if default_tau_shape:
+            self.tau_shape = 0.5 + 0.5 * m          # logit.py:448-451 (only when no hyper-parameters were given)
+            self.hparams['tau_shape'] = self.tau_shape
+        return self.rsr
 
     # ---- plain-array round trip (what a multi-GPU launch broadcasts; see occuspytial_amd.distributed)
     _ARRAY_FIELDS = ('X', 'site_id', 'site_ptr', 'W', 'y', 'obs_site', 'z0', 'a_mu', 'a_prec', 'b_mu', 'b_prec')
@@ -85,6 +122,8 @@ class FlatProblem:
         d['Q_indices'] = np.ascontiguousarray(self.Q.indices, dtype=np.int64)
         d['Q_data'] = np.ascontiguousarray(self.Q.data, dtype=np.float64)
         d['scalars'] = np.array([self.tau_rate, self.tau_shape], dtype=np.float64)
+        if self.rsr is not None:
+            d['rsr_K'], d['rsr_Q'], d['rsr_E'] = self.rsr['K'], self.rsr['Q'], self.rsr['E']
         return d
 
     @classmethod
@@ -108,6 +147,10 @@ class FlatProblem:
         self.not_surveyed = np.flatnonzero(~mask).tolist()
         self.hparams = dict(tau_rate=self.tau_rate, tau_shape=self.tau_shape, a_mu=self.a_mu,
                             a_prec=self.a_prec, b_mu=self.b_mu, b_prec=self.b_prec)
+        self.rsr = None
+        if 'rsr_K' in d:
+            K = np.ascontiguousarray(d['rsr_K'])
+            self.rsr = {'K': K, 'Q': np.ascontiguousarray(d['rsr_Q']), 'E': np.ascontiguousarray(d['rsr_E']), 'dim': K.shape[1]}
         return self
 
     def _set_hyperparams(self, hparams):

@@ -586,6 +586,9 @@ struct orc_sampler {
     uint8_t *exists_site; /* S */
     long minres_itn;
     int have_guess;
+    /* reduced-rank model (LogitRSRGibbs): rdim > 0 */
+    int rdim;
+    double *K, *Qr, *Er, *theta;
 };
 
 static void *dupmem(const void *src, size_t bytes)
@@ -653,6 +656,7 @@ void orc_destroy(orc_sampler *s)
     free(s->b_prec_by_mu); free(s->surveyed_flag); free(s->obs_site); free(s->exists_site);
     free(s->alpha); free(s->beta); free(s->eta); free(s->z); free(s->k); free(s->omega_b);
     free(s->omega_a); free(s->xz); free(s->rhs);
+    free(s->K); free(s->Qr); free(s->Er); free(s->theta);
     free(s);
 }
 
@@ -686,15 +690,118 @@ int orc_update_omega_b(orc_sampler *s)
 /* gibbs/logit.py:206-209:  tau = Generator.gamma(shape, 1/rate) = (1/rate) * standard_gamma(shape) */
 int orc_update_tau(orc_sampler *s)
 {
-    double rate = orc_tau_rate(s->n, s->indptr, s->indices, s->qdata, s->eta, s->tau_rate);
+    double rate;
+    if (s->rdim) { /* fixed.Q is K'QK and state.eta is theta (logit.py:453-455, 206-209) */
+        double quad = 0.0;
+        for (int a = 0; a < s->rdim; ++a) {
+            double t = 0.0;
+            for (int c = 0; c < s->rdim; ++c) t += s->Qr[a * s->rdim + c] * s->theta[c];
+            quad += s->theta[a] * t;
+        }
+        rate = 0.5 * quad + s->tau_rate;
+    } else {
+        rate = orc_tau_rate(s->n, s->indptr, s->indices, s->qdata, s->eta, s->tau_rate);
+    }
     double g = orc_std_gamma_draw(s->key, s->iter, ORC_STREAM_TAU, s->tau_shape);
     s->tau = (1.0 / rate) * g;
     return 0;
 }
 
 /* gibbs/logit.py:211-217 and 73-99 (prior term in edge form, see orc_edge_prior_term) */
+/* ---- reduced-rank model ---------------------------------------------------------------------- */
+int orc_rsr_theta(long n, int r, const double *K, const double *Qr, const double *Er, const double *b,
+                  const double *omega, double tau, const double *eps1, const double *eps2, double *theta)
+{
+    double *prec = (double *)calloc((size_t)r * r, sizeof(double)), *rhs = (double *)calloc((size_t)r, sizeof(double));
+    double st = sqrt(tau);
+    /* prec = K' diag(omega) K + tau Qr (logit.py:334: factor1 factor1' + tau Q);  rhs = K'(b + sqrt(omega) eps1) */
+    for (long i = 0; i < n; ++i) {
+        const double *ki = K + i * r;
+        double v = b[i] + sqrt(omega[i]) * eps1[i];
+        for (int a = 0; a < r; ++a) {
+            rhs[a] += ki[a] * v;
+            double ko = ki[a] * omega[i];
+            for (int c = a; c < r; ++c) prec[a * r + c] += ko * ki[c];
+        }
+    }
+    for (int a = 0; a < r; ++a) {
+        double t = 0.0;
+        for (int j = 0; j < r; ++j) t += Er[a * r + j] * eps2[j];
+        rhs[a] += st * t;
+        for (int c = a; c < r; ++c) prec[a * r + c] += tau * Qr[a * r + c];
+    }
+    /* upper Cholesky prec = U'U in place, then U'y = rhs, U theta = y (the reference calls np.linalg.solve) */
+    int rc = 0;
+    for (int j = 0; j < r && !rc; ++j) {
+        double s = prec[j * r + j];
+        for (int k = 0; k < j; ++k) s -= prec[k * r + j] * prec[k * r + j];
+        if (!(s > 0.0)) { rc = ORC_ERR_CHOLESKY; break; }
+        double ujj = sqrt(s);
+        prec[j * r + j] = ujj;
+        for (int i = j + 1; i < r; ++i) {
+            double t = prec[j * r + i];
+            for (int k = 0; k < j; ++k) t -= prec[k * r + j] * prec[k * r + i];
+            prec[j * r + i] = t / ujj;
+        }
+    }
+    if (!rc) {
+        for (int i = 0; i < r; ++i) {
+            double t = rhs[i];
+            for (int k = 0; k < i; ++k) t -= prec[k * r + i] * theta[k];
+            theta[i] = t / prec[i * r + i];
+        }
+        for (int i = r - 1; i >= 0; --i) {
+            double t = theta[i];
+            for (int k = i + 1; k < r; ++k) t -= prec[i * r + k] * theta[k];
+            theta[i] = t / prec[i * r + i];
+        }
+    }
+    free(prec); free(rhs);
+    return rc;
+}
+
+static void rsr_spatial(orc_sampler *s)
+{
+    for (long i = 0; i < s->n; ++i) {
+        double t = 0.0;
+        for (int a = 0; a < s->rdim; ++a) t += s->K[i * s->rdim + a] * s->theta[a];
+        s->eta[i] = t;
+    }
+}
+
+int orc_set_rsr(orc_sampler *s, int r, const double *K, const double *Qr, const double *Er)
+{
+    if (r < 1) return -1;
+    s->rdim = r;
+    s->K = dupmem(K, sizeof(double) * (size_t)(s->n * r));
+    s->Qr = dupmem(Qr, sizeof(double) * (size_t)r * r);
+    s->Er = dupmem(Er, sizeof(double) * (size_t)r * r);
+    s->theta = calloc((size_t)r, sizeof(double));
+    return 0;
+}
+
+/* logit.py:465-485: b = K'(k - omega X beta), theta from the reduced system, spatial = K theta */
+static int update_eta_rsr(orc_sampler *s)
+{
+    long n = s->n;
+    int r = s->rdim;
+    double *b = (double *)malloc(sizeof(double) * (size_t)n), *e1 = (double *)malloc(sizeof(double) * (size_t)n);
+    double *e2 = (double *)malloc(sizeof(double) * (size_t)r);
+    for (long i = 0; i < n; ++i) {
+        b[i] = s->k[i] - s->omega_b[i] * xdot(s, i, s->beta);
+        e1[i] = orc_block_normal(s->key, (uint32_t)i, 0, s->iter, ORC_STREAM_ETA_SITE);
+    }
+    for (int j = 0; j < r; ++j) e2[j] = orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_RSR);
+    int rc = orc_rsr_theta(n, r, s->K, s->Qr, s->Er, b, s->omega_b, s->tau, e1, e2, s->theta);
+    free(b); free(e1); free(e2);
+    if (rc) return rc;
+    rsr_spatial(s);
+    return 0;
+}
+
 int orc_update_eta(orc_sampler *s)
 {
+    if (s->rdim) return update_eta_rsr(s);
     long n = s->n;
     double *u = (double *)malloc(sizeof(double) * (size_t)n);
     orc_edge_prior_term(n, s->indptr, s->indices, s->qdata, s->key, s->iter, u);
@@ -824,6 +931,7 @@ long orc_get(orc_sampler *s, const char *name, double *out, long cap)
     if (!strcmp(name, "beta")) return copy_out(s->beta, s->p, out, cap);
     if (!strcmp(name, "tau")) return copy_out(&s->tau, 1, out, cap);
     if (!strcmp(name, "eta")) return copy_out(s->eta, s->n, out, cap);
+    if (!strcmp(name, "theta")) return s->rdim ? copy_out(s->theta, s->rdim, out, cap) : -1;
     if (!strcmp(name, "z")) return copy_out(s->z, s->n, out, cap);
     if (!strcmp(name, "k")) return copy_out(s->k, s->n, out, cap);
     if (!strcmp(name, "omega_b")) return copy_out(s->omega_b, s->n, out, cap);
@@ -857,6 +965,11 @@ int orc_set(orc_sampler *s, const char *name, const double *in, long len)
     } else if (!strcmp(name, "iter")) {
         if (len != 1) return -1;
         s->iter = (uint32_t)in[0];
+        return 0;
+    } else if (!strcmp(name, "theta")) { /* RSR: eta follows as K theta (logit.py:459, 485) */
+        if (!s->rdim || len != s->rdim) return -1;
+        memcpy(s->theta, in, sizeof(double) * (size_t)len);
+        rsr_spatial(s);
         return 0;
     } else return -1;
     if (len != want) return -1;

@@ -34,7 +34,8 @@ enum {
     ORC_STREAM_BETA = 5,
     ORC_STREAM_OMEGA_A = 6,
     ORC_STREAM_ALPHA = 7,
-    ORC_STREAM_Z = 8
+    ORC_STREAM_Z = 8,
+    ORC_STREAM_RSR = 9 /* standard normals of the reduced-rank (RSR) prior term: c0 = basis column */
 };
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -108,4 +109,13 @@ int orc_set(orc_sampler *s, const char *name, const double *in, long len);
 #ifdef __cplusplus
 }
 #endif
+/* ---- reduced-rank spatial effects (LogitRSRGibbs, gibbs/logit.py:269-485) ----------------------------
+ * theta ~ N(prec^-1 r, prec^-1), prec = K' diag(omega) K + tau Qr, r = K' b + K'(sqrt(omega) eps1) + sqrt(tau) Er eps2
+ * (logit.py:325-337; Er = eigenfactor of Qr, Er Er' = Qr).  K is n x r row-major.  Returns 0 or ORC_ERR_CHOLESKY. */
+int orc_rsr_theta(long n, int r, const double *K, const double *Qr, const double *Er, const double *b,
+                  const double *omega, double tau, const double *eps1, const double *eps2, double *theta);
+/* switch a sampler to the RSR model: eta becomes K theta, tau's rate 1/2 theta' Qr theta (logit.py:206-209 with
+ * fixed.Q = K'QK, logit.py:453-455); state names "theta" (r) and "eta" (= spatial, n). */
+int orc_set_rsr(orc_sampler *s, int r, const double *K, const double *Qr, const double *Er);
+
 #endif

@@ -72,6 +72,10 @@ def lib():
             f = getattr(L, name)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_int
+        L.orc_rsr_theta.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]
+        L.orc_rsr_theta.restype = C.c_int
+        L.orc_set_rsr.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.orc_set_rsr.restype = C.c_int
         L.orc_run.argtypes = [C.c_void_p, C.c_long, C.c_long, _dp, _dp, _dp]
         L.orc_run.restype = C.c_int
         L.orc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
@@ -163,6 +167,17 @@ def z_prob(xrow, beta, eta_i, Wrows, alpha):
                             float(eta_i), Wrows.shape[0], Wrows, np.ascontiguousarray(alpha))
 
 
+def rsr_theta(K, Qr, Er, b, omega, tau, eps1, eps2):
+    """theta of the reduced-rank conditional from injected standard normals (orc_rsr_theta)."""
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    n, r = K.shape
+    theta = np.zeros(r)
+    code = lib().orc_rsr_theta(n, r, K, np.ascontiguousarray(Qr, dtype=np.float64), np.ascontiguousarray(Er, dtype=np.float64),
+                               np.ascontiguousarray(b, dtype=np.float64), np.ascontiguousarray(omega, dtype=np.float64), float(tau),
+                               np.ascontiguousarray(eps1, dtype=np.float64), np.ascontiguousarray(eps2, dtype=np.float64), theta)
+    return theta, code
+
+
 def edge_prior_term(Q, key, it):
     ip, ix, d = _csr(Q)
     u = np.empty(Q.shape[0])
@@ -181,6 +196,10 @@ class OracleSampler:
                                    prob.site_ptr, prob.W, prob.y, prob.a_mu, prob.a_prec, prob.b_mu,
                                    prob.b_prec, prob.tau_rate, prob.tau_shape, int(key))
         self.key = int(key)
+        self.rsr = getattr(prob, 'rsr', None)
+        if self.rsr is not None:   # LogitRSRGibbs: eta = K theta
+            if lib().orc_set_rsr(self._h, int(self.rsr['dim']), self.rsr['K'], self.rsr['Q'], self.rsr['E']):
+                raise ValueError('bad reduced-rank basis')
 
     def __del__(self):
         if getattr(self, '_h', None):
@@ -193,9 +212,15 @@ class OracleSampler:
             raise RuntimeError(_ERRORS.get(code, f'oracle error {code}'))
 
     def set_start(self, alpha, beta, tau, eta):
+        """``eta``: the n spatial effects, or -- reduced-rank model -- the coefficients theta of the basis."""
+        eta = np.ascontiguousarray(eta, dtype=np.float64)
+        theta = None
+        if self.rsr is not None:
+            theta, eta = eta, np.zeros(self.prob.n)
         lib().orc_set_start(self._h, np.ascontiguousarray(alpha, dtype=np.float64),
-                            np.ascontiguousarray(beta, dtype=np.float64), float(tau),
-                            np.ascontiguousarray(eta, dtype=np.float64))
+                            np.ascontiguousarray(beta, dtype=np.float64), float(tau), eta)
+        if theta is not None:
+            self.set('theta', theta)
 
     def update(self, name):
         self._check(getattr(lib(), 'orc_update_' + name)(self._h))

@@ -230,6 +230,68 @@ def capture_case(name, Q, W, X, y, seed, hparams=None, iters=3):
     print(name, 'n =', n, 'minres its', [int(out[f'it{i}_eta_itn']) for i in range(iters)])
 
 
+def capture_rsr_case(name, Q, W, X, y, seed, iters=3, **rsr_kw):
+    """LogitRSRGibbs (reference gibbs/logit.py:269-485): the Moran basis K, the reduced precision K'QK, and per
+    iteration the inputs, the standard normals and the output of the theta conditional -- the only conditional
+    that differs from the ICAR sampler -- plus tau, beta, z, which read theta / spatial = K theta."""
+    import polyagamma as pg_shim
+    from occuspytial.gibbs.logit import LogitRSRGibbs
+
+    out = {}
+    Qc = sparse.csr_matrix(Q).astype(float)
+    Qc.sort_indices()
+    n, p = X.shape
+    q = next(iter(W.values())).shape[1]
+    sites, visits, Wf, yf = flatten(W, y, q)
+    out.update(Q_indptr=Qc.indptr.astype(np.int64), Q_indices=Qc.indices.astype(np.int64), Q_data=Qc.data,
+               X=X, sites=sites, visits=visits, W_flat=Wf, y_flat=yf, seed=np.int64(seed))
+    s = LogitRSRGibbs(Q, W, X, y, random_state=seed, **rsr_kw)
+    f = s.fixed
+    post = s.dists.eta_posterior
+    r = int(f.q)
+    out.update(rsr_dim=np.int64(r), rsr_K=np.asarray(f.K), rsr_Q=np.asarray(f.Q), rsr_eigen=np.asarray(post._eigen),
+               cfg_tau_rate=np.float64(f.tau_rate), cfg_tau_shape=np.float64(f.tau_shape),
+               cfg_a_mu=f.a_mu, cfg_a_prec=f.a_prec, cfg_b_mu=f.b_mu, cfg_b_prec=f.b_prec)
+    assert np.allclose(post._eigen @ post._eigen.T, f.Q, atol=1e-8)
+    s._initialize_posterior_state(None)
+    st = s.state
+    out.update(start_tau=np.float64(st.tau), start_eta=st.eta.copy(), start_alpha=st.alpha.copy(),
+               start_beta=st.beta.copy(), start_spatial=st.spatial.copy())
+    for it in range(iters):
+        t = f'it{it}_'
+        pg_shim.calls.clear()
+        out[t + 'ob_beta'], out[t + 'ob_spatial'] = st.beta.copy(), st.spatial.copy()
+        s._update_omega_b()
+        out[t + 'ob_arg'], out[t + 'omega_b'] = pg_shim.calls[0]
+        c = clone_rng(s.rng)
+        out[t + 'tau_theta'] = st.eta.copy()
+        s._update_tau()
+        out[t + 'tau_g'], out[t + 'tau'] = np.float64(c.standard_gamma(f.tau_shape)), np.float64(st.tau)
+        c = clone_rng(s.rng)
+        out[t + 'eta_k'], out[t + 'eta_beta'] = st.k.copy(), st.beta.copy()
+        s._update_eta()
+        out[t + 'eta_eps'] = c.standard_normal(r + n)      # [:r] -> eigenfactor of K'QK, [r:] -> K' sqrt(omega)
+        out[t + 'theta'], out[t + 'spatial'] = st.eta.copy(), st.spatial.copy()
+        c = clone_rng(s.rng)
+        out[t + 'beta_k'] = st.k.copy()
+        s._update_beta()
+        out[t + 'beta_eps'] = c.standard_normal(p)
+        out[t + 'beta'] = st.beta.copy()
+        pg_shim.calls.clear()
+        s._update_omega_a()
+        out[t + 'omega_a'] = pg_shim.calls[0][1]
+        s._update_alpha()
+        out[t + 'alpha'] = st.alpha.copy()
+        c = clone_rng(s.rng)
+        s._update_z()
+        out[t + 'z_u_no'] = c.uniform(size=f.n_no)
+        out[t + 'z'] = st.z.copy()
+    res = LogitRSRGibbs(Q, W, X, y, random_state=seed, **rsr_kw).sample(5, chains=1, progressbar=False)
+    out['api_alpha_shape'] = np.array(res['alpha'].shape)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'n =', n, 'basis columns =', r)
+
+
 def capture_native_helpers():
     """precision_mvnorm / ensure_sums_to_zero (reference distributions.pyx:24-110) known answers."""
     from occuspytial.distributions import ensure_sums_to_zero, precision_mvnorm
@@ -302,6 +364,10 @@ def main():
     capture_case('ref_graph300_weighted', Qw, Wg, Xg, yg, seed=21)
 
     capture_native_helpers()
+
+    # case D: the reduced-rank sampler (LogitRSRGibbs) on the 150-site problem, default threshold and q = 10
+    capture_rsr_case('ref_rsr150_r05', Q, W, X, y, seed=10)
+    capture_rsr_case('ref_rsr150_q10', Q, W, X, y, seed=10, q=10, iters=2)
 
 
 if __name__ == '__main__':

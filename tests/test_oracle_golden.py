@@ -170,3 +170,40 @@ def test_native_helpers(oracle):
 def test_cholesky_failure_is_reported(oracle):
     _, _, st = oracle.precision_mvnorm(np.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]), np.zeros(2))
     assert st == 2
+
+
+@pytest.mark.parametrize('case', ['ref_rsr150_r05', 'ref_rsr150_q10'])
+def test_reduced_rank_theta_conditional_matches_the_reference(oracle, case):
+    """LogitRSRGibbs (reference gibbs/logit.py:269-485): the oracle's theta conditional fed the standard normals
+    the reference consumed reproduces its theta and spatial = K theta; tau's rate uses theta' K'QK theta; the
+    host's Moran basis spans the reference's (eigenvectors are unique up to sign / rotation inside clusters)."""
+    from occuspytial_amd._problem import FlatProblem
+    g = load_golden(case)
+    n = g['X'].shape[0]
+    r = int(g['rsr_dim'])
+    K, Qr, E = g['rsr_K'], g['rsr_Q'], g['rsr_eigen']
+    assert np.allclose(E @ E.T, Qr, atol=1e-9)
+    it = 0
+    while f'it{it}_theta' in g:
+        t = f'it{it}_'
+        b = g[t + 'eta_k'] - g[t + 'omega_b'] * (g['X'] @ g[t + 'eta_beta'])
+        eps = g[t + 'eta_eps']
+        theta, code = oracle.rsr_theta(K, Qr, E, b, g[t + 'omega_b'], float(g[t + 'tau']), eps[r:], eps[:r])
+        assert code == 0
+        assert np.allclose(theta, g[t + 'theta'], rtol=1e-9, atol=1e-11)
+        assert np.allclose(K @ theta, g[t + 'spatial'], rtol=1e-9, atol=1e-11)
+        rate = 0.5 * g[t + 'tau_theta'] @ Qr @ g[t + 'tau_theta'] + float(g['cfg_tau_rate'])
+        assert np.isclose((1.0 / rate) * float(g[t + 'tau_g']), float(g[t + 'tau']), rtol=1e-13)
+        it += 1
+    assert it >= 2
+    # the host's own basis (FlatProblem.enable_rsr follows _configure_rsr) against the reference's
+    Q = sparse.csr_matrix((g['Q_data'], g['Q_indices'], g['Q_indptr']), shape=(n, n))
+    W, y, cur = {}, {}, 0
+    for s, v in zip(g['sites'], g['visits']):
+        W[int(s)], y[int(s)] = g['W_flat'][cur:cur + v], g['y_flat'][cur:cur + v]
+        cur += v
+    prob = FlatProblem(Q, W, g['X'], y)
+    mine = prob.enable_rsr(q=r) if case.endswith('q10') else prob.enable_rsr()
+    assert mine['dim'] == r and prob.tau_shape == float(g['cfg_tau_shape'])
+    assert np.allclose(mine['K'] @ mine['K'].T, K @ K.T, atol=1e-8)       # same column space
+    assert np.allclose(mine['E'] @ mine['E'].T, mine['Q'], atol=1e-9)
