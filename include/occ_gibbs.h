@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 1
+#define OCC_ABI_VERSION 2
 #define OCC_MAX_COVARIATES 8 /* p and q limit (register-resident p x p accumulators) */
 
 enum {
@@ -60,6 +60,11 @@ typedef struct occ_problem {
     const double *a_mu, *a_prec; /* q, q x q    base.py:49-61,177-186 */
     const double *b_mu, *b_prec; /* p, p x p */
     double tau_rate, tau_shape;
+    /* Reduced-rank model (LogitRSRGibbs, logit.py:269-485), optional: rsr_dim = m > 0 selects it.  The spatial
+     * effects are eta = K theta with K the n x m Moran-operator basis the host computed (logit.py:413-446);
+     * rsr_Q = K'QK (m x m), rsr_E its eigenfactor, E E' = K'QK (logit.py:321-323); all row-major; m <= 128. */
+    int32_t rsr_dim;
+    const double *rsr_K, *rsr_Q, *rsr_E;
 } occ_problem;
 
 typedef struct occ_sampler occ_sampler;
@@ -77,7 +82,7 @@ int occ_set_keys(occ_sampler *s, const uint64_t *keys);
 
 /* Starting values of one chain: base.py:188-197 (`start` dict) / 199-212 (default start, drawn by
  * the host with numpy exactly as the reference does).  Resets the chain's iteration counter and the
- * MINRES warm start (logit.py:71). */
+ * MINRES warm start (logit.py:71).  Reduced-rank model: `eta` points at the m coefficients theta (logit.py:457-460). */
 int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const double *beta, double tau,
                   const double *eta);
 
@@ -95,9 +100,9 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
 
 /* State of one chain by name (reference attribute names, base.py:65-82 / logit.py):
  *   alpha(q) beta(p) tau(1) eta(n) z(n) k(n) omega_b(n) omega_a(R) exists(S) xz(2n) rhs(n)
- *   minres_itn(1) iter(1)
+ *   minres_itn(1) iter(1); reduced-rank model: theta(m), and eta is K theta (the reference's `spatial`)
  * occ_get_state copies into out (capacity cap doubles) and stores the length in *len.
- * occ_set_state accepts alpha beta tau eta z omega_a xz iter (omega_b of the coming iteration is then
+ * occ_set_state accepts alpha beta tau eta z omega_a xz iter theta (theta also sets eta = K theta) (omega_b of the coming iteration is then
  * redrawn from the new state). */
 int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len);
 int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double *in, int64_t len);

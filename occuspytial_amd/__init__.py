@@ -5,8 +5,8 @@ posterior API, the per-iteration work done by hand-written HIP kernels for gfx95
 (``include/occ_gibbs.h``).  See DESIGN.md.
 """
 from .data import Data
-from .gibbs import LogitICARGibbs
+from .gibbs import LogitICARGibbs, LogitRSRGibbs
 
 __version__ = '0.2.0'
 
-__all__ = ('LogitICARGibbs', 'Data', '__version__')
+__all__ = ('LogitICARGibbs', 'LogitRSRGibbs', 'Data', '__version__')

@@ -35,6 +35,10 @@ class Engine:
             X=_ptr(prob.X), site_id=_ptr(k['site_id']), site_ptr=_ptr(k['site_ptr']),
             W=_ptr(prob.W), y=_ptr(prob.y), a_mu=_ptr(prob.a_mu), a_prec=_ptr(prob.a_prec),
             b_mu=_ptr(prob.b_mu), b_prec=_ptr(prob.b_prec), tau_rate=prob.tau_rate, tau_shape=prob.tau_shape)
+        self.rsr = getattr(prob, 'rsr', None)
+        if self.rsr is not None:   # LogitRSRGibbs: eta = K theta
+            pb.rsr_dim = int(self.rsr['dim'])
+            pb.rsr_K, pb.rsr_Q, pb.rsr_E = _ptr(self.rsr['K']), _ptr(self.rsr['Q']), _ptr(self.rsr['E'])
         karr = (C.c_uint64 * self.n_chains)(*[int(v) & (2 ** 64 - 1) for v in keys])
         h = C.c_void_p()
         code = lib.occ_create(C.byref(pb), self.n_chains, karr, int(device), C.byref(h))
@@ -76,7 +80,8 @@ class Engine:
         out = {'n_chains': np.int64(self.n_chains), 'keys': np.array(self.keys, dtype=np.uint64),
                'iter': np.array([int(self.get('iter', c)) for c in range(self.n_chains)], dtype=np.int64),
                'shape': np.array([self.prob.n, self.prob.p, self.prob.q, self.prob.R], dtype=np.int64)}
-        for name in self.CHECKPOINT_FIELDS:
+        fields = self.CHECKPOINT_FIELDS if self.rsr is None else ('alpha', 'beta', 'tau', 'theta', 'z')
+        for name in fields:
             out[name] = np.stack([np.atleast_1d(self.get(name, c)) for c in range(self.n_chains)])
         return out
 
@@ -87,17 +92,20 @@ class Engine:
         if list(np.asarray(ckpt['shape'])) != [self.prob.n, self.prob.p, self.prob.q, self.prob.R]:
             raise ValueError('checkpoint belongs to a problem of different size')
         self.set_keys([int(k) for k in np.asarray(ckpt['keys'])])
+        spatial = 'eta' if self.rsr is None else 'theta'   # reduced-rank model: the coefficients; eta = K theta follows
         for c in range(self.n_chains):
-            self.set_start(c, ckpt['alpha'][c], ckpt['beta'][c], float(np.asarray(ckpt['tau'][c]).ravel()[0]), ckpt['eta'][c])
+            self.set_start(c, ckpt['alpha'][c], ckpt['beta'][c], float(np.asarray(ckpt['tau'][c]).ravel()[0]), ckpt[spatial][c])
             self.set('z', ckpt['z'][c], c)
-            self.set('xz', ckpt['xz'][c], c)
+            if self.rsr is None:
+                self.set('xz', ckpt['xz'][c], c)
             self.set('iter', float(ckpt['iter'][c]), c)
 
     def set_start(self, chain, alpha, beta, tau, eta):
         a = np.ascontiguousarray(alpha, dtype=np.float64)
         b = np.ascontiguousarray(beta, dtype=np.float64)
         e = np.ascontiguousarray(eta, dtype=np.float64)
-        if a.shape != (self.prob.q,) or b.shape != (self.prob.p,) or e.shape != (self.prob.n,):
+        n_eta = self.prob.n if self.rsr is None else int(self.rsr['dim'])   # reduced-rank model: eta is theta
+        if a.shape != (self.prob.q,) or b.shape != (self.prob.p,) or e.shape != (n_eta,):
             raise ValueError('start values have the wrong shape')
         self._check(self._lib.occ_set_start(self._h, chain, _ptr(a), _ptr(b), float(tau), _ptr(e)))
 

@@ -25,6 +25,7 @@ class OccProblem(C.Structure):
         ('W', C.c_void_p), ('y', C.c_void_p),
         ('a_mu', C.c_void_p), ('a_prec', C.c_void_p), ('b_mu', C.c_void_p), ('b_prec', C.c_void_p),
         ('tau_rate', C.c_double), ('tau_shape', C.c_double),
+        ('rsr_dim', C.c_int32), ('rsr_K', C.c_void_p), ('rsr_Q', C.c_void_p), ('rsr_E', C.c_void_p),
     ]
 
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "occ_iter.hpp"
+#include "occ_rsr.hpp"
 
 using namespace occ;
 
@@ -22,7 +23,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER, K_GATE /* internal: not a profiled kind */ };
+enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER, K_GATE /* internal: not a profiled kind */,
+            K_RSR_RHS, K_RSR_GRAM, K_RSR_SOLVE, K_RSR_SPATIAL, K_RSR_BETA_PARTIAL /* reduced-rank model */ };
 static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
@@ -40,6 +42,9 @@ struct occ_sampler {
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
     IterArgs iter{};         // ... and of k_iter
+    // reduced-rank model (LogitRSRGibbs): rsr.m > 0.  One stream, one linear graph of two iterations.
+    RsrArgs rsr{};
+    std::vector<double> rsr_K_host;  // n x m, for theta -> eta on the host (start values, set_state)
     // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;
     // otherwise one launch per MINRES step on the main stream and omega_a / alpha / noise on the side stream
     bool persistent = false;
@@ -157,6 +162,7 @@ KernelEI pick_beta_partial(int p)
 #define OCC_PICK_P(NAME, p) \
     ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
+KernelE pick_beta_partial_rsr(int p) { return OCC_PICK_P(k_beta_partial_rsr, p); }
 KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {
@@ -187,6 +193,17 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
+        case K_RSR_RHS: hipLaunchKernelGGL(k_rsr_rhs, dim3((unsigned)((s->rsr.m + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
+        case K_RSR_GRAM: {
+            const int T = (s->rsr.m + 15) / 16;
+            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)(T * (T + 1) / 2), (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
+            break;
+        }
+        case K_RSR_SOLVE:
+            hipLaunchKernelGGL(k_rsr_solve, dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * ((size_t)s->rsr.m * s->rsr.m + 4 * s->rsr.m), st, s->rsr, e);
+            break;
+        case K_RSR_SPATIAL: hipLaunchKernelGGL(k_rsr_spatial, dim3((unsigned)((c.n + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
+        case K_RSR_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial_rsr(c.p), gs, blk, 0, st, OCC_ARGS); break;
         case K_ITER:
             if (s->iter_window == 8) hipLaunchKernelGGL(k_iter<8>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             else hipLaunchKernelGGL(k_iter<16>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
@@ -256,12 +273,33 @@ int eager_krylov(occ_sampler *s, int k_from, int *k_last)
 // One launch sequence on the main stream only, every kernel in a valid topological order of the DAG
 // (the reference's own order of conditionals, logit.py:254-266, with omega_a/alpha moved up front --
 // their inputs are last iteration's alpha and z).
+// One iteration of the reduced-rank model on one stream, the reference's order (omega_a / alpha moved up front as
+// everywhere; their inputs are last iteration's alpha and z).
+void launch_rsr_sequence(occ_sampler *s, hipStream_t st, int e)
+{
+    launch_kind(s, st, K_OMEGA_A, e);
+    launch_kind(s, st, K_ALPHA_DRAW, e);
+    launch_kind(s, st, K_NOISE, e, 1);
+    launch_kind(s, st, K_RSR_RHS, e);
+    launch_kind(s, st, K_RSR_GRAM, e);
+    launch_kind(s, st, K_RSR_SOLVE, e);
+    launch_kind(s, st, K_RSR_SPATIAL, e);
+    launch_kind(s, st, K_RSR_BETA_PARTIAL, e);
+    launch_kind(s, st, K_Z_OB, e);
+}
+
 int eager_sequence(occ_sampler *s)
 {
     if (s->need_prologue) launch_prologue(s);
     const int e = s->parity;
     // one stream, reference order: stream order is the synchronisation, the hand-over counters stay untouched
     struct NoSync { occ_sampler *s; bool old; explicit NoSync(occ_sampler *p) : s(p), old(p->launch_sync) { s->launch_sync = false; } ~NoSync() { s->launch_sync = old; } } no_sync(s);
+    if (s->rsr.m > 0) {  // reduced-rank model: the theta conditional stands where the ICAR solve is
+        launch_rsr_sequence(s, s->stream, e);
+        s->parity ^= 1;
+        s->eager_iterations += 1;
+        return OCC_OK;
+    }
     launch_kind(s, s->stream, K_OMEGA_A, e);
     launch_kind(s, s->stream, K_ALPHA_DRAW, e);
     launch_kind(s, s->stream, K_NOISE, e, 1);
@@ -328,6 +366,18 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
     int rc;
+    if (s->rsr.m > 0) {  // reduced-rank model: two iterations (both parities) on the main stream
+        const bool old_sync = s->launch_sync;
+        s->launch_sync = false;
+        HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        for (int t = 0; t < 2; ++t) launch_rsr_sequence(s, s->stream, s->parity ^ t);
+        HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
+        s->launch_sync = old_sync;
+        HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
+        s->graph_parity = s->parity;
+        s->krylov_cap = 0;
+        return OCC_OK;
+    }
     if (s->flag_sync) {
         // two sequences (both parities) per graph and stream, no event nodes: the kernels hand over through
         // the device counters of Ctx::sync
@@ -408,6 +458,10 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
+    if (s->rsr.m > 0) {  // two sequences
+        HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
+        return OCC_OK;
+    }
     if (s->flag_sync) {  // two sequences on each stream
         HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
@@ -491,6 +545,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         return set_error(s, OCC_E_BADARG, "problem sizes out of range");
     if (pb->p < 1 || pb->p > OCC_MAX_COVARIATES || pb->q < 1 || pb->q > OCC_MAX_COVARIATES)
         return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 8]");
+    if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_MAX_DIM || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
+        return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 128 columns (rsr_K, rsr_Q, rsr_E)");
     if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -682,7 +738,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         // against 251 us with one launch per MINRES step)
         s->iter_window = wmax <= 8 ? 8 : 16;
         const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
-        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && wmax <= 16 && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
+        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16 &&
+                        (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         if (s->persistent) tpb = 64;
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
@@ -811,6 +868,33 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         t.tau_rate = c.tau_rate; t.tau_shape = c.tau_shape;
         t.C = c.C; t.p = c.p; t.q = c.q;
     }
+    if (pb->rsr_dim > 0) {  // reduced-rank model
+        const int m = pb->rsr_dim;
+        std::vector<double> Kh, Qh, Eh;
+        if ((rc = fetch(s, Kh, pb->rsr_K, (size_t)n * m))) return rc;
+        if ((rc = fetch(s, Qh, pb->rsr_Q, (size_t)m * m))) return rc;
+        if ((rc = fetch(s, Eh, pb->rsr_E, (size_t)m * m))) return rc;
+        std::vector<double> Kth((size_t)m * n);
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < m; ++a) Kth[(size_t)a * n + i] = Kh[(size_t)i * m + a];
+        RsrArgs &r = s->rsr;
+        r.n = n; r.m = m; r.p = p; r.C = C;
+        if ((rc = upload(s, &r.K, Kh))) return rc;
+        if ((rc = upload(s, &r.Kt, Kth))) return rc;
+        if ((rc = upload(s, &r.Qr, Qh))) return rc;
+        if ((rc = upload(s, &r.E, Eh))) return rc;
+        r.Xt = c.Xt; r.z = c.z;
+        for (int b = 0; b < 2; ++b) { r.omega_b[b] = c.omega_b[b]; r.enorm[b] = c.enorm[b]; }
+        if ((rc = dev_alloc(s, &r.theta, (size_t)C * m))) return rc;
+        if ((rc = dev_alloc(s, &r.gram, (size_t)C * m * m))) return rc;
+        if ((rc = dev_alloc(s, &r.rhs, (size_t)C * m))) return rc;
+        r.eta = c.eta;
+        r.tau_rate = c.tau_rate; r.tau_shape = c.tau_shape;
+        r.scs = c.sc;
+        s->rsr_K_host = Kh;
+        HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(double) * ((size_t)m * m + 4 * m))));
+    }
     HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
     return OCC_OK;
@@ -829,6 +913,24 @@ int occ_create(const occ_problem *problem, int32_t n_chains, const uint64_t *key
         return rc;
     }
     *out = s;
+    return OCC_OK;
+}
+
+// theta of one chain (caller pointer), and eta = K theta computed on the host (set-up path only)
+static int set_theta(occ_sampler *s, int chain, const double *theta_in)
+{
+    const int n = s->ctx.n, m = s->rsr.m;
+    std::vector<double> th;
+    int rc = fetch(s, th, theta_in, (size_t)m);
+    if (rc) return rc;
+    std::vector<double> eta((size_t)n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double t = 0.0;
+        for (int a = 0; a < m; ++a) t = std::fma(s->rsr_K_host[(size_t)i * m + a], th[a], t);
+        eta[i] = t;
+    }
+    HIP_TRY(hipMemcpy(s->rsr.theta + (size_t)chain * m, th.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->ctx.eta + (size_t)chain * n, eta.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     return OCC_OK;
 }
 
@@ -854,7 +956,11 @@ int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const doub
     sc.ctl[0] = sc.ctl[1] = sc.mid[0] = sc.mid[1] = fresh;
     sc.it_stop = 0; sc.it_base = 0; sc.burnin = 0; sc.keep = 0; sc.err = 0;
     if ((rc = write_scalars(s, h))) return rc;
-    HIP_TRY(hipMemcpy(c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
+    if (s->rsr.m > 0) {  // `eta` holds theta; the spatial effects follow (logit.py:457-460)
+        if ((rc = set_theta(s, chain, eta))) return rc;
+    } else {
+        HIP_TRY(hipMemcpy(c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
+    }
     HIP_TRY(hipMemset(c.Xv + (size_t)chain * c.n, 0, sizeof(double2) * c.n));  // x0 = None (logit.py:71)
     s->need_prologue = true;
     return OCC_OK;
@@ -929,7 +1035,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     } else if (s->persistent && !s->flag_sync) {
         if (!s->head[0] && (rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
         if (s->need_prologue) launch_prologue(s);
-    } else if (s->flag_sync) {
+    } else if (s->flag_sync || s->rsr.m > 0) {
         if (s->need_prologue) launch_prologue(s);
         // the solve is one launch: nothing to calibrate.  The captured pair of iterations starts with one
         // sequence parity: an odd number of stepped iterations since the capture is realigned by one more step.
@@ -938,7 +1044,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
             done_min = 1;
         }
         if (!s->head[0] && n_iter > 1 && (rc = build_graph(s, 0))) return rc;
-        if (n_iter == 1) {
+        if (n_iter == 1 && done_min == 0) {
             if ((rc = eager_sequence(s))) return rc;
             done_min = 1;
         }
@@ -957,8 +1063,8 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         launch_prologue(s);
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
-    if (done_min < n_iter && s->side_enabled && !s->flag_sync) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
-    const int64_t seq_per_enqueue = s->flag_sync ? 2 : 1;
+    if (done_min < n_iter && s->side_enabled && !s->flag_sync && s->rsr.m == 0) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+    const int64_t seq_per_enqueue = (s->flag_sync || s->rsr.m > 0) ? 2 : 1;
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
@@ -993,7 +1099,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         }
         // re-size the captured solve from the solves since the last decision: mean + 2.5 sd
         const unsigned long long ds = solves - s->seen_solves;
-        if (!force && !s->persistent && ds >= 32 && done_min < n_iter) {
+        if (!force && !s->persistent && s->rsr.m == 0 && ds >= 32 && done_min < n_iter) {
             const double mean = (double)(tot - s->seen_tot) / ds;
             const double var = std::max(0.0, (double)(sq - s->seen_sq) / ds - mean * mean);
             const int want = std::max(4, (int)std::ceil(mean + 2.5 * std::sqrt(var)));
@@ -1068,6 +1174,10 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     else if (nm == "tau") v.assign(1, sc.tau);
     else if (nm == "minres_itn") v.assign(1, (double)sc.minres_itn_last);
     else if (nm == "iter") v.assign(1, (double)it);
+    else if (nm == "theta" && s->rsr.m > 0) {
+        v.resize((size_t)s->rsr.m);
+        HIP_TRY(hipMemcpy(v.data(), s->rsr.theta + (size_t)chain * s->rsr.m, sizeof(double) * v.size(), hipMemcpyDeviceToHost));
+    }
     else return set_error(s, OCC_E_STATE, "unknown state name");
     if (rc) return rc;
     *len = (int64_t)v.size();
@@ -1099,6 +1209,10 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
         std::vector<uint8_t> z(n);
         for (size_t i = 0; i < n; ++i) z[i] = in[i] != 0.0;
         HIP_TRY(hipMemcpy(c.z + chain * n, z.data(), n, hipMemcpyHostToDevice));
+    } else if (nm == "theta" && s->rsr.m > 0) {
+        if (!need((size_t)s->rsr.m)) return set_error(s, OCC_E_STATE, "wrong length");
+        int rc = set_theta(s, chain, in);
+        if (rc) return rc;
     } else if (nm == "xz") {
         if (!need(2 * n)) return set_error(s, OCC_E_STATE, "wrong length");
         std::vector<double2> x(n);

@@ -1,3 +1,3 @@
-from .logit import LogitICARGibbs
+from .logit import LogitICARGibbs, LogitRSRGibbs
 
-__all__ = ('LogitICARGibbs',)
+__all__ = ('LogitICARGibbs', 'LogitRSRGibbs')

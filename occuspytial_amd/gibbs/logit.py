@@ -62,8 +62,12 @@ class LogitICARGibbs(GibbsBase):
         st.alpha = eng.get('alpha', chain)
         st.beta = eng.get('beta', chain)
         st.tau = float(eng.get('tau', chain))
-        st.eta = eng.get('eta', chain)
-        st.spatial = st.eta
+        if self._problem.rsr is None:
+            st.eta = eng.get('eta', chain)
+            st.spatial = st.eta
+        else:   # reduced-rank model: eta holds the basis coefficients, spatial = K eta (logit.py:484-485)
+            st.eta = eng.get('theta', chain)
+            st.spatial = eng.get('eta', chain)
         st.z = eng.get('z', chain)
         st.k = st.z - 0.5
         st.omega_b = eng.get('omega_b', chain)
@@ -190,3 +194,52 @@ class LogitICARGibbs(GibbsBase):
             chains.append(ch)
         self._pull_state(eng, 0)
         return chains
+
+
+class LogitRSRGibbs(LogitICARGibbs):
+    r"""Gibbs sampler, logit link, reduced-rank (RSR) spatial random effects -- computed on an AMD MI355X.
+
+    Drop-in for the reference class of the same name (``logit.py:340-485``): ``LogitRSRGibbs(Q, W, X, y,
+    hparams=None, random_state=None, r=0.5, q=None)``.  The spatial effects are :math:`K\theta` with
+    :math:`K` the eigenvectors of the Moran operator whose eigenvalues are at least ``r`` (or the ``q`` leading
+    ones); ``state.eta`` holds :math:`\theta`, ``state.spatial`` holds :math:`K\theta`, ``fixed.Q`` is
+    :math:`K^\top Q K`, ``fixed.K`` is :math:`K`, ``fixed.q`` its number of columns, and the default
+    ``tau_shape`` becomes ``0.5 + 0.5 q`` -- all as in the reference.  The basis is computed on the host with dense
+    n x n linear algebra, once (as the reference does); per iteration the device forms
+    :math:`K^\top\Omega K + \tau K^\top QK` and solves the q x q system (``csrc/occ_rsr.hpp``).  At most 128
+    basis columns.  ``device`` selects the HIP device.
+    """
+
+    def __init__(self, Q, W, X, y, hparams=None, random_state=None, r=0.5, q=None, device=0):
+        super().__init__(Q, W, X, y, hparams, random_state, device=device)
+        self._configure_rsr(r, q, hparams)
+
+    def _configure_rsr(self, r, q, hparams):
+        rsr = self._problem.enable_rsr(r=r, q=q, default_tau_shape=not hparams)
+        if rsr['dim'] > 128:
+            raise ValueError(f'{rsr["dim"]} basis columns selected; the device path supports at most 128 '
+                             '(raise the threshold `r` or pass `q`)')
+        fixed = self.fixed
+        fixed.q = rsr['dim']
+        del fixed.Q
+        fixed.Q = rsr['Q']
+        fixed.K = rsr['K']
+        if not hparams:
+            del fixed.tau_shape
+            fixed.tau_shape = self._problem.tau_shape
+
+    def _initialize_default_start(self, state):
+        state = super()._initialize_default_start(state)
+        state.eta = self.rng.normal(scale=5, size=self.fixed.q)           # logit.py:453-455
+        state.spatial = self.fixed.K @ state.eta
+        return state
+
+    def _initialize_posterior_state(self, start=None):
+        if start is None:
+            self._initialize_default_start(self.state)
+        else:
+            self.state.alpha = start['alpha']
+            self.state.beta = start['beta']
+            self.state.tau = start['tau']
+            self.state.eta = start['eta']
+            self.state.spatial = self.fixed.K @ np.asarray(self.state.eta, dtype=float)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.occ_abi_version() == 1
+    assert lib.occ_abi_version() == 2
 
 
 def test_no_gpu_means_a_loud_failure_not_a_fallback():
@@ -301,3 +301,24 @@ def test_distribution_helpers_match_the_reference_functions():
     assert np.allclose(out, g['proj_out'], rtol=0, atol=1e-14)
     with pytest.raises(RuntimeError, match='Cholesky factorization/solver failed!'):
         precision_mvnorm(np.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]), 1)
+
+
+def test_reduced_rank_sampler_configuration_needs_no_device():
+    """LogitRSRGibbs's set-up (reference logit.py:413-455) is host work: basis size from the threshold or from
+    ``q``, ``fixed`` entries, default ``tau_shape``, the reference's error for a threshold outside [0, 1]."""
+    from occuspytial_amd import LogitRSRGibbs
+    from .conftest import load_golden
+    g = load_golden('ref_rsr150_r05')
+    Q, W, X, y = _inputs(load_golden('ref_queen150_ragged'))[:4]
+    s = LogitRSRGibbs(Q, W, X, y, random_state=10)
+    assert s.fixed.q == int(g['rsr_dim']) and s.fixed.K.shape == (150, s.fixed.q)
+    assert s.fixed.tau_shape == float(g['cfg_tau_shape'])
+    assert np.allclose(s.fixed.K @ s.fixed.K.T, g['rsr_K'] @ g['rsr_K'].T, atol=1e-8)
+    s._initialize_posterior_state(None)        # same generator calls as the reference: same start values
+    assert np.allclose(s.state.tau, float(g['start_tau'])) and np.allclose(s.state.alpha, g['start_alpha'])
+    assert s.state.eta.shape == (s.fixed.q,) and np.allclose(s.state.spatial, s.fixed.K @ s.state.eta)
+    assert LogitRSRGibbs(Q, W, X, y, q=10).fixed.q == 10
+    with pytest.raises(ValueError, match='Threshold value needs to be in'):
+        LogitRSRGibbs(Q, W, X, y, r=1.1)
+    hp = {'tau_rate': 1.0, 'tau_shape': 5.0}
+    assert LogitRSRGibbs(Q, W, X, y, hparams=hp, q=10).fixed.tau_shape == 5.0

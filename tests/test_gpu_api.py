@@ -140,3 +140,33 @@ def test_checkpoint_resume_continues_every_chain_exactly(data, tmp_path):
         bad = dict(ckpt)
         bad['shape'] = ckpt['shape'] + 1
         fresh.resume(bad, 5, progressbar=False)
+
+
+def test_reduced_rank_sampler_api(data):
+    """LogitRSRGibbs rows of the reference's test_samplers.py (shapes, same seed => same draws, q=10, bad
+    threshold), plus the reference's attribute contract: state.eta = theta (q), state.spatial = K theta (n)."""
+    from occuspytial_amd import LogitRSRGibbs
+    s = LogitRSRGibbs(*data, random_state=10)
+    out = s.sample(5, chains=1, progressbar=False)
+    assert out['alpha'].shape == (1, 5, 2) and out['beta'].shape == (1, 5, 3) and out['tau'].shape == (1, 5)
+    out2 = LogitRSRGibbs(*data, random_state=10).sample(5, chains=1, progressbar=False)
+    for k in ('alpha', 'beta', 'tau'):
+        assert np.array_equal(out[k], out2[k])
+    m = s.fixed.q
+    assert s.fixed.K.shape == (150, m) and s.fixed.Q.shape == (m, m) and s.fixed.tau_shape == 0.5 + 0.5 * m
+    assert s.state.eta.shape == (m,) and s.state.spatial.shape == (150,)
+    assert np.allclose(s.state.spatial, s.fixed.K @ s.state.eta, atol=1e-12)
+    s10 = LogitRSRGibbs(*data, random_state=10, q=10)
+    out = s10.sample(12, burnin=2, chains=3, progressbar=False)
+    assert s10.fixed.q == 10 and out['alpha'].shape == (3, 10, 2)
+    assert not np.allclose(out['tau'][0], out['tau'][1])
+    start = {'alpha': np.zeros(2), 'beta': np.zeros(3), 'tau': 2.0, 'eta': np.ones(10)}
+    out = s10.sample(4, start=start, chains=1, progressbar=False)
+    assert np.all(np.isfinite(out['beta']))
+    # checkpoint / resume on the reduced-rank model too
+    whole = LogitRSRGibbs(*data, random_state=5, q=10).sample(30, chains=2, progressbar=False)
+    first = LogitRSRGibbs(*data, random_state=5, q=10)
+    first.sample(12, chains=2, progressbar=False)
+    tail = LogitRSRGibbs(*data, random_state=77, q=10).resume(first.checkpoint(), 18, progressbar=False)
+    for k in ('alpha', 'beta', 'tau'):
+        assert np.array_equal(tail[k], whole[k][:, 12:])

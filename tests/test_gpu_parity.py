@@ -399,3 +399,65 @@ def test_eight_chains_of_config3_run_and_differ():
     for c in range(8):
         assert abs(eng.get('eta', c).sum()) < 1e-7 * np.abs(eng.get('eta', c)).sum()
     eng.close()
+
+
+# ---- reduced-rank model (LogitRSRGibbs) ---------------------------------------------------------------------
+def _rsr_problem(case):
+    prob, start = _problem_from_golden(case)
+    g = load_golden(case)
+    K = np.ascontiguousarray(g['rsr_K'])
+    prob.rsr = {'K': K, 'Q': np.ascontiguousarray(g['rsr_Q']), 'E': np.ascontiguousarray(g['rsr_eigen']), 'dim': K.shape[1]}
+    prob.tau_shape = float(g['cfg_tau_shape'])
+    return prob, start
+
+
+@pytest.mark.parametrize('case', ['ref_rsr150_r05', 'ref_rsr150_q10'])
+def test_reduced_rank_lockstep_iterations_match_oracle(oracle, case):
+    """LogitRSRGibbs on the reference's own basis K (fixture): five iterations in lock step with the oracle, whose
+    theta conditional is pinned to the reference (tests/test_oracle_golden.py); theta, eta = K theta, tau, beta,
+    alpha, z after every iteration, then the engine is re-seated on the oracle's state."""
+    from occuspytial_amd._engine import Engine
+    prob, start = _rsr_problem(case)
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    assert _rel(eng.get('eta'), orc.get('eta')) < 1e-13          # both form K theta from the start coefficients
+    for it in range(5):
+        eng.step()
+        orc.step()
+        for name, tol in (('omega_b', 1e-10), ('tau', 1e-11), ('theta', 1e-9), ('eta', 1e-9), ('beta', 1e-9), ('alpha', 1e-9)):
+            assert _rel(eng.get(name), orc.get(name)) < tol, (it, name, _rel(eng.get(name), orc.get(name)))
+        assert np.array_equal(eng.get('z'), orc.get('z'))
+        for name in ('alpha', 'beta', 'tau', 'theta', 'z'):
+            eng.set(name, orc.get(name))
+    eng.close()
+
+
+def test_reduced_rank_graph_replay_equals_stepping_and_batching():
+    """occ_run (graph of two iterations) == occ_step, and chain c of a batch == the same chain alone: bitwise."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(24, 30, visits=3, p=2, q=2, random_state=4)
+    prob = FlatProblem(Q, W, X, y)
+    m = prob.enable_rsr(q=70)['dim']
+    rng = np.random.default_rng(8)
+    keys = [KEY + c for c in range(3)]
+    starts = [dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.0 + c, eta=rng.standard_normal(m)) for c in range(3)]
+    batch = Engine(prob, keys)
+    for c in range(3):
+        batch.set_start(c, **starts[c])
+    A, B, T = batch.run(21, 2)
+    solo = Engine(prob, [keys[1]])
+    solo.set_start(0, **starts[1])
+    rec = []
+    for i in range(21):
+        solo.step()
+        rec.append((solo.get('alpha'), solo.get('beta'), solo.get('tau')))
+    for i in range(2, 21):
+        assert np.array_equal(rec[i][0], A[1, i - 2]) and np.array_equal(rec[i][1], B[1, i - 2]) and rec[i][2] == T[1, i - 2]
+    assert np.array_equal(solo.get('theta'), batch.get('theta', 1)) and np.array_equal(solo.get('eta'), batch.get('eta', 1))
+    assert abs(batch.get('eta', 0) - prob.rsr['K'] @ batch.get('theta', 0)).max() < 1e-12
+    batch.close()
+    solo.close()
