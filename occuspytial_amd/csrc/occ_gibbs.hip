@@ -193,7 +193,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
-        case K_RSR_RHS: hipLaunchKernelGGL(k_rsr_rhs, dim3((unsigned)((s->rsr.m + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
+        case K_RSR_RHS: hipLaunchKernelGGL(k_rsr_rhs, dim3((unsigned)s->rsr.nchunk, (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
         case K_RSR_GRAM: {
             const int T = (s->rsr.m + 15) / 16;
             hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)(T * (T + 1) / 2), (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
@@ -882,12 +882,16 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         if ((rc = upload(s, &r.K, Kh))) return rc;
         if ((rc = upload(s, &r.Kt, Kth))) return rc;
         if ((rc = upload(s, &r.Qr, Qh))) return rc;
-        if ((rc = upload(s, &r.E, Eh))) return rc;
+        std::vector<double> Eth((size_t)m * m);
+        for (int a = 0; a < m; ++a)
+            for (int j = 0; j < m; ++j) Eth[(size_t)j * m + a] = Eh[(size_t)a * m + j];
+        if ((rc = upload(s, &r.Et, Eth))) return rc;
         r.Xt = c.Xt; r.z = c.z;
         for (int b = 0; b < 2; ++b) { r.omega_b[b] = c.omega_b[b]; r.enorm[b] = c.enorm[b]; }
         if ((rc = dev_alloc(s, &r.theta, (size_t)C * m))) return rc;
         if ((rc = dev_alloc(s, &r.gram, (size_t)C * m * m))) return rc;
-        if ((rc = dev_alloc(s, &r.rhs, (size_t)C * m))) return rc;
+        r.nchunk = (n + 255) / 256;
+        if ((rc = dev_alloc(s, &r.rhs, (size_t)C * r.nchunk * m))) return rc;
         r.eta = c.eta;
         r.tau_rate = c.tau_rate; r.tau_shape = c.tau_shape;
         r.scs = c.sc;
@@ -1174,6 +1178,10 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     else if (nm == "tau") v.assign(1, sc.tau);
     else if (nm == "minres_itn") v.assign(1, (double)sc.minres_itn_last);
     else if (nm == "iter") v.assign(1, (double)it);
+    else if (nm == "rsr_gram" && s->rsr.m > 0) {  // K' diag(omega_b) K of the last theta update (upper tiles; tests)
+        v.resize((size_t)s->rsr.m * s->rsr.m);
+        HIP_TRY(hipMemcpy(v.data(), s->rsr.gram + (size_t)chain * v.size(), sizeof(double) * v.size(), hipMemcpyDeviceToHost));
+    }
     else if (nm == "theta" && s->rsr.m > 0) {
         v.resize((size_t)s->rsr.m);
         HIP_TRY(hipMemcpy(v.data(), s->rsr.theta + (size_t)chain * s->rsr.m, sizeof(double) * v.size(), hipMemcpyDeviceToHost));

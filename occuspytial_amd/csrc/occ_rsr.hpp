@@ -9,10 +9,12 @@
 //   rhs    = K'(k - omega_b X beta + sqrt(omega_b) eps1) + sqrt(tau) E eps2     (E E' = Qr; eps1 per site, eps2 per column)
 //   theta  = prec^-1 rhs  (upper Cholesky in LDS, two triangular solves),  eta = K theta
 // Four kernels, all chains batched on blockIdx.y, every sum in a fixed order (no atomics):
-//   k_rsr_rhs      K'u, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i: 256 sites staged in LDS per trip, one
-//                  thread per column, K read coalesced along the columns
-//   k_rsr_gram     K' diag(omega) K by 16 x 16 output tiles (upper triangle of tiles), 64 sites staged in LDS per trip
-//   k_rsr_solve    one workgroup per chain: tau, prec and rhs assembled in LDS, Cholesky, solves, theta
+//   k_rsr_rhs      K'u, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i: one workgroup per 256 sites stages u in
+//                  LDS, one thread per column reads K coalesced along the columns; partial sums per workgroup
+//   k_rsr_gram     K' diag(omega) K on the matrix cores: one wave per 16 x 16 output tile (upper triangle of tiles),
+//                  v_mfma_f64_16x16x4_f64 over four sites at a time, operands straight from global memory
+//   k_rsr_solve    one workgroup per chain: tau, prec and rhs assembled in LDS, right-looking Cholesky, the two
+//                  triangular solves by one wave, theta
 //   k_rsr_spatial  eta = K theta from the transposed copy of K (coalesced along the sites)
 // plus k_beta_partial_rsr: the partial sums of beta's system without the ICAR solve's projection step.
 #pragma once
@@ -28,13 +30,14 @@ struct RsrArgs {
     const double *K;    // [n][m]
     const double *Kt;   // [m][n]
     const double *Qr;   // [m][m]
-    const double *E;    // [m][m]
+    const double *Et;   // [m][m], the eigenfactor E of Qr (E E' = Qr) TRANSPOSED: Et[j][r] = E[r][j]
     const double *Xt;   // [p][n]
     const uint8_t *z;   // [C][n]
     const double *omega_b[2], *enorm[2];
     double *theta;      // [C][m]
     double *gram;       // [C][m][m] (upper triangle of 16 x 16 tiles written)
-    double *rhs;        // [C][m]
+    double *rhs;        // [C][nchunk][m] partial sums of K'u per 256-site workgroup
+    int nchunk;
     double *eta;        // [C][n]
     double tau_rate, tau_shape;
     ChainScalars *scs;
@@ -43,62 +46,79 @@ struct RsrArgs {
 __global__ void __launch_bounds__(256) k_rsr_rhs(const RsrArgs a, int e)
 {
     __shared__ double s_u[256];
-    const int chain = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+    const int chain = blockIdx.y, chunk = blockIdx.x, i0 = chunk * 256;
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const uint32_t it = ctl.it;
     const size_t co = (size_t)chain * a.n;
-    double acc = 0.0;
-    for (int i0 = 0; i0 < a.n; i0 += 256) {
-        const int i = i0 + (int)threadIdx.x;
-        double u = 0.0;
-        if (i < a.n) {
-            const double om = a.omega_b[it & 1][co + i];
-            const double xb = xdot(a.Xt, a.n, i, sc.beta, a.p);
-            u = fma(sqrt(om), a.enorm[it & 1][co + i], fma(-om, xb, (double)a.z[co + i] - 0.5));
-        }
-        __syncthreads();
-        s_u[threadIdx.x] = u;
-        __syncthreads();
-        if (col < a.m) {
-            const int cnt = min(256, a.n - i0);
-            for (int ii = 0; ii < cnt; ++ii) acc = fma(a.K[(size_t)(i0 + ii) * a.m + col], s_u[ii], acc);
-        }
+    const int i = i0 + (int)threadIdx.x;
+    double u = 0.0;
+    if (i < a.n) {
+        const double om = a.omega_b[it & 1][co + i];
+        const double xb = xdot(a.Xt, a.n, i, sc.beta, a.p);
+        u = fma(sqrt(om), a.enorm[it & 1][co + i], fma(-om, xb, (double)a.z[co + i] - 0.5));
     }
-    if (col < a.m) a.rhs[(size_t)chain * a.m + col] = acc;
+    s_u[threadIdx.x] = u;
+    __syncthreads();
+    const int cnt = min(256, a.n - i0);
+    for (int col = threadIdx.x; col < a.m; col += 256) {
+        double acc = 0.0;
+        for (int ii = 0; ii < cnt; ++ii) acc = fma(a.K[(size_t)(i0 + ii) * a.m + col], s_u[ii], acc);
+        a.rhs[((size_t)chain * a.nchunk + chunk) * a.m + col] = acc;
+    }
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// G = K' diag(omega) K, one wave per 16 x 16 tile of the upper triangle.  v_mfma_f64_16x16x4_f64 multiplies a 16 x 4
+// by a 4 x 16 block: here A = (K[:, a0:a0+16] scaled by omega)' and B = K[:, c0:c0+16] over four consecutive sites.
+// Operand layout (wave64, checked against numpy on the device): lane l carries A[l % 16][l / 16] and B[l / 16][l % 16];
+// it receives D[4 v + l / 16][l % 16], v = 0..3.  Both operands are 16 consecutive doubles of a row of K per site: 128-byte coalesced loads, no LDS.
 __global__ void __launch_bounds__(256) k_rsr_gram(const RsrArgs a, int e)
 {
-    __shared__ double s_a[64][17], s_c[64][17], s_om[64];
+    __shared__ double s_part[3][64][4];  // the partial tiles of waves 1..3
     const int chain = blockIdx.y;
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int T = (a.m + 15) / 16;
-    // upper triangle of tiles, enumerated row by row
-    int ta = 0, rem = (int)blockIdx.x;
+    int ta = 0, rem = (int)blockIdx.x;  // upper triangle of tiles, enumerated row by row
     while (rem >= T - ta) { rem -= T - ta; ++ta; }
     const int tc = ta + rem;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // thread (ty, tx) owns G[a0 + ty][c0 + tx]
-    const int a0 = ta * 16, c0 = tc * 16;
-    const size_t co = (size_t)chain * a.n;
-    const double *om = a.omega_b[ctl.it & 1] + co;
-    double acc = 0.0;
-    for (int i0 = 0; i0 < a.n; i0 += 64) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < 64 * 16; t += 256) {
-            const int ii = t >> 4, cc = t & 15, i = i0 + ii;
-            s_a[ii][cc] = (i < a.n && a0 + cc < a.m) ? a.K[(size_t)i * a.m + a0 + cc] : 0.0;
-            s_c[ii][cc] = (i < a.n && c0 + cc < a.m) ? a.K[(size_t)i * a.m + c0 + cc] : 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
+    const int ca = ta * 16 + lc, cc = tc * 16 + lc;
+    const bool va = ca < a.m, vc = cc < a.m;
+    const double *om = a.omega_b[ctl.it & 1] + (size_t)chain * a.n;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    // the four waves of the workgroup take every fourth block of 32 sites; eight MFMAs per trip, their loads in
+    // flight together
+    for (int i0 = wave * 32; i0 < a.n; i0 += 128) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = i0 + 4 * t + lk;
+            const bool vi = i < a.n;
+            const double w = vi ? om[i] : 0.0;
+            av[t] = (vi && va) ? a.K[(size_t)i * a.m + ca] * w : 0.0;
+            bv[t] = (vi && vc) ? a.K[(size_t)i * a.m + cc] : 0.0;
         }
-        if (threadIdx.x < 64) s_om[threadIdx.x] = (i0 + (int)threadIdx.x < a.n) ? om[i0 + threadIdx.x] : 0.0;
-        __syncthreads();
-#pragma unroll 8
-        for (int ii = 0; ii < 64; ++ii) acc = fma(s_a[ii][ty] * s_om[ii], s_c[ii][tx], acc);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
     }
-    if (a0 + ty < a.m && c0 + tx < a.m) a.gram[((size_t)chain * a.m + a0 + ty) * a.m + c0 + tx] = acc;
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s_part[wave - 1][lane][v] = acc[v];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double *G = a.gram + (size_t)chain * a.m * a.m;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double t = ((acc[v] + s_part[0][lane][v]) + s_part[1][lane][v]) + s_part[2][lane][v];  // fixed order
+        const int r = ta * 16 + 4 * v + lk;
+        if (r < a.m && vc) G[(size_t)r * a.m + cc] = t;
+    }
 }
 
 // One workgroup per chain.  Dynamic LDS: U[m][m] (upper Cholesky factor in place), then four m-vectors.
@@ -107,7 +127,7 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_scalar[2];
     __shared__ int s_bad;
-    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x;
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, nt = blockDim.x;
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
@@ -115,12 +135,12 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     double *U = smem, *th = smem + (size_t)m * m, *rh = th + m, *yv = rh + m, *tmp = yv + m;
     double *theta = a.theta + (size_t)chain * m;
     // ---- tau: rate = 1/2 theta' Qr theta + tau_rate (theta of the previous iteration)
-    for (int t = tid; t < m; t += 256) th[t] = theta[t];
+    for (int t = tid; t < m; t += nt) th[t] = theta[t];
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    for (int r = tid; r < m; r += 256) {
+    for (int r = tid; r < m; r += nt) {
         double t = 0.0;
-        for (int c = 0; c < m; ++c) t = fma(a.Qr[(size_t)r * m + c], th[c], t);
+        for (int c = 0; c < m; ++c) t = fma(a.Qr[(size_t)c * m + r], th[c], t);  // Qr is symmetric: coalesced along r
         tmp[r] = t;
     }
     __syncthreads();
@@ -138,55 +158,69 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     const double tau = s_scalar[0], st = s_scalar[1];
     // ---- prec = K'OK + tau Qr (upper triangle), rhs = K'u + sqrt(tau) E eps2
     const double *G = a.gram + (size_t)chain * m * m;
-    for (int t = tid; t < m * m; t += 256) {
+    for (int t = tid; t < m * m; t += nt) {
         const int r = t / m, c = t % m;
         U[t] = (c >= r) ? fma(tau, a.Qr[t], G[t]) : 0.0;
     }
-    for (int j = tid; j < m; j += 256) tmp[j] = block_normal(sc.key, (uint32_t)j, 0, it, STREAM_RSR);
+    for (int j = tid; j < m; j += nt) tmp[j] = block_normal(sc.key, (uint32_t)j, 0, it, STREAM_RSR);
     __syncthreads();
-    for (int r = tid; r < m; r += 256) {
+    for (int r = tid; r < m; r += nt) {
         double t = 0.0;
-        for (int j = 0; j < m; ++j) t = fma(a.E[(size_t)r * m + j], tmp[j], t);
-        rh[r] = fma(st, t, a.rhs[(size_t)chain * m + r]);
+        for (int j = 0; j < m; ++j) t = fma(a.Et[(size_t)j * m + r], tmp[j], t);  // E[r][j], read from the transposed copy
+        double ku = 0.0;  // K'u: the workgroups' partial sums in chunk order
+        for (int ch = 0; ch < a.nchunk; ++ch) ku += a.rhs[((size_t)chain * a.nchunk + ch) * m + r];
+        rh[r] = fma(st, t, ku);
     }
     __syncthreads();
-    // ---- upper Cholesky, the oracle's (left-looking) order: column j of U' from the rows above
+    // ---- upper Cholesky in place, right-looking: scale row j, rank-one update of the trailing block; two
+    // workgroup barriers per column.  An entry receives its updates for j = 0, 1, ... in turn: the order of the
+    // oracle's dot products.  Threads form a 16 x 16 grid over the trailing block (no index divisions).
+    double *row = yv;  // the scaled row j
+    const int ty = tid >> 4, tx = tid & 15;
     for (int j = 0; j < m; ++j) {
-        if (tid == 0) {
-            double s = U[(size_t)j * m + j];
-            for (int k = 0; k < j; ++k) s = fma(-U[(size_t)k * m + j], U[(size_t)k * m + j], s);
-            if (!(s > 0.0)) s_bad = 1;
-            s_scalar[0] = sqrt(s);
+        const double piv = U[(size_t)j * m + j];
+        if (tid == 0 && !(piv > 0.0)) s_bad = 1;
+        const double ujj = sqrt(piv);
+        for (int i = j + 1 + tid; i < m; i += nt) {
+            const double v = U[(size_t)j * m + i] / ujj;
+            row[i] = v;
+            U[(size_t)j * m + i] = v;
         }
         __syncthreads();
-        const double ujj = s_scalar[0];
-        for (int i = j + 1 + tid; i < m; i += 256) {
-            double t = U[(size_t)j * m + i];
-            for (int k = 0; k < j; ++k) t = fma(-U[(size_t)k * m + j], U[(size_t)k * m + i], t);
-            U[(size_t)j * m + i] = t / ujj;
-        }
         if (tid == 0) U[(size_t)j * m + j] = ujj;
+        for (int k = j + 1 + ty; k < m; k += 16) {
+            const double rk = row[k];
+            for (int i = k + tx; i < m; i += 16) U[(size_t)k * m + i] = fma(-rk, row[i], U[(size_t)k * m + i]);
+        }
         __syncthreads();
     }
     if (s_bad) {
         if (tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
         return;
     }
-    // ---- U'y = rhs (forward), U theta = y (backward): one lane, m^2 operations (m <= 128)
-    if (tid == 0) {
+    // ---- U'y = rhs (forward), U theta = y (backward) by ONE wave, column-oriented (lanes own entries lane and
+    // lane + 64; m <= 128): after y_i is known every later entry subtracts its term -- no workgroup barrier
+    if (tid < 64) {
+        double r0 = (tid < m) ? rh[tid] : 0.0, r1 = (tid + 64 < m) ? rh[tid + 64] : 0.0;
         for (int i = 0; i < m; ++i) {
-            double t = rh[i];
-            for (int k = 0; k < i; ++k) t = fma(-U[(size_t)k * m + i], yv[k], t);
-            yv[i] = t / U[(size_t)i * m + i];
+            const double num = (i < 64) ? __shfl(r0, i) : __shfl(r1, i - 64);
+            const double yi = num / U[(size_t)i * m + i];
+            if (tid == (i & 63)) { if (i < 64) r0 = yi; else r1 = yi; }
+            if (tid > i && tid < m) r0 = fma(-U[(size_t)i * m + tid], yi, r0);
+            if (tid + 64 > i && tid + 64 < m) r1 = fma(-U[(size_t)i * m + tid + 64], yi, r1);
         }
         for (int i = m - 1; i >= 0; --i) {
-            double t = yv[i];
-            for (int k = i + 1; k < m; ++k) t = fma(-U[(size_t)i * m + k], th[k], t);
-            th[i] = t / U[(size_t)i * m + i];
+            const double num = (i < 64) ? __shfl(r0, i) : __shfl(r1, i - 64);
+            const double ti = num / U[(size_t)i * m + i];
+            if (tid == (i & 63)) { if (i < 64) r0 = ti; else r1 = ti; }
+            if (tid < i) r0 = fma(-U[(size_t)tid * m + i], ti, r0);
+            if (tid + 64 < i) r1 = fma(-U[(size_t)(tid + 64) * m + i], ti, r1);
         }
+        if (tid < m) th[tid] = r0;
+        if (tid + 64 < m) th[tid + 64] = r1;
     }
     __syncthreads();
-    for (int t = tid; t < m; t += 256) theta[t] = th[t];
+    for (int t = tid; t < m; t += nt) theta[t] = th[t];
 }
 
 __global__ void __launch_bounds__(256) k_rsr_spatial(const RsrArgs a, int e)
