@@ -42,7 +42,7 @@ struct occ_sampler {
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
     IterArgs iter{};         // ... and of k_iter
-    // reduced-rank model (LogitRSRGibbs): rsr.m > 0.  One stream, one linear graph of two iterations.
+    // reduced-rank model (LogitRSRGibbs): rsr.m > 0.  One stream, one linear graph of GRAPH_SEQ iterations.
     RsrArgs rsr{};
     std::vector<double> rsr_K_host;  // n x m, for theta -> eta on the host (start values, set_state)
     // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;
@@ -90,6 +90,10 @@ struct occ_sampler {
 };
 
 namespace {
+
+// launch sequences (iterations) per captured graph on the paths that need no host decision between iterations:
+// even, so that the sequence parity is the same at every replay; a graph boundary costs several microseconds
+constexpr int GRAPH_SEQ = 2;  // (16 per graph measured the same: the boundary between two replays is not what costs)
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -366,11 +370,11 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
     int rc;
-    if (s->rsr.m > 0) {  // reduced-rank model: two iterations (both parities) on the main stream
+    if (s->rsr.m > 0) {  // reduced-rank model: GRAPH_SEQ iterations (alternating parity) on the main stream
         const bool old_sync = s->launch_sync;
         s->launch_sync = false;
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        for (int t = 0; t < 2; ++t) launch_rsr_sequence(s, s->stream, s->parity ^ t);
+        for (int t = 0; t < GRAPH_SEQ; ++t) launch_rsr_sequence(s, s->stream, s->parity ^ (t & 1));
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
         s->launch_sync = old_sync;
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
@@ -379,21 +383,21 @@ int build_graph(occ_sampler *s, int cap)
         return OCC_OK;
     }
     if (s->flag_sync) {
-        // two sequences (both parities) per graph and stream, no event nodes: the kernels hand over through
+        // GRAPH_SEQ sequences (alternating parity) per graph and stream, no event nodes: the kernels hand over through
         // the device counters of Ctx::sync
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        for (int t = 0; t < 2; ++t) {
-            launch_kind(s, s->stream, K_ITER, s->parity ^ t);
-            launch_kind(s, s->stream, K_Z_OB, s->parity ^ t);
+        for (int t = 0; t < GRAPH_SEQ; ++t) {
+            launch_kind(s, s->stream, K_ITER, s->parity ^ (t & 1));
+            launch_kind(s, s->stream, K_Z_OB, s->parity ^ (t & 1));
         }
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
         HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < GRAPH_SEQ; ++t) {
             launch_kind(s, s->side, K_GATE, 0);
-            launch_kind(s, s->side, K_OMEGA_A, s->parity ^ t);
-            launch_kind(s, s->side, K_ALPHA_DRAW, s->parity ^ t);
-            launch_kind(s, s->side, K_NOISE, s->parity ^ t, 1);
+            launch_kind(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
+            launch_kind(s, s->side, K_ALPHA_DRAW, s->parity ^ (t & 1));
+            launch_kind(s, s->side, K_NOISE, s->parity ^ (t & 1), 1);
         }
         HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->tail[0], s->tail_graph[0], nullptr, nullptr, 0));
@@ -458,11 +462,11 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
-    if (s->rsr.m > 0) {  // two sequences
+    if (s->rsr.m > 0) {  // GRAPH_SEQ sequences
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
         return OCC_OK;
     }
-    if (s->flag_sync) {  // two sequences on each stream
+    if (s->flag_sync) {  // GRAPH_SEQ sequences on each stream
         HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
         return OCC_OK;
@@ -1068,7 +1072,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
     if (done_min < n_iter && s->side_enabled && !s->flag_sync && s->rsr.m == 0) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
-    const int64_t seq_per_enqueue = (s->flag_sync || s->rsr.m > 0) ? 2 : 1;
+    const int64_t seq_per_enqueue = (s->flag_sync || s->rsr.m > 0) ? GRAPH_SEQ : 1;
 
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
