@@ -178,7 +178,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (includes Krylov calibration and the hipGraph capture), then K timed steps --------
+    # ---- warm-up (includes the hipGraph capture), then K timed steps ------------------------------
     if args.warmup > 0:
         eng.run(args.warmup, args.warmup - 1)
     stats_warm = eng.stats()

@@ -64,7 +64,7 @@ struct occ_sampler {
     // have to be produced stand-alone before the first sequence
     bool need_prologue = true;
     // graph replay.  Every graph is a LINEAR chain replayed on one of the engine's own two streams:
-    // head[e] = k_eta_init, the eta solve (k_solve, or cap + 3 k_minres launches), k_beta_partial, wait for the
+    // head[e] = k_iter (or k_eta_init, cap + 3 k_minres launches, k_beta_partial), wait for the
     // side chain, k_z_ob, record -- on the main stream; tail[e] = wait for the previous k_z_ob, k_omega_a,
     // k_alpha_draw, k_noise, record -- on the side stream.  (Graphs with parallel branches get
     // runtime-internal streams at every instantiation; on ROCm 7.2 the second or third such instantiation
@@ -1426,7 +1426,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
 }
 
 #ifdef OCC_SOLVE_STAMPS
-// developer build only: the time stamps of the last k_solve launch (chain 0, workgroup 0)
+// developer build only: the time stamps of the last k_iter launch (chain 0, workgroup 0)
 int occ_debug_solve_stamps(unsigned long long *out, int capacity)
 {
     const int n = STAMP_STEPS * STAMP_POINTS;

@@ -1,17 +1,20 @@
-// occ_kernels.hpp -- the Gibbs iteration as gfx950 kernels (chains batched on blockIdx.y).
+// occ_kernels.hpp -- the kernels of the Gibbs iteration other than the fused k_iter (gfx950; chains batched on blockIdx.y).
 //
-// One Gibbs iteration of LogitICARGibbs.step() (occuspytial/gibbs/logit.py:254-266) is a small DAG of
-// kernels; a kernel boundary is the only grid-wide synchronisation used (cheaper on MI355X than any
-// in-kernel all-to-all).  Global sums are "reduce at the consumer": every wave writes one
-// partial per quantity, and every wave of the NEXT kernel re-reduces all partials in the same fixed
-// order, so scalars are bit-identical everywhere and in every run (no float atomics anywhere).
+// One Gibbs iteration of LogitICARGibbs.step() (occuspytial/gibbs/logit.py:254-266) is a small DAG of kernels.
+// Global sums are "reduce at the consumer": a producer writes one partial per block (or 64-site slice) and
+// quantity, and every consumer re-reduces all partials in the same fixed order, so scalars are bit-identical
+// everywhere and in every run (no float atomics anywhere).
 //
 // The reference's order is omega_b, tau, eta, beta, omega_a, alpha, z.  omega_a/alpha of iteration t
 // read only alpha and z of iteration t-1, and the next iteration's omega_b reads only beta and eta of
 // iteration t, so (with counter-based variates, results do not depend on execution order):
 //
-//   main stream  k_eta_init -> k_minres x (cap+3) -> k_beta_partial -> k_z_ob
-//   side stream  k_omega_a -> k_alpha_draw -> k_noise(t+1)        (joined before k_z_ob)
+//   main stream  [tau, rhs, eta solve, projection, beta sums] -> k_z_ob
+//   side stream  k_omega_a -> k_alpha_draw -> k_noise(t+1)        (needed by k_z_ob / the next iteration)
+//
+// The bracket is ONE launch of k_iter (occ_iter.hpp) when all its workgroups fit on the device, else
+// k_eta_init -> k_minres x (cap+3) -> k_beta_partial, where a kernel boundary is the only grid-wide
+// synchronisation and a solve that needs more launches than were captured carries over (Ctl::koff).
 //
 //   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials (logit.py:195-204, 208);
 //                  stand-alone only for the first iteration after new start values -- afterwards it is
@@ -24,10 +27,12 @@
 //   k_beta_partial eta = x - (sum x / sum z) z (distributions.pyx:24-39); X' Omega X, X'(k - omega eta)
 //   k_omega_a      omega_a ~ PG(1, w'alpha) for rows of existing sites; W' Omega W, W'(y - 1/2)
 //                  (logit.py:180-193, 219-223)
-//   k_alpha_draw   alpha draw (logit.py:224), one wave per chain
+//   k_alpha_draw   alpha draw (logit.py:224), one block per chain
 //   k_z_ob         beta draw (logit.py:232, every wave); role 0: z update (logit.py:234-252), record
 //                  (alpha, beta, tau) (base.py:238-239), advance the iteration; role 1 (other half of the
 //                  grid): omega_b of the NEXT iteration
+//   k_gate         head of a side-stream sequence when the streams hand over through device counters
+// (the reduced-rank model's kernels: occ_rsr.hpp)
 #pragma once
 #include <float.h>
 #include <hip/hip_runtime.h>
@@ -656,7 +661,7 @@ __device__ __forceinline__ void projection_partials(const A &c, int chain, int i
 
 
 // ---- MINRES: the arithmetic shared by the launch-per-iteration kernel (k_minres) and the persistent
-// solve kernel (k_solve, occ_solve.hpp).  Both kernels run the SAME scalar recurrence and the same
+// iteration kernel (k_iter, occ_iter.hpp).  Both kernels run the SAME scalar recurrence and the same
 // explicitly contracted vector expressions, so a solve gives the same bits whichever of them ran it.
 struct KryStep {
     double ca, cb, cc;                     // p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}

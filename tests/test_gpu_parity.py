@@ -72,7 +72,7 @@ def _compare_iteration(eng, orc, prob, chain=0):
 
 @pytest.fixture(params=['persistent', 'launch_per_step'])
 def solve_mode(request, monkeypatch):
-    """The eta solve has two implementations of the same arithmetic: one persistent launch (k_solve, taken
+    """The eta solve has two implementations of the same arithmetic: one persistent launch (k_iter, taken
     when all workgroups of all chains fit on the device) and one launch per MINRES step (k_minres)."""
     if request.param == 'launch_per_step':
         monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
@@ -122,7 +122,7 @@ def test_free_running_chain_tracks_oracle(oracle, solve_mode):
 
 
 def test_graph_replay_equals_eager_stepping():
-    """occ_run (calibration + hipGraph replay) and occ_step (eager) are the same kernels: bitwise."""
+    """occ_run (hipGraph replay on two streams) and occ_step (eager, one stream) run the same arithmetic: bitwise."""
     from occuspytial_amd._engine import Engine
     prob, start = _problem_from_golden('ref_queen150_ragged')
     e1, e2 = Engine(prob, [KEY]), Engine(prob, [KEY])
@@ -163,7 +163,7 @@ def test_batched_chains_equal_single_chain_runs():
 
 @pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40)])
 def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, iters):
-    """k_solve exchanges g between the workgroups of a chain through write-through stores, L1-bypassing
+    """k_iter exchanges g between the workgroups of a chain through write-through stores, L1-bypassing
     loads and a per-chain arrival counter; one stale or torn value would change the bits of eta.  Same
     scalars, same contractions, same summation order as k_minres: everything must agree exactly,
     including the number of MINRES iterations of every solve."""
