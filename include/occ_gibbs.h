@@ -6,8 +6,8 @@
  * numpy/scipy, two Cython helpers and the third-party `polyagamma` C sampler.  This header is the
  * boundary a binding of that path would use: one opaque handle per (device, batch of chains), plain
  * pointers and sizes, int status codes that map onto the reference's exception types/messages.
- * The Python class occuspytial_amd.gibbs.LogitICARGibbs binds it with ctypes (INTEGRATION.md shows
- * the stub a maintainer of the reference would add).
+ * The Python classes occuspytial_amd.gibbs.LogitICARGibbs / LogitRSRGibbs bind it with ctypes
+ * (INTEGRATION.md shows the stub a maintainer of the reference would add).
  *
  * Conventions
  *  - every function returns OCC_OK (0) or a negative OCC_E* code; occ_last_error() gives the text;
@@ -86,8 +86,8 @@ int occ_set_keys(occ_sampler *s, const uint64_t *keys);
 int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const double *beta, double tau,
                   const double *eta);
 
-/* One Gibbs iteration of every chain, launched kernel by kernel with host-checked solver
- * convergence: LogitICARGibbs.step() (logit.py:254-266). */
+/* One Gibbs iteration of every chain, launched kernel by kernel on one stream in the reference's order:
+ * LogitICARGibbs.step() (logit.py:254-266). */
 int occ_step(occ_sampler *s);
 
 /* n_iter iterations of every chain; alpha/beta/tau of iterations >= burnin are recorded:
@@ -102,8 +102,8 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
  *   alpha(q) beta(p) tau(1) eta(n) z(n) k(n) omega_b(n) omega_a(R) exists(S) xz(2n) rhs(n)
  *   minres_itn(1) iter(1); reduced-rank model: theta(m), and eta is K theta (the reference's `spatial`)
  * occ_get_state copies into out (capacity cap doubles) and stores the length in *len.
- * occ_set_state accepts alpha beta tau eta z omega_a xz iter theta (theta also sets eta = K theta) (omega_b of the coming iteration is then
- * redrawn from the new state). */
+ * occ_set_state accepts alpha beta tau eta z omega_a xz iter theta (theta also sets eta = K theta); omega_b of
+ * the coming iteration is then redrawn from the new state. */
 int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len);
 int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double *in, int64_t len);
 
