@@ -167,6 +167,8 @@ KernelEI pick_beta_partial(int p)
     ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
 KernelE pick_beta_partial_rsr(int p) { return OCC_PICK_P(k_beta_partial_rsr, p); }
+using KernelRsr = void (*)(const RsrArgs, int);
+KernelRsr pick_rsr_solve(int m) { return m <= 32 ? k_rsr_solve<2> : m <= 64 ? k_rsr_solve<4> : m <= 96 ? k_rsr_solve<6> : k_rsr_solve<8>; }
 KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {
@@ -204,7 +206,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         }
         case K_RSR_SOLVE:
-            hipLaunchKernelGGL(k_rsr_solve, dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * ((size_t)s->rsr.m * s->rsr.m + 4 * s->rsr.m), st, s->rsr, e);
+            hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
             break;
         case K_RSR_SPATIAL: hipLaunchKernelGGL(k_rsr_spatial, dim3((unsigned)((c.n + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
         case K_RSR_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial_rsr(c.p), gs, blk, 0, st, OCC_ARGS); break;
@@ -900,8 +902,8 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         r.tau_rate = c.tau_rate; r.tau_shape = c.tau_shape;
         r.scs = c.sc;
         s->rsr_K_host = Kh;
-        HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(double) * ((size_t)m * m + 4 * m))));
+        HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
     }
     HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());

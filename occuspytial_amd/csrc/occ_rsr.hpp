@@ -121,32 +121,105 @@ __global__ void __launch_bounds__(256) k_rsr_gram(const RsrArgs a, int e)
     }
 }
 
-// One workgroup per chain.  Dynamic LDS: U[m][m] (upper Cholesky factor in place), then four m-vectors.
+// Row stride of the Cholesky factor in LDS: odd, so that a column walk (one row per lane) touches every bank once.
+__host__ __device__ inline int rsr_ld(int m) { return 16 * ((m + 15) / 16) + 1; }
+__host__ __device__ inline size_t rsr_solve_lds_doubles(int m) { return (size_t)m * rsr_ld(m) + 4 * (size_t)m; }
+
+// Broadcast of one lane's double; the lane index is wave-uniform.
+__device__ inline double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(x), x > 0 and far from the ends of the exponent range: the hardware estimate and two Newton steps
+// (the pivot's reciprocal root is all the factorisation needs; a sqrt followed by a division is three times
+// the dependent chain).
+__device__ inline double rsqrt_pivot(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double h = 0.5 * y;
+        const double err = fma(-(x * y), h, 0.5);  // (1 - x y^2) / 2
+        y = fma(y, err, y);
+    }
+    return y;
+}
+
+#ifdef OCC_SOLVE_STAMPS
+#define RSR_STAMP(pt) if (chain == 0 && tid == 0) g_solve_stamps[(pt)] = wall_clock64();
+#else
+#define RSR_STAMP(pt)
+#endif
+
+// One workgroup per chain.  Dynamic LDS: U[m][ld] (the finished rows of the upper Cholesky factor, ld = rsr_ld(m)),
+// then four m-vectors.  NB = number of 16-wide blocks covering m (m <= 16 NB).
+//
+// The matrix lives in REGISTERS: the 256 threads form a 16 x 16 grid (ty, tx) and thread (ty, tx) owns the entries
+// (ty + 16 a, tx + 16 b), a <= b < NB (block-cyclic, so the shrinking trailing block stays spread over all threads;
+// blocks below the diagonal are never touched).  Column j: the 16 threads of grid row j % 16 (a quarter of one
+// wave; the pivot comes by v_readlane) scale row j by 1/sqrt(pivot) and publish it to LDS row j, with zeros at and
+// left of the diagonal; ONE workgroup barrier; every thread reads the values of row j that meet its rows and
+// columns and applies the rank-one update to its registers.  A zero in row j at k <= j leaves the finished rows
+// alone, so there is not one mask or branch in the update.  The right-hand side travels as an extra column (rr):
+// the forward substitution U'y = rhs is finished when the factor is.  An entry receives its updates for j = 0, 1,
+// ... in turn: the order of the oracle's dot products.  The diagonal of U is never stored, its reciprocal is.
+template <int NB>
 __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_scalar[2];
     __shared__ int s_bad;
-    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, nt = blockDim.x;
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, nt = blockDim.x, ld = rsr_ld(m);
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const uint32_t it = ctl.it;
-    double *U = smem, *th = smem + (size_t)m * m, *rh = th + m, *yv = rh + m, *tmp = yv + m;
+    double *U = smem, *th = smem + (size_t)m * ld, *rh = th + m, *yv = rh + m, *tmp = yv + m;
     double *theta = a.theta + (size_t)chain * m;
+    const int ty = tid >> 4, tx = tid & 15;
+    RSR_STAMP(0)
+    // the Gram matrix and Qr of this thread's entries are on their way while tau is drawn
+    const double *G = a.gram + (size_t)chain * m * m;
+    double u[NB][NB], qr[NB][NB];
+#pragma unroll
+    for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+        for (int ib = ia; ib < NB; ++ib) {
+            const int k = ty + 16 * ia, i = tx + 16 * ib;
+            const bool in = (k < m) && (i < m) && (i >= k);
+            const size_t at = in ? (size_t)k * m + i : 0;  // unconditional loads (a branch per entry would serialise them)
+            const double gv = G[at], qv = a.Qr[at];
+            u[ia][ib] = in ? gv : 0.0;
+            qr[ia][ib] = in ? qv : 0.0;
+        }
     // ---- tau: rate = 1/2 theta' Qr theta + tau_rate (theta of the previous iteration)
     for (int t = tid; t < m; t += nt) th[t] = theta[t];
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    for (int r = tid; r < m; r += nt) {
-        double t = 0.0;
-        for (int c = 0; c < m; ++c) t = fma(a.Qr[(size_t)c * m + r], th[c], t);  // Qr is symmetric: coalesced along r
-        tmp[r] = t;
+    {   // theta' Qr theta = the diagonal terms + twice the upper ones: every thread its entries, then a fixed-order
+        // reduction (the lanes of a wave by xor shuffles, the four waves by thread 0)
+        double tk[NB], ti[NB], part = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            tk[ib] = th[min(ty + 16 * ib, m - 1)];
+            ti[ib] = th[min(tx + 16 * ib, m - 1)];
+        }
+#pragma unroll
+        for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+            for (int ib = ia; ib < NB; ++ib) {
+                const double w = (ty + 16 * ia == tx + 16 * ib) ? 1.0 : 2.0;  // entries outside the triangle hold qr = 0
+                part = fma(w * qr[ia][ib], tk[ia] * ti[ib], part);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((tid & 63) == 0) tmp[tid >> 6] = part;
     }
     __syncthreads();
     if (tid == 0) {
-        double quad = 0.0;
-        for (int r = 0; r < m; ++r) quad = fma(th[r], tmp[r], quad);
+        const double quad = ((tmp[0] + tmp[1]) + tmp[2]) + tmp[3];
         const double rate = 0.5 * quad + a.tau_rate;
         Cursor g(sc.key, 0u, it, STREAM_TAU);
         const double tau = (1.0 / rate) * std_gamma(g, a.tau_shape);
@@ -154,73 +227,120 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
         s_scalar[0] = tau;
         s_scalar[1] = sqrt(tau);
     }
+    for (int j = tid; j < m; j += nt) th[j] = block_normal(sc.key, (uint32_t)j, 0, it, STREAM_RSR);  // theta is spent
     __syncthreads();
     const double tau = s_scalar[0], st = s_scalar[1];
-    // ---- prec = K'OK + tau Qr (upper triangle), rhs = K'u + sqrt(tau) E eps2
-    const double *G = a.gram + (size_t)chain * m * m;
-    for (int t = tid; t < m * m; t += nt) {
-        const int r = t / m, c = t % m;
-        U[t] = (c >= r) ? fma(tau, a.Qr[t], G[t]) : 0.0;
-    }
-    for (int j = tid; j < m; j += nt) tmp[j] = block_normal(sc.key, (uint32_t)j, 0, it, STREAM_RSR);
-    __syncthreads();
-    for (int r = tid; r < m; r += nt) {
+    RSR_STAMP(1)
+    // ---- prec = K'OK + tau Qr (upper triangle, registers), rhs = K'u + sqrt(tau) E eps2
+#pragma unroll
+    for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+        for (int ib = ia; ib < NB; ++ib) u[ia][ib] = fma(tau, qr[ia][ib], u[ia][ib]);
+    {   // E eps2: two threads per row (the halves of the sum), K'u: the workgroups' partial sums in chunk order
+        const int r = tid & 127, half = tid >> 7, hm = (m + 1) >> 1;
         double t = 0.0;
-        for (int j = 0; j < m; ++j) t = fma(a.Et[(size_t)j * m + r], tmp[j], t);  // E[r][j], read from the transposed copy
-        double ku = 0.0;  // K'u: the workgroups' partial sums in chunk order
-        for (int ch = 0; ch < a.nchunk; ++ch) ku += a.rhs[((size_t)chain * a.nchunk + ch) * m + r];
-        rh[r] = fma(st, t, ku);
+        if (r < m) {
+            const int j1 = half ? m : hm;
+            for (int j = half ? hm : 0; j < j1; ++j) t = fma(a.Et[(size_t)j * m + r], th[j], t);  // E[r][j], from the transposed copy
+            if (half) tmp[r] = t;
+        }
+        __syncthreads();
+        if (r < m && !half) {
+            double ku = 0.0;
+            for (int ch = 0; ch < a.nchunk; ++ch) ku += a.rhs[((size_t)chain * a.nchunk + ch) * m + r];
+            rh[r] = fma(st, t + tmp[r], ku);
+        }
     }
     __syncthreads();
-    // ---- upper Cholesky in place, right-looking: scale row j, rank-one update of the trailing block; two
-    // workgroup barriers per column.  An entry receives its updates for j = 0, 1, ... in turn: the order of the
-    // oracle's dot products.  Threads form a 16 x 16 grid over the trailing block (no index divisions).
-    double *row = yv;  // the scaled row j
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int j = 0; j < m; ++j) {
-        const double piv = U[(size_t)j * m + j];
-        if (tid == 0 && !(piv > 0.0)) s_bad = 1;
-        const double ujj = sqrt(piv);
-        for (int i = j + 1 + tid; i < m; i += nt) {
-            const double v = U[(size_t)j * m + i] / ujj;
-            row[i] = v;
-            U[(size_t)j * m + i] = v;
+    double rr[NB];  // the right-hand side of this thread's rows (every thread of a grid row carries a copy)
+#pragma unroll
+    for (int ia = 0; ia < NB; ++ia) rr[ia] = (ty + 16 * ia < m) ? rh[ty + 16 * ia] : 0.0;
+    double *dinv = tmp;  // the reciprocals of U's diagonal
+    __syncthreads();
+    RSR_STAMP(2)
+    // ---- Cholesky + forward substitution
+#pragma unroll
+    for (int ja = 0; ja < NB; ++ja) {
+        if (16 * ja >= m) break;
+#pragma unroll 1
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * ja + jj;
+            if (j >= m) break;
+            double *Uj = U + (size_t)j * ld;
+            if ((tid >> 6) == (jj >> 2)) {  // the wave that holds grid row jj
+                const double piv = readlane_f64(u[ja][ja], ((jj & 3) << 4) | jj);
+                if (ty == jj) {
+                    if (!(piv > 0.0)) s_bad = 1;
+                    const double rinv = rsqrt_pivot(piv);
+#pragma unroll
+                    for (int ib = ja; ib < NB; ++ib) {
+                        if (16 * ib >= m) break;
+                        double v = u[ja][ib] * rinv;
+                        if (ib == ja) v = (tx > jj) ? v : 0.0;
+                        u[ja][ib] = v;
+                        Uj[tx + 16 * ib] = v;
+                    }
+                    rr[ja] = rr[ja] * rinv;
+                    if (tx == jj) {
+                        yv[j] = rr[ja];
+                        dinv[j] = rinv;
+                    }
+                }
+            }
+            __syncthreads();
+            const double yj = yv[j];
+            double ri[NB], rk[NB];
+#pragma unroll
+            for (int ib = ja; ib < NB; ++ib) {
+                if (16 * ib >= m) break;
+                ri[ib] = Uj[tx + 16 * ib];
+                rk[ib] = Uj[ty + 16 * ib];
+            }
+#pragma unroll
+            for (int ia = ja; ia < NB; ++ia) {
+                if (16 * ia >= m) break;
+#pragma unroll
+                for (int ib = ia; ib < NB; ++ib) u[ia][ib] = fma(-rk[ia], ri[ib], u[ia][ib]);
+                rr[ia] = fma(-rk[ia], yj, rr[ia]);
+            }
         }
-        __syncthreads();
-        if (tid == 0) U[(size_t)j * m + j] = ujj;
-        for (int k = j + 1 + ty; k < m; k += 16) {
-            const double rk = row[k];
-            for (int i = k + tx; i < m; i += 16) U[(size_t)k * m + i] = fma(-rk, row[i], U[(size_t)k * m + i]);
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    RSR_STAMP(3)
     if (s_bad) {
         if (tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
         return;
     }
-    // ---- U'y = rhs (forward), U theta = y (backward) by ONE wave, column-oriented (lanes own entries lane and
-    // lane + 64; m <= 128): after y_i is known every later entry subtracts its term -- no workgroup barrier
+    // ---- U theta = y (backward) by ONE wave, column-oriented (lanes own entries lane and lane + 64; m <= 128):
+    // after theta_i is known every earlier entry subtracts its term -- no workgroup barrier.  Lane t walks ITS rows
+    // of U; the loads of four steps are issued before the four dependent steps.
     if (tid < 64) {
-        double r0 = (tid < m) ? rh[tid] : 0.0, r1 = (tid + 64 < m) ? rh[tid + 64] : 0.0;
-        for (int i = 0; i < m; ++i) {
-            const double num = (i < 64) ? __shfl(r0, i) : __shfl(r1, i - 64);
-            const double yi = num / U[(size_t)i * m + i];
-            if (tid == (i & 63)) { if (i < 64) r0 = yi; else r1 = yi; }
-            if (tid > i && tid < m) r0 = fma(-U[(size_t)i * m + tid], yi, r0);
-            if (tid + 64 > i && tid + 64 < m) r1 = fma(-U[(size_t)i * m + tid + 64], yi, r1);
+        double r0 = (tid < m) ? yv[tid] : 0.0, r1 = (tid + 64 < m) ? yv[tid + 64] : 0.0;
+        const double *c0 = U + (size_t)min(tid, m - 1) * ld, *c1 = U + (size_t)min(tid + 64, m - 1) * ld;
+        for (int i0 = m - 1; i0 >= 0; i0 -= 4) {
+            double a0[4], a1[4], dv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = max(i0 - s, 0);
+                a0[s] = c0[i];
+                a1[s] = c1[i];
+                dv[s] = dinv[i];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = i0 - s;
+                if (i < 0) break;
+                const double num = (i < 64) ? readlane_f64(r0, i) : readlane_f64(r1, i - 64);
+                const double ti = num * dv[s];
+                if (tid == (i & 63)) { if (i < 64) r0 = ti; else r1 = ti; }
+                if (tid < i) r0 = fma(-a0[s], ti, r0);
+                if (tid + 64 < i) r1 = fma(-a1[s], ti, r1);
+            }
         }
-        for (int i = m - 1; i >= 0; --i) {
-            const double num = (i < 64) ? __shfl(r0, i) : __shfl(r1, i - 64);
-            const double ti = num / U[(size_t)i * m + i];
-            if (tid == (i & 63)) { if (i < 64) r0 = ti; else r1 = ti; }
-            if (tid < i) r0 = fma(-U[(size_t)tid * m + i], ti, r0);
-            if (tid + 64 < i) r1 = fma(-U[(size_t)(tid + 64) * m + i], ti, r1);
-        }
-        if (tid < m) th[tid] = r0;
-        if (tid + 64 < m) th[tid + 64] = r1;
+        if (tid < m) theta[tid] = r0;
+        if (tid + 64 < m) theta[tid + 64] = r1;
     }
-    __syncthreads();
-    for (int t = tid; t < m; t += nt) theta[t] = th[t];
+    RSR_STAMP(4)
 }
 
 __global__ void __launch_bounds__(256) k_rsr_spatial(const RsrArgs a, int e)

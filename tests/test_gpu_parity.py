@@ -434,6 +434,34 @@ def test_reduced_rank_lockstep_iterations_match_oracle(oracle, case):
     eng.close()
 
 
+@pytest.mark.parametrize('q', [3, 16, 17, 33, 64, 97, 128])
+def test_reduced_rank_every_block_count_matches_oracle(oracle, q):
+    """The theta solve keeps the matrix in registers in 16-wide blocks (k_rsr_solve<2|4|6|8>): basis sizes at and
+    around the block edges, up to the largest the kernel takes, three iterations in lock step with the oracle."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(20, 25, visits=3, p=2, q=2, random_state=5)
+    prob = FlatProblem(Q, W, X, y)
+    m = prob.enable_rsr(q=q)['dim']
+    assert m == q
+    rng = np.random.default_rng(q)
+    start = dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.5, eta=0.3 * rng.standard_normal(m))
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    for it in range(3):
+        eng.step()
+        orc.step()
+        for name, tol in (('tau', 1e-11), ('theta', 1e-9), ('eta', 1e-9), ('beta', 1e-9), ('alpha', 1e-9)):
+            assert _rel(eng.get(name), orc.get(name)) < tol, (it, name, _rel(eng.get(name), orc.get(name)))
+        assert np.array_equal(eng.get('z'), orc.get('z'))
+        for name in ('alpha', 'beta', 'tau', 'theta', 'z'):
+            eng.set(name, orc.get(name))
+    eng.close()
+
+
 def test_reduced_rank_graph_replay_equals_stepping_and_batching():
     """occ_run (graph of two iterations) == occ_step, and chain c of a batch == the same chain alone: bitwise."""
     from occuspytial_amd._engine import Engine
