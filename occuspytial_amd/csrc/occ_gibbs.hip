@@ -168,7 +168,19 @@ KernelEI pick_beta_partial(int p)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
 KernelE pick_beta_partial_rsr(int p) { return OCC_PICK_P(k_beta_partial_rsr, p); }
 using KernelRsr = void (*)(const RsrArgs, int);
-KernelRsr pick_rsr_solve(int m) { return m <= 32 ? k_rsr_solve<2> : m <= 64 ? k_rsr_solve<4> : m <= 96 ? k_rsr_solve<6> : k_rsr_solve<8>; }
+KernelRsr pick_rsr_solve(int m)
+{
+    switch ((m + 15) / 16) {
+        case 1: return k_rsr_solve<1>;
+        case 2: return k_rsr_solve<2>;
+        case 3: return k_rsr_solve<3>;
+        case 4: return k_rsr_solve<4>;
+        case 5: return k_rsr_solve<5>;
+        case 6: return k_rsr_solve<6>;
+        case 7: return k_rsr_solve<7>;
+        default: return k_rsr_solve<8>;
+    }
+}
 KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {

@@ -153,16 +153,93 @@ __device__ inline double rsqrt_pivot(double x)
 #define RSR_STAMP(pt)
 #endif
 
+// ---- the column step of k_rsr_solve's factorisation (see there).  Column j = 16 JA + jj of the factor is in LDS;
+// the step applies its rank-one update and publishes row j + 1, which lies in block row JN (JA, or JA + 1 when
+// jj = 15).  Order: block row JN first; then the pivot's reciprocal root is started and the other block rows are
+// finished while that chain runs (one basic block, the scheduler interleaves them); the owners of row j + 1 scale
+// and store it.  One workgroup barrier.
+template <int NB, int JN>
+__device__ __forceinline__ void rsr_publish_row(double (&u)[NB][NB], double (&rr)[NB], double rinv, int jn, double *Un, double *yv,
+                                                double *dinv, int ty, int tx)
+{
+    const int jjn = jn & 15;
+    if (ty == jjn) {
+#pragma unroll
+        for (int ib = JN; ib < NB; ++ib) {
+            double v = u[JN][ib] * rinv;
+            if (ib == JN) v = (tx > jjn) ? v : 0.0;  // zeros at and left of the diagonal
+            u[JN][ib] = v;
+            Un[tx + 16 * ib] = v;
+        }
+        rr[JN] = rr[JN] * rinv;
+        if (tx == jjn) {
+            yv[jn] = rr[JN];
+            dinv[jn] = rinv;
+        }
+    }
+}
+
+template <int NB, int JA, int JN>
+__device__ __forceinline__ void rsr_column(double (&u)[NB][NB], double (&rr)[NB], int jj, int ld, double *U, double *yv, double *dinv,
+                                           int &bad, int tid)
+{
+    const int j = 16 * JA + jj, jn = j + 1, jjn = jn & 15, ty = tid >> 4, tx = tid & 15;
+    const double *Uj = U + (size_t)j * ld;
+    const double yj = yv[j];
+    double ri[NB], rk[NB];
+#pragma unroll
+    for (int ib = JN; ib < NB; ++ib) {
+        ri[ib] = Uj[tx + 16 * ib];
+        rk[ib] = Uj[ty + 16 * ib];
+    }
+#pragma unroll
+    for (int ib = JN; ib < NB; ++ib) u[JN][ib] = fma(-rk[JN], ri[ib], u[JN][ib]);
+    rr[JN] = fma(-rk[JN], yj, rr[JN]);
+    // EVERY wave runs the pivot's chain on the lane its own copy of the owner would be (ten instructions, meaningless
+    // outside the owning wave): no branch, so the chain sits in one block with the updates below and hides in them
+    const double piv = readlane_f64(u[JN][JN], ((jjn & 3) << 4) | jjn);
+    double rinv = rsqrt_pivot(piv);
+    asm volatile("" : "+v"(rinv));  // keeps the chain here (it would sink into the store branch)
+#pragma unroll
+    for (int ia = JN + 1; ia < NB; ++ia) {
+#pragma unroll
+        for (int ib = ia; ib < NB; ++ib) u[ia][ib] = fma(-rk[ia], ri[ib], u[ia][ib]);
+        rr[ia] = fma(-rk[ia], yj, rr[ia]);
+    }
+    if (ty == jjn) bad |= !(piv > 0.0);
+    rsr_publish_row<NB, JN>(u, rr, rinv, jn, U + (size_t)jn * ld, yv, dinv, ty, tx);
+    __syncthreads();
+}
+
+// Block column JA (16 columns) and, recursively, the ones after it.  Row m - 1 is published by column m - 2.
+template <int NB, int JA>
+__device__ __forceinline__ void rsr_block(double (&u)[NB][NB], double (&rr)[NB], int m, int ld, double *U, double *yv, double *dinv,
+                                          int &bad, int tid)
+{
+    if constexpr (JA < NB) {
+#pragma unroll 1
+        for (int jj = 0; jj < 15; ++jj) {
+            if (16 * JA + jj + 1 >= m) return;
+            rsr_column<NB, JA, JA>(u, rr, jj, ld, U, yv, dinv, bad, tid);
+        }
+        if constexpr (JA + 1 < NB) {
+            if (16 * JA + 16 >= m) return;
+            rsr_column<NB, JA, JA + 1>(u, rr, 15, ld, U, yv, dinv, bad, tid);
+            rsr_block<NB, JA + 1>(u, rr, m, ld, U, yv, dinv, bad, tid);
+        }
+    }
+}
+
 // One workgroup per chain.  Dynamic LDS: U[m][ld] (the finished rows of the upper Cholesky factor, ld = rsr_ld(m)),
-// then four m-vectors.  NB = number of 16-wide blocks covering m (m <= 16 NB).
+// then four m-vectors.  NB = the number of 16-wide blocks covering m: 16 (NB - 1) < m <= 16 NB.
 //
 // The matrix lives in REGISTERS: the 256 threads form a 16 x 16 grid (ty, tx) and thread (ty, tx) owns the entries
 // (ty + 16 a, tx + 16 b), a <= b < NB (block-cyclic, so the shrinking trailing block stays spread over all threads;
-// blocks below the diagonal are never touched).  Column j: the 16 threads of grid row j % 16 (a quarter of one
-// wave; the pivot comes by v_readlane) scale row j by 1/sqrt(pivot) and publish it to LDS row j, with zeros at and
-// left of the diagonal; ONE workgroup barrier; every thread reads the values of row j that meet its rows and
-// columns and applies the rank-one update to its registers.  A zero in row j at k <= j leaves the finished rows
-// alone, so there is not one mask or branch in the update.  The right-hand side travels as an extra column (rr):
+// blocks below the diagonal are never touched).  Column j: every thread reads the values of row j (LDS) that meet
+// its rows and columns and applies the rank-one update to its registers; the 16 threads of grid row (j + 1) % 16
+// (a quarter of one wave; the pivot comes by v_readlane) scale row j + 1 by 1/sqrt(pivot) as soon as THEIR block
+// row is updated and publish it to LDS with zeros at and left of the diagonal; ONE workgroup barrier.  A zero in
+// row j at k <= j leaves the finished rows alone, so there is not one mask or branch in the update.  The right-hand side travels as an extra column (rr):
 // the forward substitution U'y = rhs is finished when the factor is.  An entry receives its updates for j = 0, 1,
 // ... in turn: the order of the oracle's dot products.  The diagonal of U is never stored, its reciprocal is.
 template <int NB>
@@ -258,53 +335,16 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     double *dinv = tmp;  // the reciprocals of U's diagonal
     __syncthreads();
     RSR_STAMP(2)
-    // ---- Cholesky + forward substitution
-#pragma unroll
-    for (int ja = 0; ja < NB; ++ja) {
-        if (16 * ja >= m) break;
-#pragma unroll 1
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * ja + jj;
-            if (j >= m) break;
-            double *Uj = U + (size_t)j * ld;
-            if ((tid >> 6) == (jj >> 2)) {  // the wave that holds grid row jj
-                const double piv = readlane_f64(u[ja][ja], ((jj & 3) << 4) | jj);
-                if (ty == jj) {
-                    if (!(piv > 0.0)) s_bad = 1;
-                    const double rinv = rsqrt_pivot(piv);
-#pragma unroll
-                    for (int ib = ja; ib < NB; ++ib) {
-                        if (16 * ib >= m) break;
-                        double v = u[ja][ib] * rinv;
-                        if (ib == ja) v = (tx > jj) ? v : 0.0;
-                        u[ja][ib] = v;
-                        Uj[tx + 16 * ib] = v;
-                    }
-                    rr[ja] = rr[ja] * rinv;
-                    if (tx == jj) {
-                        yv[j] = rr[ja];
-                        dinv[j] = rinv;
-                    }
-                }
-            }
-            __syncthreads();
-            const double yj = yv[j];
-            double ri[NB], rk[NB];
-#pragma unroll
-            for (int ib = ja; ib < NB; ++ib) {
-                if (16 * ib >= m) break;
-                ri[ib] = Uj[tx + 16 * ib];
-                rk[ib] = Uj[ty + 16 * ib];
-            }
-#pragma unroll
-            for (int ia = ja; ia < NB; ++ia) {
-                if (16 * ia >= m) break;
-#pragma unroll
-                for (int ib = ia; ib < NB; ++ib) u[ia][ib] = fma(-rk[ia], ri[ib], u[ia][ib]);
-                rr[ia] = fma(-rk[ia], yj, rr[ia]);
-            }
-        }
+    // ---- Cholesky + forward substitution: row 0, then one step per column (rsr_column)
+    int bad = 0;
+    if (tid < 64) {
+        const double piv = readlane_f64(u[0][0], 0);
+        bad = !(piv > 0.0);
+        rsr_publish_row<NB, 0>(u, rr, rsqrt_pivot(piv), 0, U, yv, dinv, ty, tx);
     }
+    __syncthreads();
+    rsr_block<NB, 0>(u, rr, m, ld, U, yv, dinv, bad, tid);
+    if (bad) s_bad = 1;
     __syncthreads();
     RSR_STAMP(3)
     if (s_bad) {
@@ -317,11 +357,12 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     if (tid < 64) {
         double r0 = (tid < m) ? yv[tid] : 0.0, r1 = (tid + 64 < m) ? yv[tid + 64] : 0.0;
         const double *c0 = U + (size_t)min(tid, m - 1) * ld, *c1 = U + (size_t)min(tid + 64, m - 1) * ld;
-        for (int i0 = m - 1; i0 >= 0; i0 -= 4) {
+        int i0 = m - 1;
+        for (; i0 >= 64; i0 -= 4) {  // theta_i of the upper half: lanes' second entries, every first entry takes a term
             double a0[4], a1[4], dv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int i = max(i0 - s, 0);
+                const int i = max(i0 - s, 64);
                 a0[s] = c0[i];
                 a1[s] = c1[i];
                 dv[s] = dinv[i];
@@ -329,12 +370,26 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int i = i0 - s;
+                if (i < 64) break;
+                const double ti = readlane_f64(r1, i - 64) * dv[s];
+                r0 = fma(-a0[s], ti, r0);
+                r1 = (tid + 64 < i) ? fma(-a1[s], ti, r1) : (tid + 64 == i ? ti : r1);
+            }
+        }
+        for (i0 = min(m - 1, 63); i0 >= 0; i0 -= 4) {
+            double a0[4], dv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = max(i0 - s, 0);
+                a0[s] = c0[i];
+                dv[s] = dinv[i];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = i0 - s;
                 if (i < 0) break;
-                const double num = (i < 64) ? readlane_f64(r0, i) : readlane_f64(r1, i - 64);
-                const double ti = num * dv[s];
-                if (tid == (i & 63)) { if (i < 64) r0 = ti; else r1 = ti; }
-                if (tid < i) r0 = fma(-a0[s], ti, r0);
-                if (tid + 64 < i) r1 = fma(-a1[s], ti, r1);
+                const double ti = readlane_f64(r0, i) * dv[s];
+                r0 = (tid < i) ? fma(-a0[s], ti, r0) : (tid == i ? ti : r0);
             }
         }
         if (tid < m) theta[tid] = r0;
