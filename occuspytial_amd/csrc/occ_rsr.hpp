@@ -271,12 +271,41 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
             u[ia][ib] = in ? gv : 0.0;
             qr[ia][ib] = in ? qv : 0.0;
         }
-    // ---- tau: rate = 1/2 theta' Qr theta + tau_rate (theta of the previous iteration)
-    for (int t = tid; t < m; t += nt) th[t] = theta[t];
+    // ---- while those loads fly: theta and the noise vector to LDS, then E eps2 (two threads per row: the halves of
+    // the sum) and the chunk sums of K'u -- none of it needs tau
+    for (int t = tid; t < m; t += nt) {
+        th[t] = theta[t];
+        yv[t] = block_normal(sc.key, (uint32_t)t, 0, it, STREAM_RSR);
+    }
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    {   // theta' Qr theta = the diagonal terms + twice the upper ones: every thread its entries, then a fixed-order
-        // reduction (the lanes of a wave by xor shuffles, the four waves by thread 0)
+    const int r = tid & 127, half = tid >> 7, hm = (m + 1) >> 1;
+    double es = 0.0, ku = 0.0;
+    if (r < m) {  // loads in batches (a load per loop trip would be one L2 round trip per term)
+        const int j1 = half ? m : hm;
+        for (int j0 = half ? hm : 0; j0 < j1; j0 += 16) {
+            double ev[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ev[s] = a.Et[(size_t)min(j0 + s, j1 - 1) * m + r];  // E[r][j], from the transposed copy
+#pragma unroll
+            for (int s = 0; s < 16; ++s) es = fma(ev[s], (j0 + s < j1) ? yv[j0 + s] : 0.0, es);
+        }
+        if (half) tmp[r] = es;
+        else {
+            const double *pr = a.rhs + (size_t)chain * a.nchunk * m + r;
+            for (int c0 = 0; c0 < a.nchunk; c0 += 8) {  // chunk order
+                double pv[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) pv[s] = pr[(size_t)min(c0 + s, a.nchunk - 1) * m];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) ku += (c0 + s < a.nchunk) ? pv[s] : 0.0;
+            }
+        }
+    }
+    // ---- tau: rate = 1/2 theta' Qr theta + tau_rate (theta of the previous iteration).  theta' Qr theta = the
+    // diagonal terms + twice the upper ones: every thread its entries, then a fixed-order reduction (the lanes of a
+    // wave by xor shuffles, the four waves by thread 0)
+    {
         double tk[NB], ti[NB], part = 0.0;
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
@@ -292,11 +321,11 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if ((tid & 63) == 0) tmp[tid >> 6] = part;
+        if ((tid & 63) == 0) rh[tid >> 6] = part;
     }
     __syncthreads();
     if (tid == 0) {
-        const double quad = ((tmp[0] + tmp[1]) + tmp[2]) + tmp[3];
+        const double quad = ((rh[0] + rh[1]) + rh[2]) + rh[3];
         const double rate = 0.5 * quad + a.tau_rate;
         Cursor g(sc.key, 0u, it, STREAM_TAU);
         const double tau = (1.0 / rate) * std_gamma(g, a.tau_shape);
@@ -304,7 +333,6 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
         s_scalar[0] = tau;
         s_scalar[1] = sqrt(tau);
     }
-    for (int j = tid; j < m; j += nt) th[j] = block_normal(sc.key, (uint32_t)j, 0, it, STREAM_RSR);  // theta is spent
     __syncthreads();
     const double tau = s_scalar[0], st = s_scalar[1];
     RSR_STAMP(1)
@@ -313,21 +341,7 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     for (int ia = 0; ia < NB; ++ia)
 #pragma unroll
         for (int ib = ia; ib < NB; ++ib) u[ia][ib] = fma(tau, qr[ia][ib], u[ia][ib]);
-    {   // E eps2: two threads per row (the halves of the sum), K'u: the workgroups' partial sums in chunk order
-        const int r = tid & 127, half = tid >> 7, hm = (m + 1) >> 1;
-        double t = 0.0;
-        if (r < m) {
-            const int j1 = half ? m : hm;
-            for (int j = half ? hm : 0; j < j1; ++j) t = fma(a.Et[(size_t)j * m + r], th[j], t);  // E[r][j], from the transposed copy
-            if (half) tmp[r] = t;
-        }
-        __syncthreads();
-        if (r < m && !half) {
-            double ku = 0.0;
-            for (int ch = 0; ch < a.nchunk; ++ch) ku += a.rhs[((size_t)chain * a.nchunk + ch) * m + r];
-            rh[r] = fma(st, t + tmp[r], ku);
-        }
-    }
+    if (r < m && !half) rh[r] = fma(st, es + tmp[r], ku);
     __syncthreads();
     double rr[NB];  // the right-hand side of this thread's rows (every thread of a grid row carries a copy)
 #pragma unroll
@@ -357,40 +371,40 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     if (tid < 64) {
         double r0 = (tid < m) ? yv[tid] : 0.0, r1 = (tid + 64 < m) ? yv[tid + 64] : 0.0;
         const double *c0 = U + (size_t)min(tid, m - 1) * ld, *c1 = U + (size_t)min(tid + 64, m - 1) * ld;
-        int i0 = m - 1;
-        for (; i0 >= 64; i0 -= 4) {  // theta_i of the upper half: lanes' second entries, every first entry takes a term
+        // theta_i of the upper half (lanes' second entries; every first entry takes a term), then of the lower half;
+        // the odd steps first, so that the groups of four carry no tail tests
+        auto upper = [&](int i, double a0, double a1, double dv) {
+            const double ti = readlane_f64(r1, i - 64) * dv;
+            r0 = fma(-a0, ti, r0);
+            r1 = (tid + 64 < i) ? fma(-a1, ti, r1) : (tid + 64 == i ? ti : r1);
+        };
+        auto lower = [&](int i, double a0, double dv) {
+            const double ti = readlane_f64(r0, i) * dv;
+            r0 = (tid < i) ? fma(-a0, ti, r0) : (tid == i ? ti : r0);
+        };
+        int i = m - 1;
+        for (; i >= 64 && ((i - 63) & 3); --i) upper(i, c0[i], c1[i], dinv[i]);
+        for (; i >= 64; i -= 4) {
             double a0[4], a1[4], dv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int i = max(i0 - s, 64);
-                a0[s] = c0[i];
-                a1[s] = c1[i];
-                dv[s] = dinv[i];
+                a0[s] = c0[i - s];
+                a1[s] = c1[i - s];
+                dv[s] = dinv[i - s];
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int i = i0 - s;
-                if (i < 64) break;
-                const double ti = readlane_f64(r1, i - 64) * dv[s];
-                r0 = fma(-a0[s], ti, r0);
-                r1 = (tid + 64 < i) ? fma(-a1[s], ti, r1) : (tid + 64 == i ? ti : r1);
-            }
+            for (int s = 0; s < 4; ++s) upper(i - s, a0[s], a1[s], dv[s]);
         }
-        for (i0 = min(m - 1, 63); i0 >= 0; i0 -= 4) {
+        for (; i >= 0 && ((i + 1) & 3); --i) lower(i, c0[i], dinv[i]);
+        for (; i >= 0; i -= 4) {
             double a0[4], dv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int i = max(i0 - s, 0);
-                a0[s] = c0[i];
-                dv[s] = dinv[i];
+                a0[s] = c0[i - s];
+                dv[s] = dinv[i - s];
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int i = i0 - s;
-                if (i < 0) break;
-                const double ti = readlane_f64(r0, i) * dv[s];
-                r0 = (tid < i) ? fma(-a0[s], ti, r0) : (tid == i ? ti : r0);
-            }
+            for (int s = 0; s < 4; ++s) lower(i - s, a0[s], dv[s]);
         }
         if (tid < m) theta[tid] = r0;
         if (tid + 64 < m) theta[tid + 64] = r1;
