@@ -24,7 +24,7 @@ namespace {
 thread_local std::string g_create_error;
 
 enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEGA_A, K_ALPHA_DRAW, K_Z_OB, K_ITER, K_GATE /* internal: not a profiled kind */,
-            K_RSR_RHS, K_RSR_GRAM, K_RSR_SOLVE, K_RSR_SPATIAL, K_RSR_BETA_PARTIAL /* reduced-rank model */ };
+            K_RSR_GRAM, K_RSR_SOLVE, K_RSR_ETA_BETA /* reduced-rank model */ };
 static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
 }  // namespace
@@ -166,7 +166,8 @@ KernelEI pick_beta_partial(int p)
 #define OCC_PICK_P(NAME, p) \
     ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
-KernelE pick_beta_partial_rsr(int p) { return OCC_PICK_P(k_beta_partial_rsr, p); }
+using KernelRsrE = void (*)(const RsrArgs, const Ctx *, ChainScalars *, Slot *, int, int);
+KernelRsrE pick_rsr_eta_beta(int p) { return OCC_PICK_P(k_rsr_eta_beta, p); }
 using KernelRsr = void (*)(const RsrArgs, int);
 KernelRsr pick_rsr_solve(int m)
 {
@@ -211,17 +212,13 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
-        case K_RSR_RHS: hipLaunchKernelGGL(k_rsr_rhs, dim3((unsigned)s->rsr.nchunk, (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
-        case K_RSR_GRAM: {
-            const int T = (s->rsr.m + 15) / 16;
-            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)(T * (T + 1) / 2), (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
+        case K_RSR_GRAM:
+            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e);
             break;
-        }
         case K_RSR_SOLVE:
             hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
             break;
-        case K_RSR_SPATIAL: hipLaunchKernelGGL(k_rsr_spatial, dim3((unsigned)((c.n + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e); break;
-        case K_RSR_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial_rsr(c.p), gs, blk, 0, st, OCC_ARGS); break;
+        case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
             if (s->iter_window == 8) hipLaunchKernelGGL(k_iter<8>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             else hipLaunchKernelGGL(k_iter<16>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
@@ -298,11 +295,9 @@ void launch_rsr_sequence(occ_sampler *s, hipStream_t st, int e)
     launch_kind(s, st, K_OMEGA_A, e);
     launch_kind(s, st, K_ALPHA_DRAW, e);
     launch_kind(s, st, K_NOISE, e, 1);
-    launch_kind(s, st, K_RSR_RHS, e);
     launch_kind(s, st, K_RSR_GRAM, e);
     launch_kind(s, st, K_RSR_SOLVE, e);
-    launch_kind(s, st, K_RSR_SPATIAL, e);
-    launch_kind(s, st, K_RSR_BETA_PARTIAL, e);
+    launch_kind(s, st, K_RSR_ETA_BETA, e);
     launch_kind(s, st, K_Z_OB, e);
 }
 
@@ -908,7 +903,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         for (int b = 0; b < 2; ++b) { r.omega_b[b] = c.omega_b[b]; r.enorm[b] = c.enorm[b]; }
         if ((rc = dev_alloc(s, &r.theta, (size_t)C * m))) return rc;
         if ((rc = dev_alloc(s, &r.gram, (size_t)C * m * m))) return rc;
-        r.nchunk = (n + 255) / 256;
+        r.nchunk = 1;
         if ((rc = dev_alloc(s, &r.rhs, (size_t)C * r.nchunk * m))) return rc;
         r.eta = c.eta;
         r.tau_rate = c.tau_rate; r.tau_shape = c.tau_shape;

@@ -8,15 +8,14 @@
 //   prec   = K' diag(omega_b) K + tau Qr                                      (m x m, dense, symmetric)
 //   rhs    = K'(k - omega_b X beta + sqrt(omega_b) eps1) + sqrt(tau) E eps2     (E E' = Qr; eps1 per site, eps2 per column)
 //   theta  = prec^-1 rhs  (upper Cholesky in LDS, two triangular solves),  eta = K theta
-// Four kernels, all chains batched on blockIdx.y, every sum in a fixed order (no atomics):
-//   k_rsr_rhs      K'u, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i: one workgroup per 256 sites stages u in
-//                  LDS, one thread per column reads K coalesced along the columns; partial sums per workgroup
-//   k_rsr_gram     K' diag(omega) K on the matrix cores: one wave per 16 x 16 output tile (upper triangle of tiles),
-//                  v_mfma_f64_16x16x4_f64 over four sites at a time, operands straight from global memory
-//   k_rsr_solve    one workgroup per chain: tau, prec and rhs assembled in LDS, right-looking Cholesky, the two
-//                  triangular solves by one wave, theta
-//   k_rsr_spatial  eta = K theta from the transposed copy of K (coalesced along the sites)
-// plus k_beta_partial_rsr: the partial sums of beta's system without the ICAR solve's projection step.
+// Three kernels, all chains batched on blockIdx.y, every sum in a fixed order (no atomics):
+//   k_rsr_gram     K' [diag(omega_b) K | u] on the matrix cores, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i: the
+//                  Gram matrix and K'u in one pass over K; one workgroup of 16 waves per 16 x 16 output tile (upper
+//                  triangle of tiles), v_mfma_f64_16x16x4_f64 over four sites at a time, operands from global memory
+//   k_rsr_solve    one workgroup per chain: tau, prec (in registers) and rhs assembled, right-looking Cholesky with
+//                  the forward substitution fused, back substitution by one wave, theta
+//   k_rsr_eta_beta eta = K theta from the transposed copy of K (coalesced along the sites) and, in the same thread,
+//                  the partial sums of beta's system (without the ICAR solve's projection step)
 #pragma once
 #include "occ_kernels.hpp"
 
@@ -36,75 +35,117 @@ struct RsrArgs {
     const double *omega_b[2], *enorm[2];
     double *theta;      // [C][m]
     double *gram;       // [C][m][m] (upper triangle of 16 x 16 tiles written)
-    double *rhs;        // [C][nchunk][m] partial sums of K'u per 256-site workgroup
+    double *rhs;        // [C][nchunk][m] K'u (nchunk = 1: k_rsr_gram writes the finished sums)
     int nchunk;
     double *eta;        // [C][n]
     double tau_rate, tau_shape;
     ChainScalars *scs;
 };
 
-__global__ void __launch_bounds__(256) k_rsr_rhs(const RsrArgs a, int e)
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int GRAM_WAVES = 16;    // waves per workgroup of k_rsr_gram
+constexpr int GRAM_UCHUNK = 2048;  // sites of u staged in LDS at a time by the K'u workgroups
+
+// Workgroups of k_rsr_gram per chain: the T (T + 1) / 2 tiles of the Gram matrix's upper triangle, T = ceil(m / 16),
+// then T workgroups for K'u (one per block of 16 columns of K).
+__host__ __device__ inline int rsr_gram_tiles(int m)
 {
-    __shared__ double s_u[256];
-    const int chain = blockIdx.y, chunk = blockIdx.x, i0 = chunk * 256;
-    const ChainScalars &sc = a.scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const uint32_t it = ctl.it;
-    const size_t co = (size_t)chain * a.n;
-    const int i = i0 + (int)threadIdx.x;
-    double u = 0.0;
-    if (i < a.n) {
-        const double om = a.omega_b[it & 1][co + i];
-        const double xb = xdot(a.Xt, a.n, i, sc.beta, a.p);
-        u = fma(sqrt(om), a.enorm[it & 1][co + i], fma(-om, xb, (double)a.z[co + i] - 0.5));
-    }
-    s_u[threadIdx.x] = u;
-    __syncthreads();
-    const int cnt = min(256, a.n - i0);
-    for (int col = threadIdx.x; col < a.m; col += 256) {
-        double acc = 0.0;
-        for (int ii = 0; ii < cnt; ++ii) acc = fma(a.K[(size_t)(i0 + ii) * a.m + col], s_u[ii], acc);
-        a.rhs[((size_t)chain * a.nchunk + chunk) * a.m + col] = acc;
+    const int T = (m + 15) / 16;
+    return T * (T + 1) / 2 + T;
+}
+
+// G = K' diag(omega) K and K'u, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i, one workgroup of 16 waves per
+// 16 x 16 tile of G's upper triangle and per 16 entries of K'u.  v_mfma_f64_16x16x4_f64 multiplies a 16 x 4 by a
+// 4 x 16 block: here A = K[:, a0:a0+16]' and B = (diag(omega) K)[:, c0:c0+16] over four consecutive sites.  Operand
+// layout (wave64, checked against numpy on the device): lane l carries A[l % 16][l / 16] and B[l / 16][l % 16]; it
+// receives D[4 v + l / 16][l % 16], v = 0..3.  Both operands are 16 consecutive doubles of a row of K per site:
+// 128-byte coalesced loads, no LDS.  A wave takes every 16th block of 32 sites (eight MFMAs), the loads of its next
+// block issued before the MFMAs of this one; the 16 partial tiles are added in wave order through LDS.
+// The K'u workgroups stage u (all 1024 threads, coalesced) in LDS and run the same loop with B = [u 0 ... 0].
+__device__ __forceinline__ void rsr_gram_load(const RsrArgs &a, const double *om, int i0, int lk, int ca, int cc, bool va, bool vc,
+                                              double (&av)[8], double (&bv)[8])
+{
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int i = i0 + 4 * t + lk;
+        const bool vi = i < a.n;
+        const int ii = vi ? i : 0;  // unconditional loads
+        const double w = om[ii];
+        const double ka = a.K[(size_t)ii * a.m + (va ? ca : 0)];
+        const double kc = a.K[(size_t)ii * a.m + (vc ? cc : 0)];
+        av[t] = (vi && va) ? ka : 0.0;
+        bv[t] = (vi && vc) ? kc * w : 0.0;
     }
 }
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-// G = K' diag(omega) K, one wave per 16 x 16 tile of the upper triangle.  v_mfma_f64_16x16x4_f64 multiplies a 16 x 4
-// by a 4 x 16 block: here A = (K[:, a0:a0+16] scaled by omega)' and B = K[:, c0:c0+16] over four consecutive sites.
-// Operand layout (wave64, checked against numpy on the device): lane l carries A[l % 16][l / 16] and B[l / 16][l % 16];
-// it receives D[4 v + l / 16][l % 16], v = 0..3.  Both operands are 16 consecutive doubles of a row of K per site: 128-byte coalesced loads, no LDS.
-__global__ void __launch_bounds__(256) k_rsr_gram(const RsrArgs a, int e)
+__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, int e)
 {
-    __shared__ double s_part[3][64][4];  // the partial tiles of waves 1..3
+    __shared__ double s_part[GRAM_WAVES - 1][64][4];  // the partial tiles of waves 1..15
+    __shared__ double s_u[GRAM_UCHUNK];
     const int chain = blockIdx.y;
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const int T = (a.m + 15) / 16;
-    int ta = 0, rem = (int)blockIdx.x;  // upper triangle of tiles, enumerated row by row
-    while (rem >= T - ta) { rem -= T - ta; ++ta; }
-    const int tc = ta + rem;
+    const int T = (a.m + 15) / 16, ntile = T * (T + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
-    const int ca = ta * 16 + lc, cc = tc * 16 + lc;
-    const bool va = ca < a.m, vc = cc < a.m;
-    const double *om = a.omega_b[ctl.it & 1] + (size_t)chain * a.n;
+    const size_t co = (size_t)chain * a.n;
+    const double *om = a.omega_b[ctl.it & 1] + co;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    // the four waves of the workgroup take every fourth block of 32 sites; eight MFMAs per trip, their loads in
-    // flight together
-    for (int i0 = wave * 32; i0 < a.n; i0 += 128) {
-        double av[8], bv[8];
+    int ta, tc;
+    const bool utile = (int)blockIdx.x >= ntile;
+    if (!utile) {
+        ta = 0;
+        int rem = (int)blockIdx.x;  // upper triangle of tiles, enumerated row by row
+        while (rem >= T - ta) { rem -= T - ta; ++ta; }
+        tc = ta + rem;
+        const int ca = ta * 16 + lc, cc = tc * 16 + lc;
+        const bool va = ca < a.m, vc = cc < a.m;
+        double av[8], bv[8], an[8], bn[8];
+        int i0 = wave * 32;
+        if (i0 < a.n) rsr_gram_load(a, om, i0, lk, ca, cc, va, vc, av, bv);
+        for (; i0 < a.n; i0 += 32 * GRAM_WAVES) {
+            const int i1 = i0 + 32 * GRAM_WAVES;
+            if (i1 < a.n) rsr_gram_load(a, om, i1, lk, ca, cc, va, vc, an, bn);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int i = i0 + 4 * t + lk;
-            const bool vi = i < a.n;
-            const double w = vi ? om[i] : 0.0;
-            av[t] = (vi && va) ? a.K[(size_t)i * a.m + ca] * w : 0.0;
-            bv[t] = (vi && vc) ? a.K[(size_t)i * a.m + cc] : 0.0;
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                av[t] = an[t];
+                bv[t] = bn[t];
+            }
         }
+    } else {
+        ta = (int)blockIdx.x - ntile;
+        tc = -1;
+        const int ca = ta * 16 + lc;
+        const bool va = ca < a.m;
+        const double *en = a.enorm[ctl.it & 1] + co;
+        const uint8_t *z = a.z + co;
+        for (int c0 = 0; c0 < a.n; c0 += GRAM_UCHUNK) {
+            const int cnt = min(GRAM_UCHUNK, a.n - c0);
+            for (int t = threadIdx.x; t < cnt; t += 64 * GRAM_WAVES) {
+                const int i = c0 + t;
+                const double w = om[i];
+                const double xb = xdot(a.Xt, a.n, i, sc.beta, a.p);
+                s_u[t] = fma(sqrt(w), en[i], fma(-w, xb, (double)z[i] - 0.5));
+            }
+            __syncthreads();
+            for (int i0 = wave * 32; i0 < cnt; i0 += 32 * GRAM_WAVES) {
+                double av[8], bv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
+                for (int t = 0; t < 8; ++t) {
+                    const int il = i0 + 4 * t + lk;
+                    const bool vi = il < cnt;
+                    const double ka = a.K[(size_t)(c0 + (vi ? il : 0)) * a.m + (va ? ca : 0)];
+                    av[t] = (vi && va) ? ka : 0.0;
+                    bv[t] = (vi && lc == 0) ? s_u[vi ? il : 0] : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -115,9 +156,12 @@ __global__ void __launch_bounds__(256) k_rsr_gram(const RsrArgs a, int e)
     double *G = a.gram + (size_t)chain * a.m * a.m;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const double t = ((acc[v] + s_part[0][lane][v]) + s_part[1][lane][v]) + s_part[2][lane][v];  // fixed order
-        const int r = ta * 16 + 4 * v + lk;
-        if (r < a.m && vc) G[(size_t)r * a.m + cc] = t;
+        double t = acc[v];
+#pragma unroll
+        for (int w = 0; w < GRAM_WAVES - 1; ++w) t += s_part[w][lane][v];  // fixed order
+        const int r = ta * 16 + 4 * v + lk, cc = tc * 16 + lc;
+        if (!utile && r < a.m && cc < a.m) G[(size_t)r * a.m + cc] = t;
+        if (utile && r < a.m && lc == 0) a.rhs[(size_t)chain * a.m + r] = t;
     }
 }
 
@@ -412,25 +456,13 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     RSR_STAMP(4)
 }
 
-__global__ void __launch_bounds__(256) k_rsr_spatial(const RsrArgs a, int e)
+// eta = K theta from the transposed copy of K (coalesced along the sites; the column loop's loads go out in batches
+// of 16), then, in the same thread, the site's terms of beta's system and their block partial sums (k_beta_partial
+// without the ICAR solve's projection step).
+template <int P>
+__global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS)
 {
     __shared__ double s_th[RSR_MAX_DIM];
-    const int chain = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const ChainScalars &sc = a.scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
-    for (int t = threadIdx.x; t < a.m; t += 256) s_th[t] = a.theta[(size_t)chain * a.m + t];
-    __syncthreads();
-    if (i >= a.n) return;
-    double acc = 0.0;
-    for (int c = 0; c < a.m; ++c) acc = fma(a.Kt[(size_t)c * a.n + i], s_th[c], acc);
-    a.eta[(size_t)chain * a.n + i] = acc;
-}
-
-// Partial sums of beta's system from eta = K theta (k_beta_partial without the ICAR solve's projection).
-template <int P>
-__global__ void __launch_bounds__(256) k_beta_partial_rsr(OCC_KARGS)
-{
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
@@ -447,13 +479,23 @@ __global__ void __launch_bounds__(256) k_beta_partial_rsr(OCC_KARGS)
         }
     }
     if (skip) return;
-    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+    for (int t = threadIdx.x; t < a.m; t += blockDim.x) s_th[t] = a.theta[(size_t)chain * a.m + t];
+    __syncthreads();
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x, il = min(i, n - 1);
+    double eta = 0.0;
+    for (int c0 = 0; c0 < a.m; c0 += 16) {
+        double kv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) kv[s] = a.Kt[(size_t)min(c0 + s, a.m - 1) * n + il];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) eta = fma(kv[s], (c0 + s < a.m) ? s_th[c0 + s] : 0.0, eta);
+    }
     double acc[nacc(P)];
 #pragma unroll
     for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
-        const double eta = c.eta[ci];
+        c.eta[ci] = eta;
         const double om = c.omega_b[ctl.it & 1][ci];
         const double tt = beta_rhs_term(om, eta, (double)c.z[ci]);
         double x[P];
