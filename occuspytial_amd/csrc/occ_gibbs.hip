@@ -213,7 +213,7 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
-            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e);
+            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
             break;
         case K_RSR_SOLVE:
             hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
@@ -379,7 +379,7 @@ int build_graph(occ_sampler *s, int cap)
     HIP_TRY(hipStreamSynchronize(s->stream));
     destroy_head(s);
     int rc;
-    if (s->rsr.m > 0) {  // reduced-rank model: GRAPH_SEQ iterations (alternating parity) on the main stream
+    if (s->rsr.m > 0 && !s->flag_sync) {  // reduced-rank model: GRAPH_SEQ iterations (alternating parity) on the main stream
         const bool old_sync = s->launch_sync;
         s->launch_sync = false;
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -396,8 +396,15 @@ int build_graph(occ_sampler *s, int cap)
         // the device counters of Ctx::sync
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         for (int t = 0; t < GRAPH_SEQ; ++t) {
-            launch_kind(s, s->stream, K_ITER, s->parity ^ (t & 1));
-            launch_kind(s, s->stream, K_Z_OB, s->parity ^ (t & 1));
+            const int e = s->parity ^ (t & 1);
+            if (s->rsr.m > 0) {  // reduced-rank model: k_rsr_gram opens the sequence as k_iter does
+                launch_kind(s, s->stream, K_RSR_GRAM, e);
+                launch_kind(s, s->stream, K_RSR_SOLVE, e);
+                launch_kind(s, s->stream, K_RSR_ETA_BETA, e);
+            } else {
+                launch_kind(s, s->stream, K_ITER, e);
+            }
+            launch_kind(s, s->stream, K_Z_OB, e);
         }
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
@@ -471,12 +478,12 @@ int build_graph(occ_sampler *s, int cap)
 int enqueue_sequence(occ_sampler *s)
 {
     const int e = s->parity;
-    if (s->rsr.m > 0) {  // GRAPH_SEQ sequences
+    if (s->flag_sync) {  // GRAPH_SEQ sequences on each stream
+        HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
         return OCC_OK;
     }
-    if (s->flag_sync) {  // GRAPH_SEQ sequences on each stream
-        HIP_TRY(hipGraphLaunch(s->tail[0], s->side));
+    if (s->rsr.m > 0) {  // GRAPH_SEQ sequences
         HIP_TRY(hipGraphLaunch(s->head[0], s->stream));
         return OCC_OK;
     }
@@ -768,8 +775,9 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         const int ncu = prop.multiProcessorCount;
         // at least 5/8 of the device for the main stream: k_z_ob's Polya-Gamma draws run there too
         int nmain = std::max(((s->iter.nbg * C + 7) / 8) * 8, (ncu * 5 / 64) * 8);
+        if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
-        if (s->persistent && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
+        if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
             HIP_TRY(hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()));
@@ -892,7 +900,10 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             for (int a = 0; a < m; ++a) Kth[(size_t)a * n + i] = Kh[(size_t)i * m + a];
         RsrArgs &r = s->rsr;
         r.n = n; r.m = m; r.p = p; r.C = C;
-        if ((rc = upload(s, &r.K, Kh))) return rc;
+        r.ldk = 16 * ((m + 15) / 16);
+        std::vector<double> Kp((size_t)n * r.ldk, 0.0);  // rows padded to whole 128-byte lines
+        for (int i = 0; i < n; ++i) std::copy(Kh.begin() + (size_t)i * m, Kh.begin() + (size_t)(i + 1) * m, Kp.begin() + (size_t)i * r.ldk);
+        if ((rc = upload(s, &r.K, Kp))) return rc;
         if ((rc = upload(s, &r.Kt, Kth))) return rc;
         if ((rc = upload(s, &r.Qr, Qh))) return rc;
         std::vector<double> Eth((size_t)m * m);
@@ -908,6 +919,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         r.eta = c.eta;
         r.tau_rate = c.tau_rate; r.tau_shape = c.tau_shape;
         r.scs = c.sc;
+        r.sync = c.sync;
         s->rsr_K_host = Kh;
         HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(double) * rsr_solve_lds_doubles(m))));

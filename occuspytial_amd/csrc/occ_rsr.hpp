@@ -25,8 +25,8 @@ constexpr int RSR_MAX_DIM = 128;  // m x m doubles of LDS for the Cholesky facto
 constexpr uint32_t STREAM_RSR = 9;
 
 struct RsrArgs {
-    int n, m, p, C;
-    const double *K;    // [n][m]
+    int n, m, p, C, ldk;
+    const double *K;    // [n][ldk], ldk = 16 ceil(m / 16): rows zero-padded to whole 128-byte lines
     const double *Kt;   // [m][n]
     const double *Qr;   // [m][m]
     const double *Et;   // [m][m], the eigenfactor E of Qr (E E' = Qr) TRANSPOSED: Et[j][r] = E[r][j]
@@ -40,11 +40,20 @@ struct RsrArgs {
     double *eta;        // [C][n]
     double tau_rate, tau_shape;
     ChainScalars *scs;
+    unsigned *sync;     // hand-over counters of the two streams (Ctx::sync), or null
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int GRAM_WAVES = 16;    // waves per workgroup of k_rsr_gram
+#ifdef OCC_SOLVE_STAMPS
+#define GRAM_STAMP(pt) if (chain == 0 && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ntile)) g_solve_stamps[16 + (blockIdx.x == 0 ? 0 : 4) + (pt)] = wall_clock64();
+#else
+#define GRAM_STAMP(pt)
+#endif
+#ifndef OCC_GRAM_WAVES
+#define OCC_GRAM_WAVES 16
+#endif
+constexpr int GRAM_WAVES = OCC_GRAM_WAVES;  // waves per workgroup of k_rsr_gram
 constexpr int GRAM_UCHUNK = 2048;  // sites of u staged in LDS at a time by the K'u workgroups
 
 // Workgroups of k_rsr_gram per chain: the T (T + 1) / 2 tiles of the Gram matrix's upper triangle, T = ceil(m / 16),
@@ -63,27 +72,29 @@ __host__ __device__ inline int rsr_gram_tiles(int m)
 // 128-byte coalesced loads, no LDS.  A wave takes every 16th block of 32 sites (eight MFMAs), the loads of its next
 // block issued before the MFMAs of this one; the 16 partial tiles are added in wave order through LDS.
 // The K'u workgroups stage u (all 1024 threads, coalesced) in LDS and run the same loop with B = [u 0 ... 0].
-__device__ __forceinline__ void rsr_gram_load(const RsrArgs &a, const double *om, int i0, int lk, int ca, int cc, bool va, bool vc,
-                                              double (&av)[8], double (&bv)[8])
+__device__ __forceinline__ void rsr_gram_load(const RsrArgs &a, const double *om, int i0, int lk, int ca, int cc, double (&av)[8], double (&bv)[8])
 {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int i = i0 + 4 * t + lk;
         const bool vi = i < a.n;
-        const int ii = vi ? i : 0;  // unconditional loads
-        const double w = om[ii];
-        const double ka = a.K[(size_t)ii * a.m + (va ? ca : 0)];
-        const double kc = a.K[(size_t)ii * a.m + (vc ? cc : 0)];
-        av[t] = (vi && va) ? ka : 0.0;
-        bv[t] = (vi && vc) ? kc * w : 0.0;
+        const int ii = vi ? i : 0;  // unconditional loads; the padding columns of K hold zeros
+        const double w = vi ? om[ii] : 0.0;
+        av[t] = a.K[(size_t)ii * a.ldk + ca];
+        bv[t] = a.K[(size_t)ii * a.ldk + cc] * w;
     }
 }
 
-__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, int e)
+__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, int e, int sync_on)
 {
     __shared__ double s_part[GRAM_WAVES - 1][64][4];  // the partial tiles of waves 1..15
     __shared__ double s_u[GRAM_UCHUNK];
+    __shared__ int s_noise_ok;
     const int chain = blockIdx.y;
+    // first kernel of the main stream's sequence (as k_iter in the ICAR model): k_z_ob of the previous sequence is
+    // complete, the side stream may start this sequence.  Said before anything can return or wait.
+    const bool synced = sync_on && a.sync != nullptr;
+    if (synced && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync_set(a.sync + SYNC_MAIN, a.sync[SYNC_MAIN_SEQ + e]);
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
@@ -94,19 +105,22 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     int ta, tc;
     const bool utile = (int)blockIdx.x >= ntile;
+    GRAM_STAMP(0)
+#ifdef OCC_SOLVE_STAMPS
+    if (chain == 0 && blockIdx.x == 0 && lane == 0) g_solve_stamps[40 + wave] = wall_clock64();
+#endif
     if (!utile) {
         ta = 0;
         int rem = (int)blockIdx.x;  // upper triangle of tiles, enumerated row by row
         while (rem >= T - ta) { rem -= T - ta; ++ta; }
         tc = ta + rem;
         const int ca = ta * 16 + lc, cc = tc * 16 + lc;
-        const bool va = ca < a.m, vc = cc < a.m;
         double av[8], bv[8], an[8], bn[8];
         int i0 = wave * 32;
-        if (i0 < a.n) rsr_gram_load(a, om, i0, lk, ca, cc, va, vc, av, bv);
+        if (i0 < a.n) rsr_gram_load(a, om, i0, lk, ca, cc, av, bv);
         for (; i0 < a.n; i0 += 32 * GRAM_WAVES) {
             const int i1 = i0 + 32 * GRAM_WAVES;
-            if (i1 < a.n) rsr_gram_load(a, om, i1, lk, ca, cc, va, vc, an, bn);
+            if (i1 < a.n) rsr_gram_load(a, om, i1, lk, ca, cc, an, bn);
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
 #pragma unroll
@@ -119,26 +133,42 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
         ta = (int)blockIdx.x - ntile;
         tc = -1;
         const int ca = ta * 16 + lc;
-        const bool va = ca < a.m;
         const double *en = a.enorm[ctl.it & 1] + co;
         const uint8_t *z = a.z + co;
+        if (synced) {  // the noise of this iteration comes from the side stream's previous sequence
+            if (threadIdx.x == 0) s_noise_ok = sync_wait(a.sync + SYNC_NOISE, a.sync[SYNC_MAIN_SEQ + e]) ? 1 : 0;
+            __syncthreads();
+            if (!s_noise_ok) {
+                if (threadIdx.x == 0) a.scs[chain].err = -2;  // OCC_E_HIP: the side stream never arrived
+                return;
+            }
+        }
+        double beta[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) beta[j] = (j < a.p) ? sc.beta[min(j, a.p - 1)] : 0.0;
         for (int c0 = 0; c0 < a.n; c0 += GRAM_UCHUNK) {
             const int cnt = min(GRAM_UCHUNK, a.n - c0);
             for (int t = threadIdx.x; t < cnt; t += 64 * GRAM_WAVES) {
                 const int i = c0 + t;
-                const double w = om[i];
-                const double xb = xdot(a.Xt, a.n, i, sc.beta, a.p);
-                s_u[t] = fma(sqrt(w), en[i], fma(-w, xb, (double)z[i] - 0.5));
+                const double w = om[i], ev = en[i], zv = (double)z[i];
+                double x[MAXC];
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) x[j] = a.Xt[(size_t)min(j, a.p - 1) * a.n + i];  // all loads out before the sum
+                double xb = 0.0;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) xb = fma(x[j], beta[j], xb);
+                s_u[t] = fma(sqrt(w), ev, fma(-w, xb, zv - 0.5));
             }
             __syncthreads();
+            if (c0 == 0) { GRAM_STAMP(2) }
             for (int i0 = wave * 32; i0 < cnt; i0 += 32 * GRAM_WAVES) {
                 double av[8], bv[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int il = i0 + 4 * t + lk;
                     const bool vi = il < cnt;
-                    const double ka = a.K[(size_t)(c0 + (vi ? il : 0)) * a.m + (va ? ca : 0)];
-                    av[t] = (vi && va) ? ka : 0.0;
+                    const double ka = a.K[(size_t)(c0 + (vi ? il : 0)) * a.ldk + ca];
+                    av[t] = vi ? ka : 0.0;
                     bv[t] = (vi && lc == 0) ? s_u[vi ? il : 0] : 0.0;
                 }
 #pragma unroll
@@ -147,12 +177,17 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
             __syncthreads();
         }
     }
+    GRAM_STAMP(1)
+#ifdef OCC_SOLVE_STAMPS
+    if (chain == 0 && blockIdx.x == 0 && lane == 0) g_solve_stamps[24 + wave] = wall_clock64();
+#endif
     if (wave > 0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) s_part[wave - 1][lane][v] = acc[v];
     }
     __syncthreads();
     if (wave != 0) return;
+    GRAM_STAMP(2)
     double *G = a.gram + (size_t)chain * a.m * a.m;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -163,6 +198,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
         if (!utile && r < a.m && cc < a.m) G[(size_t)r * a.m + cc] = t;
         if (utile && r < a.m && lc == 0) a.rhs[(size_t)chain * a.m + r] = t;
     }
+    GRAM_STAMP(3)
 }
 
 // Row stride of the Cholesky factor in LDS: odd, so that a column walk (one row per lane) touches every bank once.

@@ -462,8 +462,14 @@ def test_reduced_rank_every_block_count_matches_oracle(oracle, q):
     eng.close()
 
 
-def test_reduced_rank_graph_replay_equals_stepping_and_batching():
-    """occ_run (graph of two iterations) == occ_step, and chain c of a batch == the same chain alone: bitwise."""
+@pytest.mark.parametrize('env', [{}, {'OCC_CU_SPLIT': '0'}, {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EVENT_SYNC': '1'}],
+                         ids=['two-streams-flag-handovers', 'no-cu-partition', 'one-stream', 'no-flag-handovers'])
+def test_reduced_rank_graph_replay_equals_stepping_and_batching(monkeypatch, env):
+    """occ_run (graphs of two iterations; by default two streams on disjoint CUs handing over through device
+    counters, k_rsr_gram opening the main sequence) == occ_step (one stream), and chain c of a batch == the same
+    chain alone: bitwise, in every scheduling mode."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     from occuspytial_amd._engine import Engine
     from occuspytial_amd._problem import FlatProblem
     from occuspytial_amd.utils import make_lattice_problem

@@ -34,4 +34,11 @@ names = ['tau (Qr matvec, gamma draw)', 'rhs (noise, E matvec, chunk sums)', 'Ch
 for i, nm in enumerate(names):
     print('%-36s %8.2f us' % (nm, (t[i + 1] - t[i]) / 100.0))
 print('%-36s %8.2f us' % ('total', (t[4] - t[0]) / 100.0))
+gs = np.array(buf[16:24], dtype=np.int64)
+print('k_rsr_gram tile 0: loop %.2f us, reduction+store %.2f us; K\'u workgroup: u staged %.2f us, whole %.2f us' % (
+    (gs[1] - gs[0]) / 100.0, (gs[3] - gs[1]) / 100.0, (gs[6] - gs[4]) / 100.0, (gs[7] - gs[4]) / 100.0))
+ws = np.array(buf[24:40], dtype=np.int64)
+print('tile 0, loop end of waves 0..15 after kernel start (us):', ' '.join('%.1f' % ((w - gs[0]) / 100.0) for w in ws))
+w0 = np.array(buf[40:56], dtype=np.int64)
+print('tile 0, start of waves 0..15 after kernel start (us):', ' '.join('%.1f' % ((w - gs[0]) / 100.0) for w in w0))
 eng.close()

@@ -1,7 +1,11 @@
 """Developer script: LogitRSRGibbs engine timing.  python tools/rsr_time.py rows cols m chains iters"""
 import sys, time
 sys.path.insert(0, '.')
+import os
 import numpy as np
+if os.environ.get('OCC_LIB_PATH'):
+    import occuspytial_amd._lib as L
+    L.LIB_PATH = os.environ['OCC_LIB_PATH']
 from occuspytial_amd._engine import Engine
 from occuspytial_amd._problem import FlatProblem, chain_generators
 from occuspytial_amd.utils import make_lattice_problem
