@@ -119,8 +119,9 @@ typedef struct occ_stats {
     int64_t solves;          /* eta solves since creation (all chains) */
     double last_run_ms;      /* device time of the last occ_run (HIP events on the engine's stream) */
     int32_t n_blocks_sites, n_blocks_rows, threads_per_block, n_chains;
-    int32_t persistent_solve; /* 1: fused iteration kernel with the persistent eta solve (k_iter + k_z_ob per
-                                 iteration), 0: one launch per MINRES step, omega_a/alpha/noise on a side stream */
+    int32_t persistent_solve; /* 1, 2: fused iteration kernel with the persistent eta solve (k_iter + k_z_ob per iteration;
+                                 2: one XCD per chain, its workgroups exchange through that XCD's L2), 0: one launch per
+                                 MINRES step, omega_a/alpha/noise on a side stream */
     int32_t solve_workgroups; /* workgroups per chain of the persistent solve */
     int32_t main_stream_cus;  /* > 0: CUs reserved for the main stream (k_iter, k_z_ob); the side stream has the others */
     int32_t pad_;

@@ -49,6 +49,7 @@ struct occ_sampler {
     // otherwise one launch per MINRES step on the main stream and omega_a / alpha / noise on the side stream
     bool persistent = false;
     int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
+    bool xcd_local = false;  // k_iter<8, 1>: one XCD per chain, exchange through that XCD's L2 (occ_iter.hpp)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -220,8 +221,9 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
-            if (s->iter_window == 8) hipLaunchKernelGGL(k_iter<8>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else hipLaunchKernelGGL(k_iter<16>, dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else hipLaunchKernelGGL((k_iter<16, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
     }
@@ -792,6 +794,33 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
         }
     }
+    // ---- one XCD per chain?  Needs the 8-wide window (two workgroups per CU), at most one chain per XCD, the
+    // chain's flags in one wave's lanes, room for nbg workgroups on the main stream's CUs of an XCD -- and a
+    // probe launch that finds every column of the (8, nbg) grid on one XCD of its own.
+    if (s->persistent && s->iter_window == 8 && C <= XL_SLOTS && s->iter.nbg <= 64 && !std::getenv("OCC_NO_XCD_LOCAL")) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        const int cus_per_xcd = (s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount) / XL_SLOTS;
+        if (2 * cus_per_xcd >= s->iter.nbg) {
+            const int nbg = s->iter.nbg;
+            unsigned *probe = nullptr;
+            if ((rc = dev_alloc(s, &probe, (size_t)XL_SLOTS * nbg))) return rc;
+            bool ok = true;
+            for (int rep = 0; rep < 3 && ok; ++rep) {  // the dealing must not depend on what ran before
+                hipLaunchKernelGGL(k_xl_probe, dim3(XL_SLOTS, (unsigned)nbg), dim3(ITER_WG), 0, s->stream, probe, nbg);
+                std::vector<unsigned> h((size_t)XL_SLOTS * nbg);
+                HIP_TRY(hipMemcpyAsync(h.data(), probe, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                unsigned seen = 0;
+                for (int x = 0; x < XL_SLOTS && ok; ++x) {
+                    for (int y = 0; y < nbg; ++y) ok = ok && h[(size_t)x * nbg + y] == h[(size_t)x * nbg] && h[(size_t)x * nbg] != 0;
+                    ok = ok && !(seen & (1u << h[(size_t)x * nbg]));
+                    seen |= 1u << h[(size_t)x * nbg];
+                }
+            }
+            s->xcd_local = ok;
+        }
+    }
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
@@ -1293,7 +1322,7 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->n_blocks_rows = s->ctx.nb_r;
     out->threads_per_block = s->tpb;
     out->n_chains = s->ctx.C;
-    out->persistent_solve = s->persistent ? 1 : 0;
+    out->persistent_solve = s->persistent ? (s->xcd_local ? 2 : 1) : 0;
     out->solve_workgroups = s->iter.nbg;
     out->main_stream_cus = s->main_cus;
     out->profile_minres_iterations = s->profile_minres_iterations;

@@ -16,12 +16,21 @@
 // per solve have to be guessed when the graph is captured.  Here the solve runs exactly the steps it needs and
 // chains do not wait for each other inside the launch.
 //
-// Exchange between the workgroups of a chain: payload stored write-through (sc1), every storing wave drained,
-// one lane adds to the chain's arrival counter and polls it, then every load of exchanged bytes is an sc1 load
-// (per-CU L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs' L2s are not coherent with
-// each other).  Only g = A p (16 B per site) and four partial sums per 64-site slice are exchanged per step:
-// p_{k-2}, p_{k-3} at the NEIGHBOURS of a site stay in the registers of the lane that re-formed them.  The arrival
-// counter is monotonic over the whole run (ChainScalars::bar_base).
+// Exchange between the workgroups of a chain, two forms (template parameter XL).  Only g = A p (16 B per site) and
+// four partial sums per 64-site slice are exchanged per step: p_{k-2}, p_{k-3} at the NEIGHBOURS of a site stay in
+// the registers of the lane that re-formed them.
+//   XL = 0, any placement: payload stored write-through (sc1), every storing wave drained, one lane adds to the
+//     chain's arrival counter (agent scope) and polls it, then every load of exchanged bytes is an sc1 load (per-CU
+//     L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs' L2s are not coherent with each
+//     other), and every hop is a round trip to the memory side: 2.3 us per store -> barrier -> load (tools/xcc_probe4).
+//   XL = 1, ONE XCD PER CHAIN: the grid is (8, nbg) and the chain is blockIdx.x -- workgroups are dealt to the eight
+//     XCDs round-robin in linear order, so all workgroups of a chain share one XCD and its L2.  Payload and one
+//     arrival FLAG per workgroup are PLAIN stores (they stay in that L2), every load of exchanged bytes and every
+//     poll is an sc1 load (L1 bypassed, L2-served): 0.7 us per store -> barrier -> load, no atomics.  A flag carries
+//     the XCC_ID of its writer and every poll checks it against the reader's: a launch whose placement differs
+//     fails loudly (OCC_E_HIP) instead of reading another XCD's stale lines.  The host verifies the placement with
+//     a probe launch before it takes this form (create_impl).
+// The arrival counter / flag values are monotonic over the whole run (ChainScalars::bar_base).
 //
 // The arithmetic is that of the stand-alone kernels, through the same functions (minres_pre/post, kry_form_*,
 // eta_rhs_site, ...), with partial sums per 64-site slice reduced in the same order: k_iter, the
@@ -35,7 +44,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
-constexpr int BAR_STRIDE = 32;                  // unsigned words per chain in IterArgs::bar (128 B)
+constexpr int BAR_STRIDE = 64;                  // unsigned words per chain in IterArgs::bar: the counter, or one flag per workgroup
+constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch = XCDs the grid's x dimension walks over
 
 // Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
 // chain 0 / workgroup 0; the product build compiles the hooks away.
@@ -80,10 +90,11 @@ __device__ __forceinline__ double2 unpack_d2(v4u r)
 {
     return make_double2(__hiloint2double((int)r.y, (int)r.x), __hiloint2double((int)r.w, (int)r.z));
 }
-// 16-byte write-through store / L1-bypassing load (aux 16 = sc1)
-__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, double2 v)
+// 16-byte write-through store / L1-bypassing load (aux 16 = sc1); XL: a plain store, the line stays in the XCD's L2
+template <int XL>
+__device__ __forceinline__ void store_x(__amdgpu_buffer_rsrc_t r, int byte_off, double2 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(pack_d2(v), r, byte_off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_d2(v), r, byte_off, 0, XL ? 0 : 16);
 }
 __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
@@ -95,16 +106,41 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
 // adds to the chain's counter.  WAIT: that lane polls until the counter has reached `target` arrivals
 // (compared modulo 2^32); `fail_flag` (LDS) is set when the poll gave up (a workgroup of the chain is not
 // running).
+//
+// XL form: ARRIVE stores the workgroup's flag = (barrier number << 4) | XCC_ID (plain store); WAIT: the first wave
+// loads all nbg (<= 64) flags of the chain, one per lane (sc1), until every flag has reached the barrier number,
+// then checks that every writer sits on the reader's XCD.
+#define BAR_STAMP(pt)
 #define OCC_CHAIN_ARRIVE()                                                                                 \
     do {                                                                                                   \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        BAR_STAMP(3)                                                                                       \
         __syncthreads();                                                                                   \
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    } while (0)
-#define OCC_CHAIN_WAIT(target_expr, fail_flag)                                                             \
-    do {                                                                                                   \
         if (threadIdx.x == 0) {                                                                            \
-            const unsigned target_ = (target_expr);                                                        \
+            if (XL) __builtin_amdgcn_raw_buffer_store_b32(((bar_base + nbar) << 4) | my_xcc, fbuf, wg * 4, 0, 0); \
+            else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+        }                                                                                                  \
+        BAR_STAMP(4)                                                                                       \
+    } while (0)
+#define OCC_CHAIN_WAIT(fail_flag)                                                                          \
+    do {                                                                                                   \
+        if (XL) {                                                                                          \
+            if (threadIdx.x < 64) {                                                                        \
+                const unsigned want_ = (bar_base + nbar) << 4;                                             \
+                int fail_ = 0;                                                                             \
+                unsigned spins_ = 0, flag_;                                                                \
+                for (;;) {                                                                                 \
+                    flag_ = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fbuf, (int)threadIdx.x * 4, 0, 16); /* lanes >= nbg: out of range, 0 */ \
+                    if ((int)threadIdx.x >= ia.nbg) flag_ = want_ | my_xcc;                                \
+                    if (__all((int)((flag_ & ~15u) - want_) >= 0)) break;                                  \
+                    __builtin_amdgcn_s_sleep(1);                                                           \
+                    if (++spins_ > ITER_SPIN_LIMIT) { fail_ = 1; break; }                                  \
+                }                                                                                          \
+                if (!fail_ && __any((flag_ & 15u) != my_xcc)) fail_ = 1; /* a workgroup of the chain on another XCD */ \
+                if (threadIdx.x == 0) fail_flag = fail_;                                                   \
+            }                                                                                              \
+        } else if (threadIdx.x == 0) {                                                                     \
+            const unsigned target_ = bar_base + nbar * (unsigned)ia.nbg;                                   \
             int fail_ = 0;                                                                                 \
             unsigned spins_ = 0;                                                                           \
             while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target_) < 0) { \
@@ -113,13 +149,14 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
             }                                                                                              \
             fail_flag = fail_;                                                                             \
         }                                                                                                  \
+        BAR_STAMP(5)                                                                                       \
         __syncthreads();                                                                                   \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* compiler only: no load moves above the poll */ \
     } while (0)
-#define OCC_CHAIN_BARRIER(target_expr, fail_flag)                                                          \
+#define OCC_CHAIN_BARRIER(fail_flag)                                                                       \
     do {                                                                                                   \
         OCC_CHAIN_ARRIVE();                                                                                \
-        OCC_CHAIN_WAIT(target_expr, fail_flag);                                                            \
+        OCC_CHAIN_WAIT(fail_flag);                                                                         \
     } while (0)
 
 // Partial sums of beta's system for one 64-site slice (k_beta_partial's, per wave).
@@ -168,15 +205,24 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
         default: { constexpr int D = 8; CALL; } break;                                                     \
     }
 
-// NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU)
-template <int NW>
-__global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int sync_on)
+// Placement probe for the XL form: the XCC_ID (+ 1) of every workgroup of a (XL_SLOTS, nbg) grid.
+__global__ void __launch_bounds__(ITER_WG) k_xl_probe(unsigned *out, int nbg)
+{
+    if (threadIdx.x == 0) out[blockIdx.x * nbg + blockIdx.y] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) + 1u;
+}
+
+// NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
+// XL = 1: one XCD per chain (see the head of this file)
+template <int NW, int XL>
+__global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArgs ia, int e, int sync_on)
 {
     __shared__ int s_flag, s_noise_ok;
     const KryArgs &a = ia.a;
-    // grid = (nbg, C): the chain is blockIdx.y (a scalar register: the buffer descriptors below must be provably
-    // wave-uniform, or every buffer access becomes a serialising waterfall loop)
-    const int chain = (int)blockIdx.y, wg = (int)blockIdx.x;
+    // grid = (nbg, C), the chain is blockIdx.y; XL: grid = (8, nbg), the chain is blockIdx.x (a scalar register
+    // either way: the buffer descriptors below must be provably wave-uniform, or every buffer access becomes a
+    // serialising waterfall loop)
+    const int chain = XL ? (int)blockIdx.x : (int)blockIdx.y, wg = XL ? (int)blockIdx.y : (int)blockIdx.x;
+    if (XL && chain >= ia.C) return;  // the grid walks over all eight XCDs, the chains may be fewer
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
     // before anything can return or wait.
@@ -204,6 +250,9 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     const size_t co = (size_t)chain * n;
     const double2 zero2 = make_double2(0.0, 0.0);
     unsigned *cnt = ia.bar + (size_t)chain * BAR_STRIDE;
+    const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)cnt, 0, ia.nbg * 4, 0x00020000);  // XL: the chain's flags
+    const unsigned my_xcc = XL ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) : 0u;  // HW_REG_XCC_ID
+    (void)fbuf; (void)my_xcc;
     const unsigned bar_base = sc.bar_base;
     unsigned nbar = 0;  // barriers passed in this launch
     const __amdgpu_buffer_rsrc_t gbuf[2] = {
@@ -292,10 +341,10 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     }
     const double2 p0 = make_double2(y - ax, 1.0 - az);
     if (act) ia.rhs[ci] = y;
-    store_sc1(gbuf[0], myoff, p0);
+    store_x<XL>(gbuf[0], myoff, p0);
     PHASE_STAMP(0, 2)
     ++nbar;
-    OCC_CHAIN_BARRIER(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+    OCC_CHAIN_BARRIER(s_flag);
     PHASE_STAMP(0, 3)
     bool failed = s_flag != 0;
 #pragma unroll
@@ -307,6 +356,8 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     int k = 1;
     KryPre pre = minres_pre(s);
+#undef BAR_STAMP
+#define BAR_STAMP(pt) SOLVE_STAMP(pt)
     for (; !failed; ++k) {
         SOLVE_STAMP(0)
         const KryStep st = minres_post(s, pre, k, S0, S1, S2, xn2, a.maxiter);
@@ -338,24 +389,27 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
             if (k >= 2) part[2] = dot2(p, pm1);
             pm2 = pm1;
             pm1 = p;
-            store_sc1(gbuf[k & 1], myoff, g);
+            store_x<XL>(gbuf[k & 1], myoff, g);
         }
         if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
         if (slice_act) {  // per-slice sums: the granularity (and order) of k_minres at 64 threads per block
             const double t0 = wave_sum(part[0]), t1 = wave_sum(part[1]), t2 = wave_sum(part[2]), t3 = wave_sum(part[3]);
-            if (lane == 0) store_sc1(pbuf[k & 1], slice * 32, make_double2(t0, t1));
-            if (lane == 1) store_sc1(pbuf[k & 1], slice * 32 + 16, make_double2(t2, t3));
+            if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(t0, t1));
+            if (lane == 1) store_x<XL>(pbuf[k & 1], slice * 32 + 16, make_double2(t2, t3));
         }
         SOLVE_STAMP(2)
         ++nbar;
         OCC_CHAIN_ARRIVE();
         pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
-        OCC_CHAIN_WAIT(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+        OCC_CHAIN_WAIT(s_flag);
         SOLVE_STAMP(6)
         if (s_flag) { failed = true; break; }
         // ---- everything below reads what other workgroups published in this step: sc1 loads only
         // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the
         // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
+        // the neighbours' g first: those loads are on their way while the sums are formed
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
             double2 lo[4], hi[4];
@@ -367,12 +421,12 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
         }
-#pragma unroll
-        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
         SOLVE_STAMP(7)
         S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
         SOLVE_STAMP(8)
     }
+#undef BAR_STAMP
+#define BAR_STAMP(pt)
 
     // ---- phase C: sum-to-zero projection, eta, partial sums of beta's system.  The solve stopped at the top
     // of step k, uniformly over the chain: buffers of parity k are free (everybody has passed barrier k-1).
@@ -381,10 +435,10 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
     if (!failed) {
         if (slice_act) {
             const double t0 = wave_sum(act ? x.x : 0.0), t1 = wave_sum(act ? x.y : 0.0);
-            if (lane == 0) store_sc1(pbuf[k & 1], slice * 32, make_double2(t0, t1));
+            if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(t0, t1));
         }
         ++nbar;
-        OCC_CHAIN_BARRIER(bar_base + nbar * (unsigned)ia.nbg, s_flag);
+        OCC_CHAIN_BARRIER(s_flag);
         failed = s_flag != 0;
     }
     if (!failed) {
@@ -416,7 +470,7 @@ __global__ void __launch_bounds__(ITER_WG) k_iter(const IterArgs ia, int e, int 
         Ctl m = ctl;
         m.koff = 0u;
         sc.mid[e] = m;
-        sc.bar_base = bar_base + nbar * (unsigned)ia.nbg;
+        sc.bar_base = bar_base + nbar * (XL ? 1u : (unsigned)ia.nbg);
         sc.minres_itn_last = s.itn;
         sc.krylov_total += (unsigned long long)s.itn;
         sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;

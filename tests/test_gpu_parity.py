@@ -163,10 +163,11 @@ def test_batched_chains_equal_single_chain_runs():
 
 @pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40)])
 def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, iters):
-    """k_iter exchanges g between the workgroups of a chain through write-through stores, L1-bypassing
-    loads and a per-chain arrival counter; one stale or torn value would change the bits of eta.  Same
-    scalars, same contractions, same summation order as k_minres: everything must agree exactly,
-    including the number of MINRES iterations of every solve."""
+    """k_iter exchanges g between the workgroups of a chain -- one XCD per chain: plain stores, L1-bypassing loads
+    and one arrival flag per workgroup through that XCD's L2; any placement: write-through stores, L1-bypassing
+    loads and an agent-scope arrival counter -- and one stale or torn value would change the bits of eta.  Same
+    scalars, same contractions, same summation order as k_minres: everything must agree exactly, including the
+    number of MINRES iterations of every solve."""
     from occuspytial_amd._engine import Engine
     from occuspytial_amd._problem import FlatProblem
     from occuspytial_amd.utils import make_lattice_problem
@@ -175,29 +176,33 @@ def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, latti
     keys = [KEY + 7 * c for c in range(chains)]
     starts = [_random_start(prob, 11 + c) for c in range(chains)]
     out = {}
-    for mode in ('persistent', 'launch_per_step'):
-        if mode == 'launch_per_step':
-            monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
-        else:
-            monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
+    modes = {'xcd_local': {}, 'any_placement': {'OCC_NO_XCD_LOCAL': '1'}, 'launch_per_step': {'OCC_NO_PERSISTENT': '1'}}
+    for mode, env in modes.items():
+        for k in ('OCC_NO_PERSISTENT', 'OCC_NO_XCD_LOCAL'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         eng = Engine(prob, keys)
-        assert eng.stats()['persistent_solve'] == (mode == 'persistent')
+        # 2: one XCD per chain (at most 8 chains, at most 64 workgroups per chain), 1: any placement, 0: launch per step
+        assert eng.stats()['persistent_solve'] == {'xcd_local': 2, 'any_placement': 1, 'launch_per_step': 0}[mode]
         for c in range(chains):
             eng.set_start(c, **starts[c])
         rec = eng.run(iters, 0)
         state = [(eng.get('eta', c), eng.get('xz', c), eng.get('z', c), eng.get('minres_itn', c)) for c in range(chains)]
         out[mode] = (rec, state, eng.stats()['krylov_mean'])
         eng.close()
-    for u, v in zip(out['persistent'][0], out['launch_per_step'][0]):
-        assert np.array_equal(u, v)
-    for su, sv in zip(out['persistent'][1], out['launch_per_step'][1]):
-        for u, v in zip(su, sv):
+    for mode in ('xcd_local', 'any_placement'):
+        for u, v in zip(out[mode][0], out['launch_per_step'][0]):
             assert np.array_equal(u, v)
-    assert out['persistent'][2] == out['launch_per_step'][2]
+        for su, sv in zip(out[mode][1], out['launch_per_step'][1]):
+            for u, v in zip(su, sv):
+                assert np.array_equal(u, v)
+        assert out[mode][2] == out['launch_per_step'][2]
 
 
 @pytest.mark.parametrize('env', [{'OCC_EVENT_SYNC': '1'}, {'OCC_EVENT_SYNC': '1', 'OCC_STREAM_EVENTS': '1'}, {'OCC_CU_SPLIT': '0'},
-                                 {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EAGER_ONLY': '1'},
+                                 {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EAGER_ONLY': '1'}, {'OCC_NO_XCD_LOCAL': '1'},
+                                 {'OCC_NO_XCD_LOCAL': '1', 'OCC_CU_SPLIT': '0'},
                                  {'OCC_NO_PERSISTENT': '1', 'OCC_STREAM_EVENTS': '1'}, {'OCC_NO_PERSISTENT': '1', 'OCC_NO_SIDE_STREAM': '1'}])
 def test_every_scheduling_mode_gives_the_same_chains(monkeypatch, env):
     """How an iteration is scheduled -- hand-overs by device counters (default), by event nodes, by stream
@@ -251,7 +256,7 @@ def test_wide_rows_fused_kernel_is_bit_identical_to_launch_per_step(monkeypatch)
         else:
             monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
         eng = Engine(prob, keys)
-        assert eng.stats()['persistent_solve'] == (mode == 'persistent')
+        assert bool(eng.stats()['persistent_solve']) == (mode == 'persistent')
         for c in range(3):
             eng.set_start(c, **starts[c])
         rec = eng.run(40, 0)
