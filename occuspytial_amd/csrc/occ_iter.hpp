@@ -398,11 +398,18 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
             if (lane == 1) store_x<XL>(pbuf[k & 1], slice * 32 + 16, make_double2(t2, t3));
         }
         SOLVE_STAMP(2)
+#ifdef OCC_SOLVE_STAMPS
+        if (chain == 0 && k == 6 && threadIdx.x == 0 && wg < 40) g_solve_stamps[480 + wg] = __builtin_readcyclecounter();
+#endif
         ++nbar;
         OCC_CHAIN_ARRIVE();
         pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
+        SOLVE_STAMP(9)
         OCC_CHAIN_WAIT(s_flag);
         SOLVE_STAMP(6)
+#ifdef OCC_SOLVE_STAMPS
+        if (chain == 0 && k == 6 && threadIdx.x == 0 && wg < 40) g_solve_stamps[520 + wg] = __builtin_readcyclecounter();
+#endif
         if (s_flag) { failed = true; break; }
         // ---- everything below reads what other workgroups published in this step: sc1 loads only
         // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the

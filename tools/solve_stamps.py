@@ -31,14 +31,14 @@ buf = (C.c_ulonglong * (STEPS * PTS))()
 assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
 t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
 itn = int(eng.get('minres_itn', 0))
-names = ['scalars', 'compute+store', 'drain stores', 'sync+signal', 'pre+poll', 'sync', 'loads+partial sums', 'wave sums', 'to next step']
-pts = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+names = ['scalars', 'compute+store', 'drain stores', 'sync+signal', 'minres_pre', 'poll', 'sync', 'loads+partial sums', 'wave sums', 'to next step']
+pts = [0, 1, 2, 3, 4, 9, 5, 6, 7, 8]
 print('last solve of chain 0: %d iterations; shader-clock ticks per segment' % itn)
 print('step ' + ' '.join('%13s' % n for n in names) + '   step total')
 tot = np.zeros(len(names))
 cnt = 0
 for k in range(2, min(itn + 1, STEPS - 1)):
-    d = [t[k, pts[j + 1]] - t[k, pts[j]] for j in range(8)] + [t[k + 1, 0] - t[k, 8]]
+    d = [t[k, pts[j + 1]] - t[k, pts[j]] for j in range(9)] + [t[k + 1, 0] - t[k, 8]]
     print('%4d ' % k + ' '.join('%13d' % v for v in d) + '   %d' % (t[k + 1, 0] - t[k, 0]))
     tot += np.array(d, dtype=float)
     cnt += 1
@@ -47,4 +47,10 @@ cyc = lambda a, b: int(b - a)
 print('phase A: tau %d, rhs+p0 %d, barrier %d, to first step %d' % (cyc(t[0,0], t[0,1]), cyc(t[0,1], t[0,2]), cyc(t[0,2], t[0,3]), cyc(t[0,3], t[1,0])))
 L = STEPS - 1
 print('phase C: proj sums+barrier %d, eta+beta partials+stats %d; kernel start to end %d' % (cyc(t[L,0], t[L,1]), cyc(t[L,1], t[L,2]), cyc(t[0,0], t[L,2])))
+flat = np.array(buf, dtype=np.int64)
+arr, rel = flat[480:520], flat[520:560]
+if arr.min() > 0:
+    a0 = arr.min()
+    print('step 6, workgroups 0..39 of chain 0: compute done at (ticks after the first):', ' '.join('%d' % (v - a0) for v in arr))
+    print('                                      barrier passed at:', ' '.join('%d' % (v - a0) for v in rel))
 eng.close()
