@@ -75,8 +75,9 @@ def pmc_traffic(kernel, workload_key):
         return None
     if d.get('workload') != workload_key:
         return None
-    k = d['kernels'].get(kernel)
-    return k['hbm_bytes_per_launch'] if k else None
+    # template instances carry their arguments in the name (occ::k_iter<8, 1>)
+    hits = [v for name, v in d['kernels'].items() if name == kernel or name.startswith(kernel + '<')]
+    return hits[0]['hbm_bytes_per_launch'] if hits else None
 
 
 def sell_entry_count(prob):

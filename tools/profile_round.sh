@@ -17,3 +17,5 @@ python tools/pmc_traffic.py $out/fetch $out/write profiles/${tag}_pmc_hbm_traffi
 # 3. the plain bench line (not profiled)
 python bench.py 2> $out/bench.err | tail -n 1 > profiles/${tag}_bench.json
 cat profiles/${tag}_bench.json
+# the GPU box only returns gpurun_out/: a copy of everything for the caller to move into profiles/
+mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_* gpurun_out/profiles_$tag/
