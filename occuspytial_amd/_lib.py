@@ -67,6 +67,9 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built, or no usable gfx950 device)."""
 
 
+ABI_VERSION = 2  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
+
+
 def load():
     """Load the shared library and declare its prototypes (no GPU call is made here)."""
     global _lib
@@ -80,6 +83,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        if lib.occ_abi_version() != ABI_VERSION:  # a stale build: struct layouts would not match
+            raise EngineUnavailable(f'{LIB_PATH} has ABI version {lib.occ_abi_version()}, this binding needs {ABI_VERSION}: rebuild it '
+                                    '(`make -C occuspytial_amd/csrc`)')
         _lib = lib
     return _lib
 
