@@ -42,7 +42,8 @@ struct occ_sampler {
     Ctx *ctx_dev = nullptr;  // the copy kernels read
     KryArgs kry{};           // by-value argument block of k_minres
     IterArgs iter{};         // ... and of k_iter
-    // reduced-rank model (LogitRSRGibbs): rsr.m > 0.  One stream, one linear graph of GRAPH_SEQ iterations.
+    // reduced-rank model (LogitRSRGibbs): rsr.m > 0.  k_rsr_gram / k_rsr_solve / k_rsr_eta_beta stand where k_iter is;
+    // scheduled like the fused ICAR iteration (two streams with flag hand-overs, or one linear graph of GRAPH_SEQ iterations).
     RsrArgs rsr{};
     std::vector<double> rsr_K_host;  // n x m, for theta -> eta on the host (start values, set_state)
     // fused iteration (occ_iter.hpp): k_iter + k_z_ob on one stream, the eta solve persistent inside k_iter;

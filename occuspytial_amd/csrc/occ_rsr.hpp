@@ -7,7 +7,7 @@
 //   rate   = 1/2 theta' Qr theta + tau_rate,  tau ~ Gamma
 //   prec   = K' diag(omega_b) K + tau Qr                                      (m x m, dense, symmetric)
 //   rhs    = K'(k - omega_b X beta + sqrt(omega_b) eps1) + sqrt(tau) E eps2     (E E' = Qr; eps1 per site, eps2 per column)
-//   theta  = prec^-1 rhs  (upper Cholesky in LDS, two triangular solves),  eta = K theta
+//   theta  = prec^-1 rhs  (upper Cholesky with the matrix in registers, two triangular solves),  eta = K theta
 // Three kernels, all chains batched on blockIdx.y, every sum in a fixed order (no atomics):
 //   k_rsr_gram     K' [diag(omega_b) K | u] on the matrix cores, u_i = k_i - omega_i x_i'beta + sqrt(omega_i) eps1_i: the
 //                  Gram matrix and K'u in one pass over K; one workgroup of 16 waves per 16 x 16 output tile (upper
