@@ -212,7 +212,8 @@ __device__ inline double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// 1 / sqrt(x), x > 0 and far from the ends of the exponent range: the hardware estimate and two Newton steps
+// 1 / sqrt(x), x > 0 and far from the ends of the exponent range: the hardware estimate (v_rsq_f64: 2^-24 relative,
+// measured on gfx950) and two Newton steps (one leaves 4e-15, two 1.2 ulp against a long-double reference)
 // (the pivot's reciprocal root is all the factorisation needs; a sqrt followed by a division is three times
 // the dependent chain).
 __device__ inline double rsqrt_pivot(double x)
