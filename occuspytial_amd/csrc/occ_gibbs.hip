@@ -783,11 +783,19 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
-            HIP_TRY(hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()));
-            s->main_cus = nmain;
-            s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
-        } else {
+            // a runtime that cannot mask CUs (an error here is not sticky) gets the unpartitioned streams below
+            if (hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()) == hipSuccess) {
+                if (hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()) == hipSuccess) {
+                    s->main_cus = nmain;
+                    s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
+                } else {
+                    (void)hipStreamDestroy(s->stream);
+                    s->stream = nullptr;
+                }
+            }
+            (void)hipGetLastError();
+        }
+        if (s->main_cus == 0) {
             int prio_low = 0, prio_high = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
             if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
