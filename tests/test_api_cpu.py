@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.occ_abi_version() == 2
+    # header, library and binding agree on the ABI version (struct layouts); __graft_entry__.build() checks the same
+    version = int(re.search(r'#define\s+OCC_ABI_VERSION\s+(\d+)', header).group(1))
+    assert lib.occ_abi_version() == version == _lib.ABI_VERSION
 
 
 def test_no_gpu_means_a_loud_failure_not_a_fallback():
