@@ -778,6 +778,12 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         const int ncu = prop.multiProcessorCount;
         // at least 5/8 of the device for the main stream: k_z_ob's Polya-Gamma draws run there too
         int nmain = std::max(((s->iter.nbg * C + 7) / 8) * 8, (ncu * 5 / 64) * 8);
+        // more workgroups than the partition can give one CU each: the 8-wide window runs two per CU
+        if (nmain > ncu - 32 && s->iter_window == 8) nmain = std::max((((s->iter.nbg * C + 1) / 2 + 7) / 8) * 8, (ncu * 5 / 64) * 8);
+        // one XCD per chain (decided for good by the probe below): a chain's nbg workgroups share the nmain / 8 CUs of
+        // one XCD whatever the number of chains, two per CU
+        if (s->persistent && s->iter_window == 8 && C <= XL_SLOTS && s->iter.nbg <= 64 && !std::getenv("OCC_NO_XCD_LOCAL"))
+            nmain = std::max(8 * ((s->iter.nbg + 1) / 2), (ncu * 5 / 64) * 8);
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
