@@ -51,6 +51,9 @@ struct occ_sampler {
     bool persistent = false;
     int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
     bool xcd_local = false;  // k_iter<8, 1>: one XCD per chain, exchange through that XCD's L2 (occ_iter.hpp)
+    bool xl_candidate = false, fused_fallback = false;
+    bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
+    int xl_nbg = 0;          // workgroups per chain of the XCD-local form
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -222,9 +225,10 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
-            if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else hipLaunchKernelGGL((k_iter<16, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            if (s->xcd_local && s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG_XL), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
         default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
     }
@@ -761,8 +765,17 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         // against 251 us with one launch per MINRES step)
         s->iter_window = wmax <= 8 ? 8 : 16;
         const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
-        s->persistent = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16 &&
-                        (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
+        const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16;
+        s->persistent = fused_ok && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
+        // one XCD per chain (k_iter<8, 1, *>, one workgroup per CU): 256-thread workgroups while a chain's fit the 20
+        // CUs of an XCD the main stream normally has, else 512-thread ones; candidates -- the probe below decides
+        s->xl_wide = nbg > (prop.multiProcessorCount * 5 / 64);
+        s->xl_nbg = s->xl_wide ? (n + ITER_WG_XL - 1) / ITER_WG_XL : nbg;
+        s->xl_candidate = fused_ok && s->iter_window == 8 && C <= XL_SLOTS && s->xl_nbg <= 64 &&
+                          XL_SLOTS * s->xl_nbg <= prop.multiProcessorCount - 32 &&  // the CU partition must hold it
+                          !std::getenv("OCC_NO_XCD_LOCAL");
+        s->fused_fallback = s->persistent;  // what holds without the XCD-local form
+        s->persistent = s->persistent || s->xl_candidate;
         if (s->persistent) tpb = 64;
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
@@ -782,8 +795,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         if (nmain > ncu - 32 && s->iter_window == 8) nmain = std::max((((s->iter.nbg * C + 1) / 2 + 7) / 8) * 8, (ncu * 5 / 64) * 8);
         // one XCD per chain (decided for good by the probe below): a chain's nbg workgroups share the nmain / 8 CUs of
         // one XCD whatever the number of chains, two per CU
-        if (s->persistent && s->iter_window == 8 && C <= XL_SLOTS && s->iter.nbg <= 64 && !std::getenv("OCC_NO_XCD_LOCAL"))
-            nmain = std::max(8 * ((s->iter.nbg + 1) / 2), (ncu * 5 / 64) * 8);
+        if (s->xl_candidate) nmain = std::max(8 * s->xl_nbg, (ncu * 5 / 64) * 8);
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
@@ -812,17 +824,17 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     // ---- one XCD per chain?  Needs the 8-wide window (two workgroups per CU), at most one chain per XCD, the
     // chain's flags in one wave's lanes, room for nbg workgroups on the main stream's CUs of an XCD -- and a
     // probe launch that finds every column of the (8, nbg) grid on one XCD of its own.
-    if (s->persistent && s->iter_window == 8 && C <= XL_SLOTS && s->iter.nbg <= 64 && !std::getenv("OCC_NO_XCD_LOCAL")) {
+    if (s->xl_candidate) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         const int cus_per_xcd = (s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount) / XL_SLOTS;
-        if (2 * cus_per_xcd >= s->iter.nbg) {
-            const int nbg = s->iter.nbg;
+        bool ok = s->xl_nbg <= cus_per_xcd;
+        if (ok) {
+            const int nbg = s->xl_nbg;
             unsigned *probe = nullptr;
             if ((rc = dev_alloc(s, &probe, (size_t)XL_SLOTS * nbg))) return rc;
-            bool ok = true;
             for (int rep = 0; rep < 3 && ok; ++rep) {  // the dealing must not depend on what ran before
-                hipLaunchKernelGGL(k_xl_probe, dim3(XL_SLOTS, (unsigned)nbg), dim3(ITER_WG), 0, s->stream, probe, nbg);
+                hipLaunchKernelGGL(k_xl_probe, dim3(XL_SLOTS, (unsigned)nbg), dim3(s->xl_wide ? ITER_WG_XL : ITER_WG), 0, s->stream, probe, nbg);
                 std::vector<unsigned> h((size_t)XL_SLOTS * nbg);
                 HIP_TRY(hipMemcpyAsync(h.data(), probe, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->stream));
                 HIP_TRY(hipStreamSynchronize(s->stream));
@@ -833,7 +845,14 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
                     seen |= 1u << h[(size_t)x * nbg];
                 }
             }
-            s->xcd_local = ok;
+        }
+        s->xcd_local = ok;
+        if (ok) {
+            s->iter.nbg = s->xl_nbg;
+        } else {  // any-placement form, if its workgroups fit the main stream's CUs two (8-wide window) per CU; else one launch per step
+            const int cus = s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount;
+            s->persistent = s->fused_fallback && (long long)s->iter.nbg * C <= 2LL * cus;
+            if (!s->persistent) tpb = 256;
         }
     }
     s->tpb = tpb;

@@ -42,7 +42,8 @@ namespace occ {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter
+constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter, any placement
+constexpr int ITER_WG_XL = 512;                 // ... one XCD per chain: two waves per SIMD IN one workgroup (see k_iter)
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
 constexpr int BAR_STRIDE = 64;                  // unsigned words per chain in IterArgs::bar: the counter, or one flag per workgroup
 constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch = XCDs the grid's x dimension walks over
@@ -206,17 +207,28 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
     }
 
 // Placement probe for the XL form: the XCC_ID (+ 1) of every workgroup of a (XL_SLOTS, nbg) grid.
-__global__ void __launch_bounds__(ITER_WG) k_xl_probe(unsigned *out, int nbg)
+__global__ void __launch_bounds__(ITER_WG_XL) k_xl_probe(unsigned *out, int nbg)
 {
     if (threadIdx.x == 0) out[blockIdx.x * nbg + blockIdx.y] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) + 1u;
 }
 
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
-template <int NW, int XL>
-__global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArgs ia, int e, int sync_on)
+//
+// W512 (with XL, where a chain's waves outnumber the SIMDs its XCD gives the main stream) runs 512 threads per
+// workgroup: two waves share a SIMD, and
+// the f64 dependency chains of the scalar recurrence do not interleave -- two 256-thread workgroups per CU each ran
+// the whole recurrence and the second arrived a microsecond late at every barrier.  With both waves of a SIMD in
+// ONE workgroup the uniform work (tau, the re-reduction of the partial sums, minres_pre / minres_post) is done by
+// wave 0 alone, the others sleep at the workgroup barrier, and the step's coefficients travel through LDS.
+template <int NW, int XL, int W512>
+__global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512) ? 2 : 1) k_iter(const IterArgs ia, int e, int sync_on)
 {
+    constexpr int WGT = W512 ? ITER_WG_XL : ITER_WG;
+    constexpr bool SHARE = W512 != 0;  // two waves per SIMD in this workgroup: wave 0 does the uniform work for all
     __shared__ int s_flag, s_noise_ok;
+    __shared__ double s_bcast[12];  // W512: tau, then the coefficients of the coming step, from wave 0 to the workgroup
+    __shared__ Slot s_slot;         // W512: the MINRES scalar state (wave 0)
     const KryArgs &a = ia.a;
     // grid = (nbg, C), the chain is blockIdx.y; XL: grid = (8, nbg), the chain is blockIdx.x (a scalar register
     // either way: the buffer descriptors below must be provably wave-uniform, or every buffer access becomes a
@@ -243,7 +255,8 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
         s_noise_ok = sync_wait(ia.sync + SYNC_NOISE, j) ? 1 : 0;
     }
     const uint32_t it = ctl.it;
-    const int n = a.n, i = wg * ITER_WG + (int)threadIdx.x;
+    const int n = a.n, i = wg * WGT + (int)threadIdx.x;
+    const bool lead = !SHARE || threadIdx.x < 64;  // the wave that does the uniform work
     const bool act = i < n;
     const int lane = threadIdx.x & 63, slice = i >> 6;
     const bool slice_act = slice < a.nb_n;  // a slice with at least one site owns a partial sum
@@ -265,8 +278,8 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
 
     // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
     PHASE_STAMP(0, 0)
-    double tau;
-    {
+    double tau = 0.0;
+    if (lead) {
         double q = 0.0;
         const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
         for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
@@ -285,6 +298,11 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
         Cursor gcur(sc.key, 0u, it, STREAM_TAU);
         tau = (1.0 / rate) * std_gamma(gcur, ia.tau_shape);  // every lane draws the same tau (uniform control flow)
         if (writer) sc.tau = tau;
+        if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
+    }
+    if (SHARE) {
+        __syncthreads();
+        tau = s_bcast[0];
     }
     PHASE_STAMP(0, 1)
     // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
@@ -350,17 +368,44 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
 
-    // ---- phase B: MINRES
-    Slot s = {};
+    // ---- phase B: MINRES.  The coefficients of step k come from the sums of step k - 1 (minres_post); the lead wave
+    // (W512: wave 0, else every wave for itself) forms them at the bottom of step k - 1 and, XL, hands them over in LDS.
+    // W512: the scalar state lives in LDS (only wave 0 touches it; in registers it would cost every wave 30 VGPRs)
+    Slot s_reg = {};
+    Slot &s = SHARE ? s_slot : s_reg;
+    if (SHARE && threadIdx.x == 0) {
+#define X(f) s_slot.f = 0;
+        OCC_SLOT_FIELDS(X)
+#undef X
+    }
     double2 g = zero2, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     int k = 1;
-    KryPre pre = minres_pre(s);
+    KryPre pre = {};
+    KryStep st = {};
+#define OCC_NEXT_STEP(kn)                                                                                  \
+    do {                                                                                                   \
+        if (lead) {                                                                                        \
+            st = minres_post(s, pre, (kn), S0, S1, S2, xn2, a.maxiter);                                    \
+            if (SHARE && threadIdx.x == 0) {                                                               \
+                s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.sj;            \
+                s_bcast[4] = st.oldeps; s_bcast[5] = st.delta; s_bcast[6] = st.denom; s_bcast[7] = st.phi; \
+                s_bcast[8] = st.rotate ? 1.0 : 0.0; s_bcast[9] = st.stop ? 1.0 : 0.0;                      \
+            }                                                                                              \
+        }                                                                                                  \
+        if (SHARE) {                                                                                       \
+            __syncthreads();                                                                               \
+            st.ca = s_bcast[0]; st.cb = s_bcast[1]; st.cc = s_bcast[2]; st.sj = s_bcast[3];                \
+            st.oldeps = s_bcast[4]; st.delta = s_bcast[5]; st.denom = s_bcast[6]; st.phi = s_bcast[7];     \
+            st.rotate = s_bcast[8] != 0.0; st.stop = s_bcast[9] != 0.0;                                    \
+        }                                                                                                  \
+    } while (0)
+    if (lead) pre = minres_pre(s);
+    OCC_NEXT_STEP(1);
 #undef BAR_STAMP
 #define BAR_STAMP(pt) SOLVE_STAMP(pt)
     for (; !failed; ++k) {
         SOLVE_STAMP(0)
-        const KryStep st = minres_post(s, pre, k, S0, S1, S2, xn2, a.maxiter);
         if (st.stop) break;
         SOLVE_STAMP(1)
         double part[4] = {0.0, 0.0, 0.0, 0.0};
@@ -403,7 +448,7 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
 #endif
         ++nbar;
         OCC_CHAIN_ARRIVE();
-        pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
+        if (lead) pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
         SOLVE_STAMP(9)
         OCC_CHAIN_WAIT(s_flag);
         SOLVE_STAMP(6)
@@ -417,21 +462,25 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
         // the neighbours' g first: those loads are on their way while the sums are formed
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
-            double2 lo[4], hi[4];
+        if (lead) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+                double2 lo[4], hi[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                lo[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
-                hi[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32 + 16);
+                for (int r = 0; r < 4; ++r) {
+                    lo[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
+                    hi[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32 + 16);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
+            SOLVE_STAMP(7)
+            S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
         }
-        SOLVE_STAMP(7)
-        S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
         SOLVE_STAMP(8)
+        OCC_NEXT_STEP(k + 1);
     }
+#undef OCC_NEXT_STEP
 #undef BAR_STAMP
 #define BAR_STAMP(pt)
 
@@ -449,17 +498,24 @@ __global__ void __launch_bounds__(ITER_WG, NW == 8 ? 2 : 1) k_iter(const IterArg
         failed = s_flag != 0;
     }
     if (!failed) {
-        double sx = 0.0, sz = 0.0;
-        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
-            double2 v[4];
+        if (lead) {
+            double sx = 0.0, sz = 0.0;
+            for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+                double2 v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
+                for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sx += v[r].x; sz += v[r].y; }
+                for (int r = 0; r < 4; ++r) { sx += v[r].x; sz += v[r].y; }
+            }
+            sx = wave_sum(sx);
+            sz = wave_sum(sz);
+            proj_a = -sx / sz;
+            if (SHARE && threadIdx.x == 0) s_bcast[10] = proj_a;
         }
-        sx = wave_sum(sx);
-        sz = wave_sum(sz);
-        proj_a = -sx / sz;
+        if (SHARE) {
+            __syncthreads();
+            proj_a = s_bcast[10];
+        }
         PHASE_STAMP(STAMP_STEPS - 1, 1)
     } else if (writer) {
         sc.err = -2;  // OCC_E_HIP: reported by the host as an over-subscribed persistent launch
