@@ -54,6 +54,7 @@ struct occ_sampler {
     bool xl_candidate = false, fused_fallback = false;
     bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
     int xl_nbg = 0;          // workgroups per chain of the XCD-local form
+    int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -767,13 +768,28 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
         const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16;
         s->persistent = fused_ok && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
-        // one XCD per chain (k_iter<8, 1, *>, one workgroup per CU): 256-thread workgroups while a chain's fit the 20
-        // CUs of an XCD the main stream normally has, else 512-thread ones; candidates -- the probe below decides
-        s->xl_wide = nbg > (prop.multiProcessorCount * 5 / 64);
-        s->xl_nbg = s->xl_wide ? (n + ITER_WG_XL - 1) / ITER_WG_XL : nbg;
-        s->xl_candidate = fused_ok && s->iter_window == 8 && C <= XL_SLOTS && s->xl_nbg <= 64 &&
-                          XL_SLOTS * s->xl_nbg <= prop.multiProcessorCount - 32 &&  // the CU partition must hold it
-                          !std::getenv("OCC_NO_XCD_LOCAL");
+        // one XCD per chain (k_iter<8, 1, *>); candidates -- the probe below decides.  Per XCD the main stream has 20 CUs
+        // (24 for larger lattices, 28 when few chains leave the side stream little to do), whole shader engines'
+        // worth: an XCD deals a chain's workgroups round-robin over its four shader engines, so its CUs in the mask
+        // must be a multiple of four (26 workgroups on 26 CUs per XCD dead-locked, on 28 they run).
+        //   A  256-thread workgroups, one per CU            nbg <= 20
+        //   B  512-thread workgroups, one per CU            ceil(n / 512) <= 24, or <= 28 with at most two chains
+        //   C  256-thread workgroups, two per CU            nbg <= 64 (partition of at most 24 CUs per XCD, else none)
+        {
+            const int ncu = prop.multiProcessorCount, nbg512 = (n + ITER_WG_XL - 1) / ITER_WG_XL;
+            const int base = (ncu * 5 / 64) * 8;  // 160 of 256
+            const bool xl_ok = fused_ok && s->iter_window == 8 && C <= XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
+            auto part = [&](int per_xcd) { return std::max(32 * ((per_xcd + 3) / 4), base); };
+            s->xl_candidate = false;
+            if (xl_ok && nbg <= base / XL_SLOTS) {
+                s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 1; s->xl_main = base;
+            } else if (xl_ok && nbg512 <= 64 && (part(nbg512) <= ncu - 64 || (part(nbg512) <= ncu - 32 && C <= 2))) {
+                s->xl_candidate = true; s->xl_wide = true; s->xl_nbg = nbg512; s->xl_per_cu = 1; s->xl_main = part(nbg512);
+            } else if (xl_ok && nbg <= 64 && nbg <= 2 * (ncu / XL_SLOTS)) {
+                s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 2;
+                s->xl_main = part((nbg + 1) / 2) <= ncu - 64 ? part((nbg + 1) / 2) : 0;  // 0: no CU partition
+            }
+        }
         s->fused_fallback = s->persistent;  // what holds without the XCD-local form
         s->persistent = s->persistent || s->xl_candidate;
         if (s->persistent) tpb = 64;
@@ -795,7 +811,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         if (nmain > ncu - 32 && s->iter_window == 8) nmain = std::max((((s->iter.nbg * C + 1) / 2 + 7) / 8) * 8, (ncu * 5 / 64) * 8);
         // one XCD per chain (decided for good by the probe below): a chain's nbg workgroups share the nmain / 8 CUs of
         // one XCD whatever the number of chains, two per CU
-        if (s->xl_candidate) nmain = std::max(8 * s->xl_nbg, (ncu * 5 / 64) * 8);
+        if (s->xl_candidate) nmain = s->xl_main;  // 0: none
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
         if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
@@ -828,7 +844,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         const int cus_per_xcd = (s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount) / XL_SLOTS;
-        bool ok = s->xl_nbg <= cus_per_xcd;
+        bool ok = s->xl_nbg <= s->xl_per_cu * cus_per_xcd;
         if (ok) {
             const int nbg = s->xl_nbg;
             unsigned *probe = nullptr;
