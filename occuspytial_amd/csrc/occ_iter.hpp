@@ -1,7 +1,7 @@
 // occ_iter.hpp -- k_iter: the critical path of one Gibbs iteration of every chain in ONE persistent launch (gfx950).
 //
-// nbg workgroups of 256 threads per chain (one site per thread), ALL of them resident at once (the host takes this
-// path only when they fit at most two per CU).  Per chain, in order:
+// nbg workgroups of 256 (or, one XCD per chain on larger lattices, 512) threads per chain, one site per thread, ALL
+// of them resident at once (the host takes this path only when they fit at most two per CU).  Per chain, in order:
 //   A  tau ~ Gamma (logit.py:206-209), right-hand side of the eta system (logit.py:75-78, 213),
 //      p_0 = b - A x0 with the warm start x0 (logit.py:71, 82-88)                         [k_eta_init]
 //   B  joint MINRES for [x z] (logit.py:82-92), vectors in registers, one barrier per step AMONG THE WORKGROUPS
