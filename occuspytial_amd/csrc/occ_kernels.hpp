@@ -682,20 +682,62 @@ struct KryPre {
     double Anorm, test2, Acond;            // (a)
     double t_ab, delta, gbar, gbar2, sj;   // (c): t_ab = alfa_j^2 + beta_j^2
 };
-__device__ __forceinline__ KryPre minres_pre(const Slot &s)
+// The two halves of minres_pre: what the stopping test (a) needs, what the rotation (c) needs.
+__device__ __forceinline__ void minres_pre_a(const Slot &s, KryPre &q)
 {
-    KryPre q;  // entries that the coming step does not use may be inf / nan (early steps): they are never read
     q.Anorm = sqrt(s.tnorm2);
     q.test2 = (q.Anorm == 0.0) ? INFINITY : s.root / q.Anorm;
     q.Acond = s.gmax / s.gmin;
+}
+__device__ __forceinline__ void minres_pre_c(const Slot &s, KryPre &q)
+{
     q.t_ab = fma(s.beta, s.beta, s.alfa * s.alfa);
     q.delta = fma(s.sn, s.alfa, s.cs * s.dbar);
     q.gbar = fma(-s.cs, s.alfa, s.sn * s.dbar);
     q.gbar2 = q.gbar * q.gbar;
     q.sj = 1.0 / s.beta;
+}
+__device__ __forceinline__ KryPre minres_pre(const Slot &s)
+{
+    KryPre q;  // entries that the coming step does not use may be inf / nan (early steps): they are never read
+    minres_pre_a(s, q);
+    minres_pre_c(s, q);
     return q;
 }
-__device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+// (a): scipy's stopping test of iteration k - 3.  True: the solve ended before step k (istop, itn, done set).
+// Reads phibar, beta1, istop of the slot and nothing (b) / (c) write before it in the same step.
+__device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, double xn2, long long maxiter)
+{
+    if (k < 4) return false;
+    const double eps = DBL_EPSILON;
+    const int j = k - 3;
+    const double rtol = 1e-5;
+    const double Anorm = q.Anorm;
+    const double ynorm = sqrt(xn2);
+    const double epsx = Anorm * ynorm * eps;
+    const double rnorm = s.phibar;
+    const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+    const double test2 = q.test2;
+    const double Acond = q.Acond;
+    int istop = s.istop;
+    if (istop == 0) {
+        const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+        if (t2 <= 1.0) istop = 2;
+        if (t1 <= 1.0) istop = 1;
+        if ((long long)j >= maxiter) istop = 6;
+        if (Acond >= 0.1 / eps) istop = 4;
+        if (epsx >= s.beta1) istop = 3;
+        if (test2 <= rtol) istop = 2;
+        if (test1 <= rtol) istop = 1;
+    }
+    if (istop != 0) {
+        s.istop = istop; s.itn = j; s.done = 1;
+        return true;
+    }
+    return false;
+}
+// (b) + (c): beta_{k-1}, alfa_{k-1}, the rotation of iteration k - 2 and the coefficients of step k
+__device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int k, double S0, double S1, double S2)
 {
     KryStep st;
     st.ca = st.cb = st.cc = 0.0;
@@ -703,33 +745,6 @@ __device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, 
     st.rotate = false;
     st.stop = false;
     const double eps = DBL_EPSILON;
-    if (k >= 4) {  // (a)
-        const int j = k - 3;
-        const double rtol = 1e-5;
-        const double Anorm = q.Anorm;
-        const double ynorm = sqrt(xn2);
-        const double epsx = Anorm * ynorm * eps;
-        const double rnorm = s.phibar;
-        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
-        const double test2 = q.test2;
-        const double Acond = q.Acond;
-        int istop = s.istop;
-        if (istop == 0) {
-            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
-            if (t2 <= 1.0) istop = 2;
-            if (t1 <= 1.0) istop = 1;
-            if ((long long)j >= maxiter) istop = 6;
-            if (Acond >= 0.1 / eps) istop = 4;
-            if (epsx >= s.beta1) istop = 3;
-            if (test2 <= rtol) istop = 2;
-            if (test1 <= rtol) istop = 1;
-        }
-        if (istop != 0) {
-            s.istop = istop; s.itn = j; s.done = 1;
-            st.stop = true;
-            return st;
-        }
-    }
     if (k >= 2) {  // (b)
         if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
             s.done = 1; s.istop = 0; s.itn = 0;
@@ -778,6 +793,18 @@ __device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, 
     }
     s.itn = k;
     return st;
+}
+__device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+{
+    if (minres_post_a(s, q, k, xn2, maxiter)) {
+        KryStep st;
+        st.ca = st.cb = st.cc = 0.0;
+        st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
+        st.rotate = false;
+        st.stop = true;
+        return st;
+    }
+    return minres_post_bc(s, q, k, S0, S1, S2);
 }
 __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
 {
