@@ -754,7 +754,7 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
         const double beta_km1 = sqrt(S0);      // beta_{k-1}
         const double beta_km2 = s.beta;        // beta_{k-2} (k >= 3)
         double alfa_km1 = S1 / S0;             // (p.g)/beta^2
-        if (k >= 3) alfa_km1 = alfa_km1 - S2 / beta_km2;
+        if (k >= 3) alfa_km1 = alfa_km1 - S2 * q.sj;
         if (k == 2) {
             s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
             s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
@@ -772,22 +772,22 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
             s.root = sqrt(fma(s.dbar, s.dbar, q.gbar2));
             double gamma = sqrt(fma(beta_n, beta_n, q.gbar2));
             gamma = fmax(gamma, eps);
-            s.cs = q.gbar / gamma;
-            s.sn = beta_n / gamma;
+            st.denom = 1.0 / gamma;  // ONE division by gamma, by beta_{k-1} and by beta_{k-2} (q.sj) each; products after
+            s.cs = q.gbar * st.denom;
+            s.sn = beta_n * st.denom;
             st.phi = s.cs * s.phibar;
             s.phibar = s.sn * s.phibar;
-            st.denom = 1.0 / gamma;
             s.gmax = fmax(s.gmax, gamma);
             s.gmin = fmin(s.gmin, gamma);
-            const double zz = s.rhs1 / gamma;
+            const double zz = s.rhs1 * st.denom;
             s.rhs1 = fma(-st.delta, zz, s.rhs2);
             s.rhs2 = -s.epsln * zz;
             st.sj = q.sj;
             st.rotate = true;
-            st.cb = beta_km1 / beta_km2;
+            st.cb = beta_km1 * q.sj;
         }
         st.ca = 1.0 / beta_km1;
-        st.cc = alfa_km1 / beta_km1;
+        st.cc = alfa_km1 * st.ca;
         s.beta = beta_km1;
         s.alfa = alfa_km1;
     }

@@ -18,7 +18,9 @@ KEY = 0x9E3779B97F4A7C15
 TOL = {
     'omega_b': 1e-10, 'omega_a': 1e-10,  # PG(1,z): same accept/reject path, libm-level differences
     'tau': 1e-11, 'rhs': 1e-11,
-    'xz': 1e-8,                          # 2n MINRES: rounding in the reductions amplified by the recurrence
+    'xz': 5e-8,                          # 2n MINRES: rounding in the reductions and in the scalar recurrence (the device
+                                         # divides once by gamma / beta and multiplies, scipy and the oracle divide each
+                                         # time) amplified by the recurrence; measured worst case 1.4e-8
     'eta': 1e-7,                         # eta = x - (sum x / sum z) z cancels leading digits of xz (|eta| << |x|);
                                          # both are far inside the solver's own stopping tolerance (rtol 1e-5)
     'beta': 1e-7, 'alpha': 1e-8,         # beta's right-hand side carries eta's difference (logit.py:128-136)
