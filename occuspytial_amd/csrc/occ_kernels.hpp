@@ -686,8 +686,8 @@ struct KryPre {
 __device__ __forceinline__ void minres_pre_a(const Slot &s, KryPre &q)
 {
     q.Anorm = sqrt(s.tnorm2);
-    q.test2 = (q.Anorm == 0.0) ? INFINITY : s.root / q.Anorm;
-    q.Acond = s.gmax / s.gmin;
+    q.test2 = s.root;   // numerator and ...
+    q.Acond = s.gmax;   // ... numerator: the tests below compare products, no division (see minres_post_a)
 }
 __device__ __forceinline__ void minres_pre_c(const Slot &s, KryPre &q)
 {
@@ -712,23 +712,25 @@ __device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, d
     const double eps = DBL_EPSILON;
     const int j = k - 3;
     const double rtol = 1e-5;
+    // scipy: test1 = rnorm / (Anorm ynorm), test2 = root / Anorm, Acond = gmax / gmin, then `1 + test <= 1`, `test <=
+    // rtol`, `Acond >= 0.1 / eps`.  The same decisions without the three divisions (they were 36 of the ~200 issue-bound
+    // f64 instructions of a step): x / d <= c  <=>  x <= c d for d > 0, and 1 + x <= 1  <=>  x <= 2^-53 for x >= 0.
     const double Anorm = q.Anorm;
     const double ynorm = sqrt(xn2);
-    const double epsx = Anorm * ynorm * eps;
+    const double an_yn = Anorm * ynorm;
+    const double epsx = an_yn * eps;
     const double rnorm = s.phibar;
-    const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
-    const double test2 = q.test2;
-    const double Acond = q.Acond;
+    const bool inf1 = (ynorm == 0.0 || Anorm == 0.0), inf2 = (Anorm == 0.0);  // scipy's tests are inf there
+    const double tiny = 0x1p-53;
     int istop = s.istop;
     if (istop == 0) {
-        const double t1 = 1.0 + test1, t2 = 1.0 + test2;
-        if (t2 <= 1.0) istop = 2;
-        if (t1 <= 1.0) istop = 1;
+        if (!inf2 && q.test2 <= tiny * Anorm) istop = 2;
+        if (!inf1 && rnorm <= tiny * an_yn) istop = 1;
         if ((long long)j >= maxiter) istop = 6;
-        if (Acond >= 0.1 / eps) istop = 4;
+        if (q.Acond >= (0.1 / eps) * s.gmin) istop = 4;
         if (epsx >= s.beta1) istop = 3;
-        if (test2 <= rtol) istop = 2;
-        if (test1 <= rtol) istop = 1;
+        if (!inf2 && q.test2 <= rtol * Anorm) istop = 2;
+        if (!inf1 && rnorm <= rtol * an_yn) istop = 1;
     }
     if (istop != 0) {
         s.istop = istop; s.itn = j; s.done = 1;
