@@ -685,9 +685,9 @@ struct KryPre {
 // The two halves of minres_pre: what the stopping test (a) needs, what the rotation (c) needs.
 __device__ __forceinline__ void minres_pre_a(const Slot &s, KryPre &q)
 {
-    q.Anorm = sqrt(s.tnorm2);
-    q.test2 = s.root;   // numerator and ...
-    q.Acond = s.gmax;   // ... numerator: the tests below compare products, no division (see minres_post_a)
+    q.Anorm = s.tnorm2;  // Anorm^2: the tests below compare squares and products, no sqrt, no division (minres_post_a)
+    q.test2 = s.root;    // root^2 (the slot keeps the square)
+    q.Acond = s.gmax;
 }
 __device__ __forceinline__ void minres_pre_c(const Slot &s, KryPre &q)
 {
@@ -712,25 +712,24 @@ __device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, d
     const double eps = DBL_EPSILON;
     const int j = k - 3;
     const double rtol = 1e-5;
-    // scipy: test1 = rnorm / (Anorm ynorm), test2 = root / Anorm, Acond = gmax / gmin, then `1 + test <= 1`, `test <=
-    // rtol`, `Acond >= 0.1 / eps`.  The same decisions without the three divisions (they were 36 of the ~200 issue-bound
-    // f64 instructions of a step): x / d <= c  <=>  x <= c d for d > 0, and 1 + x <= 1  <=>  x <= 2^-53 for x >= 0.
-    const double Anorm = q.Anorm;
-    const double ynorm = sqrt(xn2);
-    const double an_yn = Anorm * ynorm;
-    const double epsx = an_yn * eps;
-    const double rnorm = s.phibar;
-    const bool inf1 = (ynorm == 0.0 || Anorm == 0.0), inf2 = (Anorm == 0.0);  // scipy's tests are inf there
-    const double tiny = 0x1p-53;
+    // scipy: test1 = rnorm / (Anorm ynorm), test2 = root / Anorm, Acond = gmax / gmin, epsx = Anorm ynorm eps, then
+    // `1 + test <= 1`, `test <= rtol`, `Acond >= 0.1 / eps`, `epsx >= beta1`.  The same decisions on squares and
+    // products -- no square root and no division (they were 70 of the ~200 issue-bound f64 instructions of a step):
+    // for non-negative x, c, d:  x / d <= c  <=>  x^2 <= c^2 d^2 (d > 0),  and  1 + x <= 1  <=>  x <= 2^-53.
+    const double tn2 = q.Anorm, root2 = q.test2;        // Anorm^2, root^2
+    const double ay2 = tn2 * xn2;                        // (Anorm ynorm)^2
+    const double rn2 = s.phibar * s.phibar;              // rnorm^2 (phibar >= 0)
+    const bool inf1 = (xn2 == 0.0 || tn2 == 0.0), inf2 = (tn2 == 0.0);  // scipy's tests are inf there
+    const double tiny2 = 0x1p-106, rtol2 = rtol * rtol;
     int istop = s.istop;
     if (istop == 0) {
-        if (!inf2 && q.test2 <= tiny * Anorm) istop = 2;
-        if (!inf1 && rnorm <= tiny * an_yn) istop = 1;
+        if (!inf2 && root2 <= tiny2 * tn2) istop = 2;
+        if (!inf1 && rn2 <= tiny2 * ay2) istop = 1;
         if ((long long)j >= maxiter) istop = 6;
         if (q.Acond >= (0.1 / eps) * s.gmin) istop = 4;
-        if (epsx >= s.beta1) istop = 3;
-        if (!inf2 && q.test2 <= rtol * Anorm) istop = 2;
-        if (!inf1 && rnorm <= rtol * an_yn) istop = 1;
+        if (ay2 * (eps * eps) >= s.beta1 * s.beta1) istop = 3;
+        if (!inf2 && root2 <= rtol2 * tn2) istop = 2;
+        if (!inf1 && rn2 <= rtol2 * ay2) istop = 1;
     }
     if (istop != 0) {
         s.istop = istop; s.itn = j; s.done = 1;
@@ -771,7 +770,7 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
             st.delta = q.delta;
             s.epsln = s.sn * beta_n;
             s.dbar = -s.cs * beta_n;
-            s.root = sqrt(fma(s.dbar, s.dbar, q.gbar2));
+            s.root = fma(s.dbar, s.dbar, q.gbar2);  // root^2: only the stopping test reads it, as a square
             double gamma = sqrt(fma(beta_n, beta_n, q.gbar2));
             gamma = fmax(gamma, eps);
             st.denom = 1.0 / gamma;  // ONE division by gamma, by beta_{k-1} and by beta_{k-2} (q.sj) each; products after
