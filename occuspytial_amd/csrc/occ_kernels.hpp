@@ -55,6 +55,7 @@ __host__ __device__ constexpr int nacc(int d) { return d * (d + 1) / 2 + d; }
 #endif
 struct alignas(OCC_SLOT_ALIGN) Slot {
     double beta1, beta, oldb, alfa, dbar, epsln, phibar, rhs1, rhs2, tnorm2, gmax, gmin, cs, sn, root;
+    double ibeta;  // 1 / beta: the division of the step that formed beta, reused by the next one (its `sj`)
     int itn;    // Lanczos steps completed
     int istop;  // scipy's istop code
     int done;   // x is final
@@ -66,7 +67,7 @@ struct alignas(OCC_SLOT_ALIGN) Slot {
 // scalar and vector paths, which cost k_minres_b 13-25 us per launch on MI355X.
 #define OCC_SLOT_FIELDS(X) \
     X(beta1) X(beta) X(oldb) X(alfa) X(dbar) X(epsln) X(phibar) X(rhs1) X(rhs2) X(tnorm2) X(gmax) X(gmin) \
-    X(cs) X(sn) X(root) X(itn) X(istop) X(done)
+    X(cs) X(sn) X(root) X(ibeta) X(itn) X(istop) X(done)
 __device__ __forceinline__ Slot slot_load(const Slot *p)
 {
     Slot s;
@@ -695,7 +696,7 @@ __device__ __forceinline__ void minres_pre_c(const Slot &s, KryPre &q)
     q.delta = fma(s.sn, s.alfa, s.cs * s.dbar);
     q.gbar = fma(-s.cs, s.alfa, s.sn * s.dbar);
     q.gbar2 = q.gbar * q.gbar;
-    q.sj = 1.0 / s.beta;
+    q.sj = s.ibeta;  // = 1 / s.beta, bit for bit: the quotient the step that formed s.beta took (its `ca`)
 }
 __device__ __forceinline__ KryPre minres_pre(const Slot &s)
 {
@@ -790,6 +791,7 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
         st.ca = 1.0 / beta_km1;
         st.cc = alfa_km1 * st.ca;
         s.beta = beta_km1;
+        s.ibeta = st.ca;
         s.alfa = alfa_km1;
     }
     s.itn = k;
