@@ -438,9 +438,9 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         }
         if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
         if (slice_act) {  // per-slice sums: the granularity (and order) of k_minres at 64 threads per block
-            const double t0 = wave_sum(part[0]), t1 = wave_sum(part[1]), t2 = wave_sum(part[2]), t3 = wave_sum(part[3]);
-            if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(t0, t1));
-            if (lane == 1) store_x<XL>(pbuf[k & 1], slice * 32 + 16, make_double2(t2, t3));
+            wave_sum4(part);
+            if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(part[0], part[1]));
+            if (lane == 1) store_x<XL>(pbuf[k & 1], slice * 32 + 16, make_double2(part[2], part[3]));
         }
         SOLVE_STAMP(2)
 #ifdef OCC_SOLVE_STAMPS
@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
             }
             SOLVE_STAMP(7)
-            S0 = wave_sum(acc[0]); S1 = wave_sum(acc[1]); S2 = wave_sum(acc[2]); xn2 = wave_sum(acc[3]);
+            wave_sum4(acc);
+            S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
         }
         SOLVE_STAMP(8)
         OCC_NEXT_STEP(k + 1);

@@ -180,6 +180,32 @@ __device__ __forceinline__ double wave_sum(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
 }
 
+// Four wave sums at once, each in wave_sum's order (bit-identical to four calls): written level by level so that the four
+// independent dependency chains sit next to each other -- a DPP move has to wait for the add that feeds it, and four
+// calls in a row expose that wait 24 times.
+__device__ __forceinline__ void wave_sum4(double (&v)[4])
+{
+#define OCC_LEVEL(CTRL, MASK)                                                      \
+    {                                                                               \
+        double t_[4];                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) t_[q_] = dpp_shifted<CTRL, MASK>(v[q_]); \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) v[q_] += t_[q_];           \
+    }
+    OCC_LEVEL(0xB1, 0xf)
+    OCC_LEVEL(0x4E, 0xf)
+    OCC_LEVEL(0x141, 0xf)
+    OCC_LEVEL(0x140, 0xf)
+    OCC_LEVEL(0x142, 0xa)
+    OCC_LEVEL(0x143, 0xc)
+#undef OCC_LEVEL
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long b = __double_as_longlong(v[q]);
+        const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+        v[q] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
+    }
+}
+
 // XCD-aware workgroup -> (chain, tile) map.  MI355X deals workgroups round-robin over its 8 XCDs (each
 // with a private L2), so with the plain map consecutive tiles of one chain land on 8 different L2s and
 // every neighbour gather of the lattice re-fetches its lines into several of them (measured: fabric
