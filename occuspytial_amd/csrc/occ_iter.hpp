@@ -383,10 +383,12 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     int k = 1;
     KryPre pre = {};
     KryStep st = {};
+#define NEXT_STAMP(pt)
 #define OCC_NEXT_STEP(kn)                                                                                  \
     do {                                                                                                   \
         if (lead) {                                                                                        \
             st = minres_post(s, pre, (kn), S0, S1, S2, xn2, a.maxiter);                                    \
+            NEXT_STAMP(10)                                                                                 \
             if (SHARE && threadIdx.x == 0) {                                                               \
                 s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.sj;            \
                 s_bcast[4] = st.oldeps; s_bcast[5] = st.delta; s_bcast[6] = st.denom; s_bcast[7] = st.phi; \
@@ -479,7 +481,12 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
         }
         SOLVE_STAMP(8)
+#undef NEXT_STAMP
+#define NEXT_STAMP(pt) SOLVE_STAMP(pt)
         OCC_NEXT_STEP(k + 1);
+        SOLVE_STAMP(11)
+#undef NEXT_STAMP
+#define NEXT_STAMP(pt)
     }
 #undef OCC_NEXT_STEP
 #undef BAR_STAMP

@@ -212,21 +212,7 @@ __device__ inline double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// 1 / sqrt(x), x > 0 and far from the ends of the exponent range: the hardware estimate (v_rsq_f64: 2^-24 relative,
-// measured on gfx950) and two Newton steps (one leaves 4e-15, two 1.2 ulp against a long-double reference)
-// (the pivot's reciprocal root is all the factorisation needs; a sqrt followed by a division is three times
-// the dependent chain).
-__device__ inline double rsqrt_pivot(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const double h = 0.5 * y;
-        const double err = fma(-(x * y), h, 0.5);  // (1 - x y^2) / 2
-        y = fma(y, err, y);
-    }
-    return y;
-}
+__device__ __forceinline__ double rsqrt_pivot(double x) { return rsqrt_nr(x); }  // occ_kernels.hpp
 
 #ifdef OCC_SOLVE_STAMPS
 #define RSR_STAMP(pt) if (chain == 0 && tid == 0) g_solve_stamps[(pt)] = wall_clock64();

@@ -31,14 +31,14 @@ buf = (C.c_ulonglong * (STEPS * PTS))()
 assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
 t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
 itn = int(eng.get('minres_itn', 0))
-names = ['scalars', 'compute+store', 'drain stores', 'sync+signal', 'minres_pre', 'poll', 'sync', 'loads+partial sums', 'wave sums', 'to next step']
-pts = [0, 1, 2, 3, 4, 9, 5, 6, 7, 8]
+names = ['top', 'compute+store', 'drain stores', 'sync+signal', 'minres_pre', 'poll', 'sync', 'loads+partial sums', 'wave sums', 'minres_post', 'hand-over', 'to next step']
+pts = [0, 1, 2, 3, 4, 9, 5, 6, 7, 8, 10, 11]
 print('last solve of chain 0: %d iterations; shader-clock ticks per segment' % itn)
 print('step ' + ' '.join('%13s' % n for n in names) + '   step total')
 tot = np.zeros(len(names))
 cnt = 0
 for k in range(2, min(itn + 1, STEPS - 1)):
-    d = [t[k, pts[j + 1]] - t[k, pts[j]] for j in range(9)] + [t[k + 1, 0] - t[k, 8]]
+    d = [t[k, pts[j + 1]] - t[k, pts[j]] for j in range(11)] + [t[k + 1, 0] - t[k, 11]]
     print('%4d ' % k + ' '.join('%13d' % v for v in d) + '   %d' % (t[k + 1, 0] - t[k, 0]))
     tot += np.array(d, dtype=float)
     cnt += 1
