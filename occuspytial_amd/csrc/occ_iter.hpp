@@ -387,7 +387,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 #define OCC_NEXT_STEP(kn)                                                                                  \
     do {                                                                                                   \
         if (lead) {                                                                                        \
-            st = minres_post(s, pre, (kn), S0, S1, S2, xn2, a.maxiter);                                    \
+            if (SHARE) { /* the LDS-resident state through registers: every load out before the first use */ \
+                Slot t_ = slot_load(&s);                                                                   \
+                st = minres_post(t_, pre, (kn), S0, S1, S2, xn2, a.maxiter);                               \
+                slot_store(&s, t_);                                                                        \
+            } else {                                                                                       \
+                st = minres_post(s, pre, (kn), S0, S1, S2, xn2, a.maxiter);                                \
+            }                                                                                              \
             NEXT_STAMP(10)                                                                                 \
             if (SHARE && threadIdx.x == 0) {                                                               \
                 s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.sj;            \
