@@ -467,9 +467,12 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         // ---- everything below reads what other workgroups published in this step: sc1 loads only
         // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the
         // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
-        // the neighbours' g first: those loads are on their way while the sums are formed
+        // W512: the lead wave's sums are the critical path (the coefficients of the next step hang on them), its
+        // gathers are not: sums' loads first there; the other forms keep the gathers in front (every wave sums)
+        if (!SHARE) {
 #pragma unroll
-        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+            for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+        }
         if (lead) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
@@ -482,9 +485,17 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
             }
+            if (SHARE) {
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+            }
             SOLVE_STAMP(7)
             wave_sum4(acc);
             S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
+        }
+        if (SHARE && !lead) {
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
         }
         SOLVE_STAMP(8)
 #undef NEXT_STAMP
