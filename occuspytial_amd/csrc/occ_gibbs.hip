@@ -231,7 +231,14 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
             break;
-        default: hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
+        default:
+            if (s->tpb == 64) {  // 64-site slices (fused paths): 256-thread blocks, beta once per block, partial sums still per slice
+                const unsigned nb4 = (unsigned)((c.n + 255) / 256);
+                hipLaunchKernelGGL(pick_z_ob(c.p), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2);
+            } else {
+                hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0);
+            }
+            break;
     }
 }
 

@@ -535,7 +535,8 @@ __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainSc
 // omega_b ~ PG(1, x_i'beta + eta_i) of iteration `it` into omega_b[it & 1], and the partials of eta'Q eta
 // (logit.py:195-204, 208).  `blk` is the block index within the role's own grid.
 template <int P>
-__device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &sc, const double (&beta)[P], int chain, uint32_t it, int blk)
+__device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &sc, const double (&beta)[P], int chain, uint32_t it, int blk,
+                                             bool per_wave = false)
 {
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     double quad[1] = {0.0};
@@ -554,6 +555,12 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
         double qe = c.qdiag[i] * eta_i;
         for (int k = 0; k < width; ++k) qe = fma(c.sell_val[base + k * 64 + lane], eta[c.sell_col[base + k * 64 + lane]], qe);
         quad[0] = eta_i * qe;
+    }
+    if (per_wave) {  // several waves per block, partial sums still per 64-site slice (c.nb_n counts slices)
+        const double t = wave_sum(quad[0]);
+        const int slice = blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && slice < c.nb_n) c.part_quad[(size_t)chain * c.nb_n + slice] = t;
+        return;
     }
     block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
 }
@@ -1323,15 +1330,18 @@ __device__ __forceinline__ void record_draws(const Ctx &c, const ChainScalars &s
 }
 
 template <int P>
-__device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool synced, unsigned seq)
+__device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool synced, unsigned seq,
+                                          bool per_wave)
 {
-    __shared__ int s_wait_ok;
+    __shared__ int s_wait_ok, s_beta_ok;
+    __shared__ double s_beta[P];
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.mid[e];
     const bool skip = ctl.koff || ctl.it >= sc.it_stop;
-    const int nb = c.nb_n;
+    // per_wave: 256-thread blocks over 64-site slices (c.nb_n of them): beta is formed by wave 0 for the block
+    const int nb = per_wave ? (c.n + (int)blockDim.x - 1) / (int)blockDim.x : c.nb_n;
     const uint32_t it = ctl.it;
     const bool writer = (blk == 0 && threadIdx.x == 0);
     if (writer) {
@@ -1351,9 +1361,23 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     double beta[P];
     {
         double sums[nacc(P)];
-        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);
+        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);  // several waves: wave 0 + LDS
         const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
-        const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, it, STREAM_BETA, beta);
+        bool ok = true;
+        if (!per_wave || threadIdx.x < 64) {
+            ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, it, STREAM_BETA, beta);
+            if (per_wave && threadIdx.x == 0) {
+                s_beta_ok = ok ? 1 : 0;
+#pragma unroll
+                for (int a = 0; a < P; ++a) s_beta[a] = beta[a];
+            }
+        }
+        if (per_wave) {  // the draw (a Cholesky factor and Box-Muller normals) once per block, not once per wave
+            __syncthreads();
+            ok = s_beta_ok != 0;
+#pragma unroll
+            for (int a = 0; a < P; ++a) beta[a] = s_beta[a];
+        }
         if (writer) {
             if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
 #pragma unroll
@@ -1361,7 +1385,7 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
         }
     }
     if (blk >= nb) {  // role 1
-        omega_b_body<P>(c, sc, beta, chain, it + 1u, blk - nb);
+        omega_b_body<P>(c, sc, beta, chain, it + 1u, blk - nb, per_wave);
         return;
     }
     // role 0 needs alpha of THIS iteration, drawn on the side stream
@@ -1384,14 +1408,14 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
 }
 
 template <int P>
-__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int sync_on)
+__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave
 {
     __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
-    const bool synced = sync_on && c.sync != nullptr;
+    const bool synced = (flags & 1) && c.sync != nullptr;
     // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
     const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
-    z_ob_body<P>(c, scs, chain_base, e, synced, seq);
+    z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0);
 }
 
 }  // namespace occ
