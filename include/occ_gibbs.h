@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 2
+#define OCC_ABI_VERSION 3
 #define OCC_MAX_COVARIATES 8 /* p and q limit (register-resident p x p accumulators) */
 
 enum {
@@ -124,7 +124,8 @@ typedef struct occ_stats {
                                  MINRES step, omega_a/alpha/noise on a side stream */
     int32_t solve_workgroups; /* workgroups per chain of the persistent solve */
     int32_t main_stream_cus;  /* > 0: CUs reserved for the main stream (k_iter, k_z_ob); the side stream has the others */
-    int32_t pad_;
+    int32_t fused_fallbacks;  /* calls that were re-run on the launch-per-step path after a device-side wait in the fused kernel
+                                 gave up (its workgroups were not resident together); the engine stays on that path */
     double profile_minres_iterations; /* mean MINRES iterations per solve over the k_iter launches of the last occ_profile */
     int64_t iter_kernel_launches;     /* k_iter launches of the last occ_run ... */
     double iter_kernel_mean_us;       /* ... and their mean duration, first workgroup in to last chain out, by the
@@ -145,6 +146,16 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 #define OCC_N_KERNEL_KINDS 9
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
+
+/* Variates of the engine's own generators, drawn ON THE DEVICE by the device functions the kernels use, for the
+ * known-answer and distributional tests of the samplers that stand where the reference calls the third-party
+ * polyagamma package (logit.py:191-193, 202-204) and numpy's Generator.gamma (logit.py:209): out[i] comes from the
+ * sub-stream (key, index i, iteration, stream) exactly as a kernel of the iteration would draw it.
+ * kind 0: PG(1, param[i]);  1: standard gamma of shape param[i];  2: standard normal;  3: uniform on (0, 1)
+ * (param is ignored for kinds 2 and 3).  Host pointers (or device pointers of `device`); n < 2^31.
+ * Errors are reported through occ_last_error(NULL). */
+int occ_draw(int32_t device, int32_t kind, uint64_t key, uint32_t iteration, uint32_t stream, int64_t n, const double *param,
+             double *out);
 
 const char *occ_last_error(const occ_sampler *s); /* NULL handle: error of the last failed occ_create */
 int32_t occ_abi_version(void);

@@ -145,3 +145,22 @@ class Engine:
         return {k: {'launches': int(counts[i]), 'total_us': float(total[i]),
                     'avg_us': float(total[i]) / counts[i] if counts[i] else 0.0}
                 for i, k in enumerate(_lib.KERNEL_KINDS)}
+
+
+DRAW_KINDS = {'pg1': 0, 'std_gamma': 1, 'normal': 2, 'uniform': 3}
+
+
+def device_draw(kind, param=None, n=None, key=1, it=0, stream=1, device=0):
+    """Variates of the engine's own generators drawn on the device (``occ_draw``): element ``i`` comes from the
+    sub-stream ``(key, i, it, stream)`` exactly as the kernels draw it.  ``kind``: ``'pg1'`` (``param`` = z),
+    ``'std_gamma'`` (``param`` = shape), ``'normal'``, ``'uniform'`` (``n`` draws)."""
+    lib = _lib.load()
+    par = None
+    if kind in ('pg1', 'std_gamma'):
+        par = np.ascontiguousarray(param, dtype=np.float64).ravel()
+        n = par.size
+    out = np.empty(int(n))
+    code = lib.occ_draw(int(device), DRAW_KINDS[kind], int(key) & (2 ** 64 - 1), int(it), int(stream), int(n),
+                        _ptr(par) if par is not None else None, _ptr(out))
+    _lib.raise_for(code, None)
+    return out

@@ -36,7 +36,7 @@ class OccStats(C.Structure):
         ('krylov_mean', C.c_double), ('krylov_total', C.c_int64), ('solves', C.c_int64), ('last_run_ms', C.c_double),
         ('n_blocks_sites', C.c_int32), ('n_blocks_rows', C.c_int32), ('threads_per_block', C.c_int32),
         ('n_chains', C.c_int32), ('persistent_solve', C.c_int32), ('solve_workgroups', C.c_int32),
-        ('main_stream_cus', C.c_int32), ('pad_', C.c_int32), ('profile_minres_iterations', C.c_double),
+        ('main_stream_cus', C.c_int32), ('fused_fallbacks', C.c_int32), ('profile_minres_iterations', C.c_double),
         ('iter_kernel_launches', C.c_int64), ('iter_kernel_mean_us', C.c_double),
     ]
 
@@ -58,6 +58,7 @@ SYMBOLS = (
     ('occ_set_state', C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64]),
     ('occ_get_stats', C.c_int, [C.c_void_p, C.POINTER(OccStats)]),
     ('occ_profile', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ('occ_draw', C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
 )
 
 _lib = None
@@ -67,7 +68,7 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built, or no usable gfx950 device)."""
 
 
-ABI_VERSION = 2  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
+ABI_VERSION = 3  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
 
 
 def load():

@@ -52,6 +52,19 @@ struct occ_sampler {
     int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
     bool xcd_local = false;  // k_iter<8, 1>: one XCD per chain, exchange through that XCD's L2 (occ_iter.hpp)
     bool xl_candidate = false, fused_fallback = false;
+    bool any_fits = false;   // the any-placement form fits the main stream's CUs (arithmetic; the residency probe decides)
+    int nbg_any = 0;         // its workgroups per chain
+    int tpb_plain = 256;     // threads per block of the launch-per-step path when no fused form applies
+    int iter_flags_extra = 0;  // OR-ed into k_iter's flags (2: residency probe)
+    bool device_timeout = false;  // the last error was a device-side wait that gave up (not a HIP API failure)
+    // state of every chain at the start of the running occ_run / occ_step (fused engines only): what the call is re-run from
+    double *snap_eta = nullptr;
+    uint8_t *snap_z = nullptr;
+    double2 *snap_x = nullptr;
+    double *snap_theta = nullptr;
+    std::vector<ChainScalars> snap_sc;
+    int snap_parity = 0;
+    int64_t fused_fallbacks = 0;  // occ_run calls that were re-run on the launch-per-step path after a device-side time-out
     bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
     int xl_nbg = 0;          // workgroups per chain of the XCD-local form
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
@@ -64,6 +77,9 @@ struct occ_sampler {
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
+    unsigned long long clock_init[4] = {~0ull, 0ull, 0ull, 0ull};
+    int launch_rc = 0;       // first failed kernel launch since the last take_launch_rc()
+    std::string launch_err;
     // launch-sequence ("slot") parity: the kernels of the next sequence read ChainScalars::ctl[parity]
     int parity = 0;
     // start values / state were just set by the host: omega_b and the noise of the current iteration
@@ -205,7 +221,16 @@ KernelE pick_omega_a(int q)
 
 // ---- single launches (all chains) ----------------------------------------------------------------
 #define OCC_ARGS s->ctx_dev, s->ctx.sc, s->ctx.slots, 0, e
-void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
+static const char *kind_name(int kind)
+{
+    static const char *names[] = {"k_omega_b", "k_noise", "k_eta_init", "k_minres", "k_beta_partial", "k_omega_a", "k_alpha_draw",
+                                  "k_z_ob", "k_iter", "k_gate", "k_rsr_gram", "k_rsr_solve", "k_rsr_eta_beta"};
+    return (kind >= 0 && kind < (int)(sizeof(names) / sizeof(names[0]))) ? names[kind] : "kernel";
+}
+
+// One kernel launch (all chains).  A launch the runtime rejects (bad grid, too much dynamic LDS, ...) is reported at
+// once -- also during stream capture -- instead of surfacing later as stale results or a barrier time-out.
+int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
 {
     const Ctx &c = s->ctx;
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
@@ -226,10 +251,10 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
-            if (s->xcd_local && s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG_XL), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
-            else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, s->launch_sync ? 1 : 0);
+            if (s->xcd_local && s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG_XL), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+            else if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+            else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+            else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
             break;
         default:
             if (s->tpb == 64) {  // 64-site slices (fused paths): 256-thread blocks, beta once per block, partial sums still per slice
@@ -240,6 +265,29 @@ void launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             }
             break;
     }
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        s->err = std::string("launch of ") + kind_name(kind) + " failed: " + hipGetErrorString(le);
+        return OCC_E_HIP;
+    }
+    return OCC_OK;
+}
+// Launches inside sequences (and stream captures, which an early return would leave open) record the first failure in
+// s->launch_rc; the caller collects it at the end of the sequence / after hipStreamEndCapture with take_launch_rc().
+#define LAUNCH(...)                                          \
+    do {                                                     \
+        const int lrc_ = launch_kind(__VA_ARGS__);           \
+        if (lrc_ != OCC_OK && s->launch_rc == OCC_OK) {      \
+            s->launch_rc = lrc_;                             \
+            s->launch_err = s->err;                          \
+        }                                                    \
+    } while (0)
+int take_launch_rc(occ_sampler *s)
+{
+    const int rc = s->launch_rc;
+    if (rc != OCC_OK) s->err = s->launch_err;
+    s->launch_rc = OCC_OK;
+    return rc;
 }
 
 int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
@@ -263,6 +311,7 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
         if (h[c].err == OCC_E_MINRES) { s->err = "MINRES solver did not converge!"; return OCC_E_MINRES; }
         if (h[c].err == OCC_E_CHOLESKY) { s->err = "Cholesky factorization/solver failed!"; return OCC_E_CHOLESKY; }
         if (h[c].err == OCC_E_HIP) {
+            s->device_timeout = true;
             s->err = "a device-side wait timed out (a barrier among the workgroups of a chain in k_iter, or a hand-over "
                      "between the two streams): the device is over-subscribed or its queues are being serialised; "
                      "OCC_EVENT_SYNC=1 hands over through events, OCC_NO_PERSISTENT=1 uses one launch per MINRES step";
@@ -273,11 +322,12 @@ int check_device_errors(occ_sampler *s, const std::vector<ChainScalars> &h)
 }
 
 // omega_b and the right-hand-side noise of the CURRENT iteration, stand-alone (after new start values).
-void launch_prologue(occ_sampler *s)
+int launch_prologue(occ_sampler *s)
 {
-    launch_kind(s, s->stream, K_OMEGA_B, s->parity);
-    launch_kind(s, s->stream, K_NOISE, s->parity, 0);  // ahead = 0: outside the sequence counting
+    LAUNCH(s, s->stream, K_OMEGA_B, s->parity);
+    LAUNCH(s, s->stream, K_NOISE, s->parity, 0);  // ahead = 0: outside the sequence counting
     s->need_prologue = false;
+    return take_launch_rc(s);
 }
 
 // Krylov launches from `k_from` with the host watching the `done` flags.  On return *k_last is the
@@ -286,10 +336,11 @@ int eager_krylov(occ_sampler *s, int k_from, int *k_last)
 {
     std::vector<Slot> slots((size_t)s->ctx.C * NSLOT);
     for (int k = k_from;; ++k) {
-        launch_kind(s, s->stream, K_MINRES, s->parity, k);
+        LAUNCH(s, s->stream, K_MINRES, s->parity, k);
         if (k < 4) continue;
         HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
+        if (int lrc = take_launch_rc(s)) return lrc;
         bool all = true;
         for (int c = 0; c < s->ctx.C; ++c) all = all && slots[(size_t)c * NSLOT + (k & (NSLOT - 1))].done;
         if (all) {
@@ -305,20 +356,24 @@ int eager_krylov(occ_sampler *s, int k_from, int *k_last)
 // their inputs are last iteration's alpha and z).
 // One iteration of the reduced-rank model on one stream, the reference's order (omega_a / alpha moved up front as
 // everywhere; their inputs are last iteration's alpha and z).
-void launch_rsr_sequence(occ_sampler *s, hipStream_t st, int e)
+int launch_rsr_sequence(occ_sampler *s, hipStream_t st, int e)
 {
-    launch_kind(s, st, K_OMEGA_A, e);
-    launch_kind(s, st, K_ALPHA_DRAW, e);
-    launch_kind(s, st, K_NOISE, e, 1);
-    launch_kind(s, st, K_RSR_GRAM, e);
-    launch_kind(s, st, K_RSR_SOLVE, e);
-    launch_kind(s, st, K_RSR_ETA_BETA, e);
-    launch_kind(s, st, K_Z_OB, e);
+    LAUNCH(s, st, K_OMEGA_A, e);
+    LAUNCH(s, st, K_ALPHA_DRAW, e);
+    LAUNCH(s, st, K_NOISE, e, 1);
+    LAUNCH(s, st, K_RSR_GRAM, e);
+    LAUNCH(s, st, K_RSR_SOLVE, e);
+    LAUNCH(s, st, K_RSR_ETA_BETA, e);
+    LAUNCH(s, st, K_Z_OB, e);
+    return OCC_OK;
 }
 
 int eager_sequence(occ_sampler *s)
 {
-    if (s->need_prologue) launch_prologue(s);
+    if (s->need_prologue) {
+        const int prc = launch_prologue(s);
+        if (prc) return prc;
+    }
     const int e = s->parity;
     // one stream, reference order: stream order is the synchronisation, the hand-over counters stay untouched
     struct NoSync { occ_sampler *s; bool old; explicit NoSync(occ_sampler *p) : s(p), old(p->launch_sync) { s->launch_sync = false; } ~NoSync() { s->launch_sync = old; } } no_sync(s);
@@ -326,25 +381,25 @@ int eager_sequence(occ_sampler *s)
         launch_rsr_sequence(s, s->stream, e);
         s->parity ^= 1;
         s->eager_iterations += 1;
-        return OCC_OK;
+        return take_launch_rc(s);
     }
-    launch_kind(s, s->stream, K_OMEGA_A, e);
-    launch_kind(s, s->stream, K_ALPHA_DRAW, e);
-    launch_kind(s, s->stream, K_NOISE, e, 1);
+    LAUNCH(s, s->stream, K_OMEGA_A, e);
+    LAUNCH(s, s->stream, K_ALPHA_DRAW, e);
+    LAUNCH(s, s->stream, K_NOISE, e, 1);
     if (s->persistent) {
-        launch_kind(s, s->stream, K_ITER, e);
+        LAUNCH(s, s->stream, K_ITER, e);
     } else {
-        launch_kind(s, s->stream, K_ETA_INIT, e);
+        LAUNCH(s, s->stream, K_ETA_INIT, e);
         int k_last = 0;
         int rc = eager_krylov(s, 1, &k_last);
         if (rc) return rc;
         s->calib_max = std::max(s->calib_max, k_last - 3);
-        launch_kind(s, s->stream, K_BETA_PARTIAL, e, k_last);
+        LAUNCH(s, s->stream, K_BETA_PARTIAL, e, k_last);
     }
-    launch_kind(s, s->stream, K_Z_OB, e);
+    LAUNCH(s, s->stream, K_Z_OB, e);
     s->parity ^= 1;
     s->eager_iterations += 1;
-    return OCC_OK;
+    return take_launch_rc(s);
 }
 
 void destroy_head(occ_sampler *s)
@@ -404,7 +459,7 @@ int build_graph(occ_sampler *s, int cap)
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
         s->graph_parity = s->parity;
         s->krylov_cap = 0;
-        return OCC_OK;
+        return take_launch_rc(s);
     }
     if (s->flag_sync) {
         // GRAPH_SEQ sequences (alternating parity) per graph and stream, no event nodes: the kernels hand over through
@@ -413,37 +468,37 @@ int build_graph(occ_sampler *s, int cap)
         for (int t = 0; t < GRAPH_SEQ; ++t) {
             const int e = s->parity ^ (t & 1);
             if (s->rsr.m > 0) {  // reduced-rank model: k_rsr_gram opens the sequence as k_iter does
-                launch_kind(s, s->stream, K_RSR_GRAM, e);
-                launch_kind(s, s->stream, K_RSR_SOLVE, e);
-                launch_kind(s, s->stream, K_RSR_ETA_BETA, e);
+                LAUNCH(s, s->stream, K_RSR_GRAM, e);
+                LAUNCH(s, s->stream, K_RSR_SOLVE, e);
+                LAUNCH(s, s->stream, K_RSR_ETA_BETA, e);
             } else {
-                launch_kind(s, s->stream, K_ITER, e);
+                LAUNCH(s, s->stream, K_ITER, e);
             }
-            launch_kind(s, s->stream, K_Z_OB, e);
+            LAUNCH(s, s->stream, K_Z_OB, e);
         }
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
         HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
         for (int t = 0; t < GRAPH_SEQ; ++t) {
-            launch_kind(s, s->side, K_GATE, 0);
-            launch_kind(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
-            launch_kind(s, s->side, K_ALPHA_DRAW, s->parity ^ (t & 1));
-            launch_kind(s, s->side, K_NOISE, s->parity ^ (t & 1), 1);
+            LAUNCH(s, s->side, K_GATE, 0);
+            LAUNCH(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
+            LAUNCH(s, s->side, K_ALPHA_DRAW, s->parity ^ (t & 1));
+            LAUNCH(s, s->side, K_NOISE, s->parity ^ (t & 1), 1);
         }
         HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->tail[0], s->tail_graph[0], nullptr, nullptr, 0));
         s->graph_parity = s->parity;
         s->krylov_cap = 0;
-        return OCC_OK;
+        return take_launch_rc(s);
     }
     for (int e = 0; e < 2; ++e) {
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         if (s->persistent) {
-            launch_kind(s, s->stream, K_ITER, e);
+            LAUNCH(s, s->stream, K_ITER, e);
         } else {
-            launch_kind(s, s->stream, K_ETA_INIT, e);
-            for (int k = 1; k <= cap + 3; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
-            launch_kind(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
+            LAUNCH(s, s->stream, K_ETA_INIT, e);
+            for (int k = 1; k <= cap + 3; ++k) LAUNCH(s, s->stream, K_MINRES, e, k);
+            LAUNCH(s, s->stream, K_BETA_PARTIAL, e, cap + 3);
         }
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[e]));
         if (s->event_nodes) {  // ... -> wait(side chain of this iteration) -> k_z_ob -> record
@@ -451,7 +506,7 @@ int build_graph(occ_sampler *s, int cap)
             if ((rc = graph_leaf(s, s->head_graph[e], &leaf))) return rc;
             HIP_TRY(hipGraphAddEventWaitNode(&wait, s->head_graph[e], &leaf, 1, s->ev_side[e]));
             HIP_TRY(hipStreamBeginCaptureToGraph(s->stream, s->head_graph[e], &wait, nullptr, 1, hipStreamCaptureModeThreadLocal));
-            launch_kind(s, s->stream, K_Z_OB, e);
+            LAUNCH(s, s->stream, K_Z_OB, e);
             hipGraph_t same = nullptr;
             HIP_TRY(hipStreamEndCapture(s->stream, &same));
             if ((rc = graph_leaf(s, s->head_graph[e], &leaf))) return rc;
@@ -464,18 +519,18 @@ int build_graph(occ_sampler *s, int cap)
             HIP_TRY(hipGraphCreate(&s->tail_graph[e], 0));
             HIP_TRY(hipGraphAddEventWaitNode(&wait, s->tail_graph[e], nullptr, 0, s->ev_z[e ^ 1]));
             HIP_TRY(hipStreamBeginCaptureToGraph(s->side, s->tail_graph[e], &wait, nullptr, 1, hipStreamCaptureModeThreadLocal));
-            launch_kind(s, s->side, K_OMEGA_A, e);
-            launch_kind(s, s->side, K_ALPHA_DRAW, e);
-            launch_kind(s, s->side, K_NOISE, e, 1);
+            LAUNCH(s, s->side, K_OMEGA_A, e);
+            LAUNCH(s, s->side, K_ALPHA_DRAW, e);
+            LAUNCH(s, s->side, K_NOISE, e, 1);
             hipGraph_t same = nullptr;
             HIP_TRY(hipStreamEndCapture(s->side, &same));
             if ((rc = graph_leaf(s, s->tail_graph[e], &leaf))) return rc;
             HIP_TRY(hipGraphAddEventRecordNode(&rec, s->tail_graph[e], &leaf, 1, s->ev_side[e]));
         } else {
             HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
-            launch_kind(s, s->side, K_OMEGA_A, e);
-            launch_kind(s, s->side, K_ALPHA_DRAW, e);
-            launch_kind(s, s->side, K_NOISE, e, 1);
+            LAUNCH(s, s->side, K_OMEGA_A, e);
+            LAUNCH(s, s->side, K_ALPHA_DRAW, e);
+            LAUNCH(s, s->side, K_NOISE, e, 1);
             HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[e]));
         }
         HIP_TRY(hipGraphInstantiate(&s->tail[e], s->tail_graph[e], nullptr, nullptr, 0));
@@ -485,7 +540,7 @@ int build_graph(occ_sampler *s, int cap)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
         std::fprintf(stderr, "[occ] graphs captured, Krylov cap %d: %.2f ms host time\n", cap, ms);
     }
-    return OCC_OK;
+    return take_launch_rc(s);
 }
 
 // Enqueue one launch sequence (one Gibbs iteration of every chain, or a carried solve) without any
@@ -518,10 +573,10 @@ int enqueue_sequence(occ_sampler *s)
         HIP_TRY(hipGraphLaunch(s->tail[e], s->stream));
         HIP_TRY(hipGraphLaunch(s->head[e], s->stream));
     }
-    launch_kind(s, s->stream, K_Z_OB, e);
+    LAUNCH(s, s->stream, K_Z_OB, e);
     if (s->side_enabled) HIP_TRY(hipEventRecord(s->ev_z[e], s->stream));
     s->parity ^= 1;
-    return OCC_OK;
+    return take_launch_rc(s);
 }
 
 int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
@@ -537,6 +592,58 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
         sc.keep = (uint32_t)keep;
         ctl.koff = 0;
     }
+    return write_scalars(s, h);
+}
+
+
+// The two streams without a CU partition: the main stream (critical path) at the higher priority.
+int create_plain_streams(occ_sampler *s)
+{
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
+    HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
+    HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
+    s->main_cus = 0;
+    s->flag_sync = false;
+    return OCC_OK;
+}
+
+// ICAR model on the launch-per-step path: no CU partition, hand-overs by events (the device-counter hand-overs and
+// the partition exist for the fused kernel's sake).
+int demote_streams(occ_sampler *s)
+{
+    if (s->rsr.m > 0 || s->main_cus == 0) return OCC_OK;
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); s->side = nullptr; }
+    return create_plain_streams(s);
+}
+
+// Residency probe of the fused iteration kernel in the form s->xcd_local / xl_wide / iter_window / iter.nbg select:
+// k_iter itself (flags bit 1) -- same grid, registers and LDS as the real launch -- runs ONE barrier among the
+// workgroups of every chain with a short time limit, three times.  It passes exactly when every chain's workgroups
+// are resident together on the CUs the main stream owns (and, one XCD per chain, share that XCD: a flag carries its
+// writer's XCC_ID).  The condition it checks: workgroups per chain <= (workgroups the kernel's registers and LDS allow
+// per CU) x (CUs of the stream's mask that the dispatcher gives the chain) -- per XCD and per shader engine, which
+// only the hardware knows (26 workgroups on a 26-CU-per-XCD mask dead-locked, on 28 they ran).
+int residency_probe(occ_sampler *s, bool *ok)
+{
+    *ok = true;
+    std::vector<ChainScalars> h;
+    int rc;
+    for (int rep = 0; rep < 3 && *ok; ++rep) {
+        s->iter_flags_extra = 2;
+        LAUNCH(s, s->stream, K_ITER, 0);
+        s->iter_flags_extra = 0;
+        if ((rc = take_launch_rc(s))) return rc;
+        if ((rc = read_scalars(s, h))) return rc;
+        for (auto &sc : h)
+            if (sc.err != 0) *ok = false;
+    }
+    // the barrier state starts from scratch whatever the probes left behind
+    HIP_TRY(hipMemset(s->ctx.bar, 0, sizeof(unsigned) * (size_t)s->ctx.C * BAR_STRIDE));
+    if ((rc = read_scalars(s, h))) return rc;
+    for (auto &sc : h) { sc.bar_base = 0; sc.err = 0; }
     return write_scalars(s, h);
 }
 
@@ -799,6 +906,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         }
         s->fused_fallback = s->persistent;  // what holds without the XCD-local form
         s->persistent = s->persistent || s->xl_candidate;
+        s->tpb_plain = tpb;  // what the launch-per-step path takes when no fused form applies
         if (s->persistent) tpb = 64;
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
@@ -820,7 +928,12 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         // one XCD whatever the number of chains, two per CU
         if (s->xl_candidate) nmain = s->xl_main;  // 0: none
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
-        if (const char *split = std::getenv("OCC_CU_SPLIT")) nmain = std::atoi(split);  // 0: no masks
+        if (const char *split = std::getenv("OCC_CU_SPLIT")) {  // developer knob: CUs of the main stream; 0: no masks
+            nmain = std::atoi(split);
+            // a partition is cut in whole shader engines per XCD (see above): multiples of 32 CUs, both streams non-empty
+            if (nmain != 0 && (nmain < 32 || nmain % 32 != 0 || nmain > ncu - 32))
+                return set_error(s, OCC_E_BADARG, "OCC_CU_SPLIT must be 0 (no partition) or a multiple of 32 that leaves the side stream at least 32 CUs");
+        }
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
@@ -836,46 +949,22 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             }
             (void)hipGetLastError();
         }
-        if (s->main_cus == 0) {
-            int prio_low = 0, prio_high = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-            if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
-            HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
-            HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
-        }
+        if (s->main_cus == 0 && (rc = create_plain_streams(s))) return rc;
     }
-    // ---- one XCD per chain?  Needs the 8-wide window (two workgroups per CU), at most one chain per XCD, the
-    // chain's flags in one wave's lanes, room for nbg workgroups on the main stream's CUs of an XCD -- and a
-    // probe launch that finds every column of the (8, nbg) grid on one XCD of its own.
-    if (s->xl_candidate) {
+    // ---- which form of the fused iteration kernel?  Arithmetic first (workgroups against the CUs the main stream
+    // owns); the RESIDENCY PROBE further down -- k_iter itself, one barrier per chain -- has the last word.
+    {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-        const int cus_per_xcd = (s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount) / XL_SLOTS;
-        bool ok = s->xl_nbg <= s->xl_per_cu * cus_per_xcd;
-        if (ok) {
-            const int nbg = s->xl_nbg;
-            unsigned *probe = nullptr;
-            if ((rc = dev_alloc(s, &probe, (size_t)XL_SLOTS * nbg))) return rc;
-            for (int rep = 0; rep < 3 && ok; ++rep) {  // the dealing must not depend on what ran before
-                hipLaunchKernelGGL(k_xl_probe, dim3(XL_SLOTS, (unsigned)nbg), dim3(s->xl_wide ? ITER_WG_XL : ITER_WG), 0, s->stream, probe, nbg);
-                std::vector<unsigned> h((size_t)XL_SLOTS * nbg);
-                HIP_TRY(hipMemcpyAsync(h.data(), probe, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->stream));
-                HIP_TRY(hipStreamSynchronize(s->stream));
-                unsigned seen = 0;
-                for (int x = 0; x < XL_SLOTS && ok; ++x) {
-                    for (int y = 0; y < nbg; ++y) ok = ok && h[(size_t)x * nbg + y] == h[(size_t)x * nbg] && h[(size_t)x * nbg] != 0;
-                    ok = ok && !(seen & (1u << h[(size_t)x * nbg]));
-                    seen |= 1u << h[(size_t)x * nbg];
-                }
-            }
-        }
-        s->xcd_local = ok;
-        if (ok) {
-            s->iter.nbg = s->xl_nbg;
-        } else {  // any-placement form, if its workgroups fit the main stream's CUs two (8-wide window) per CU; else one launch per step
-            const int cus = s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount;
-            s->persistent = s->fused_fallback && (long long)s->iter.nbg * C <= 2LL * cus;
-            if (!s->persistent) tpb = 256;
+        const int cus = s->main_cus > 0 ? s->main_cus : prop.multiProcessorCount;
+        s->any_fits = s->fused_fallback && (long long)s->iter.nbg * C <= (long long)(s->iter_window == 8 ? 2 : 1) * cus;
+        s->nbg_any = s->iter.nbg;
+        const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
+        if (!trust && s->xl_candidate && s->xl_nbg > s->xl_per_cu * (cus / XL_SLOTS)) s->xl_candidate = false;
+        s->persistent = s->xl_candidate || s->any_fits;
+        if (!s->persistent) {
+            tpb = s->tpb_plain;
+            if (pb->rsr_dim == 0 && (rc = demote_streams(s))) return rc;
         }
     }
     s->tpb = tpb;
@@ -974,6 +1063,32 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         t.rhs = c.rhs; t.eta = c.eta; t.part_quad = c.part_quad; t.part_beta = c.part_beta;
         t.tau_rate = c.tau_rate; t.tau_shape = c.tau_shape;
         t.C = c.C; t.p = c.p; t.q = c.q;
+    }
+    // ---- fused iteration kernel: which form is RESIDENT?  One XCD per chain first, then any placement, else one launch
+    // per MINRES step (the partial sums stay per 64-site slice: the three paths return the same bits).
+    if (s->persistent) {
+        const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
+        bool ok = false;
+        if (s->xl_candidate) {
+            s->xcd_local = true;
+            s->iter.nbg = s->xl_nbg;
+            ok = trust;
+            if (!trust && (rc = residency_probe(s, &ok))) return rc;
+            if (!ok) s->xcd_local = false;
+        }
+        if (!ok && s->any_fits) {
+            s->xl_wide = false;
+            s->iter.nbg = s->nbg_any;
+            ok = trust;
+            if (!trust && (rc = residency_probe(s, &ok))) return rc;
+        }
+        if (!ok) {
+            s->persistent = false;
+            s->iter.nbg = s->nbg_any;
+            if ((rc = demote_streams(s))) return rc;
+            if (!s->flag_sync) { c.sync = nullptr; s->iter.sync = nullptr; }
+            if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] the fused iteration kernel is not resident on this device: one launch per MINRES step\n");
+        }
     }
     if (pb->rsr_dim > 0) {  // reduced-rank model
         const int m = pb->rsr_dim;
@@ -1093,10 +1208,8 @@ int occ_set_keys(occ_sampler *s, const uint64_t *keys)
     return write_scalars(s, h);
 }
 
-int occ_step(occ_sampler *s)
+static int step_impl(occ_sampler *s)
 {
-    if (!s) return OCC_E_BADARG;
-    HIP_TRY(hipSetDevice(s->device));
     int rc = set_window(s, 1, 0, 0);
     if (rc) return rc;
     if ((rc = eager_sequence(s))) return rc;
@@ -1107,12 +1220,8 @@ int occ_step(occ_sampler *s)
     return check_device_errors(s, h);
 }
 
-int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
+static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
 {
-    if (!s) return OCC_E_BADARG;
-    if (n_iter < 1 || burnin < 0 || burnin >= n_iter) return set_error(s, OCC_E_BADARG, "burnin value cannot be larger than sample size");
-    if (!out_alpha || !out_beta || !out_tau) return set_error(s, OCC_E_BADARG, "null output buffer");
-    HIP_TRY(hipSetDevice(s->device));
     Ctx &c = s->ctx;
     const int C = c.C, p = c.p, q = c.q;
     const int64_t keep = n_iter - burnin;
@@ -1133,8 +1242,9 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     int rc = set_window(s, n_iter, burnin, keep);
     if (rc) return rc;
     if (c.iter_clock) {  // k_iter's clock counts this run only
-        const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
-        HIP_TRY(hipMemcpyAsync(c.iter_clock, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+        // (a member, not a stack array: the copy is asynchronous and the source must outlive it)
+        s->clock_init[0] = ~0ull; s->clock_init[1] = s->clock_init[2] = s->clock_init[3] = 0ull;
+        HIP_TRY(hipMemcpyAsync(c.iter_clock, s->clock_init, sizeof(s->clock_init), hipMemcpyHostToDevice, s->stream));
     }
     std::vector<ChainScalars> h;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -1149,9 +1259,9 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         done_min = n_iter;
     } else if (s->persistent && !s->flag_sync) {
         if (!s->head[0] && (rc = build_graph(s, 0))) return rc;  // the solve is one launch: nothing to calibrate
-        if (s->need_prologue) launch_prologue(s);
+        if (s->need_prologue && (rc = launch_prologue(s))) return rc;
     } else if (s->flag_sync || s->rsr.m > 0) {
-        if (s->need_prologue) launch_prologue(s);
+        if (s->need_prologue && (rc = launch_prologue(s))) return rc;
         // the solve is one launch: nothing to calibrate.  The captured pair of iterations starts with one
         // sequence parity: an odd number of stepped iterations since the capture is realigned by one more step.
         if (s->head[0] && s->parity != s->graph_parity) {
@@ -1175,7 +1285,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
         if (force) cap = std::max(1, std::atoi(force));
         if (done_min < n_iter && (rc = build_graph(s, cap))) return rc;
     } else if (s->need_prologue) {
-        launch_prologue(s);
+        if ((rc = launch_prologue(s))) return rc;
     }
     // the first side chain waits for "the previous k_z_ob": everything enqueued so far
     if (done_min < n_iter && s->side_enabled && !s->flag_sync && s->rsr.m == 0) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
@@ -1243,6 +1353,100 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
             out_tau[(size_t)ch * keep + t] = row[q + p];
         }
     return OCC_OK;
+}
+
+
+// ---- run-time fallback of the fused iteration kernel ------------------------------------------------
+// k_iter's barriers need every workgroup of a chain resident at once.  The residency probe at creation checks that
+// on the device as it is then; another tenant of the device (a second engine, another process) can still take the CU
+// slots later.  A barrier that gives up sets the chain's error word, the enqueued batch drains in milliseconds (every
+// kernel skips such a chain), and the call is RE-RUN from the state it started with on the launch-per-step path: the
+// variates are functions of (key, iteration, index) and both paths return the same bits, so the caller gets exactly
+// what the fused path would have returned.  The engine stays on the launch-per-step path afterwards
+// (occ_stats::persistent_solve = 0, ::fused_fallbacks counts).
+static int snapshot_take(occ_sampler *s)
+{
+    const Ctx &c = s->ctx;
+    const size_t Cn = (size_t)c.C * c.n;
+    int rc;
+    if (!s->snap_eta) {
+        if ((rc = dev_alloc(s, &s->snap_eta, Cn, false))) return rc;
+        if ((rc = dev_alloc(s, &s->snap_z, Cn, false))) return rc;
+        if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
+    }
+    if ((rc = read_scalars(s, s->snap_sc))) return rc;
+    s->snap_parity = s->parity;
+    HIP_TRY(hipMemcpyAsync(s->snap_eta, c.eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->snap_z, c.z, Cn, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->snap_x, c.Xv, sizeof(double2) * Cn, hipMemcpyDeviceToDevice, s->stream));
+    return OCC_OK;
+}
+
+static int fallback_to_launch_per_step(occ_sampler *s)
+{
+    Ctx &c = s->ctx;
+    const size_t Cn = (size_t)c.C * c.n;
+    (void)hipStreamSynchronize(s->stream);
+    if (s->side) (void)hipStreamSynchronize(s->side);
+    (void)hipGetLastError();
+    if (std::getenv("OCC_VERBOSE") || !std::getenv("OCC_QUIET"))
+        std::fprintf(stderr, "[occ] device-side wait timed out in the fused iteration kernel (%s); re-running the call with one launch per MINRES step\n",
+                     s->err.c_str());
+    destroy_graph(s);
+    s->persistent = false;
+    s->xcd_local = false;
+    s->device_timeout = false;
+    s->launch_rc = OCC_OK;
+    int rc;
+    if ((rc = demote_streams(s))) return rc;
+    s->flag_sync = false;
+    c.sync = nullptr;
+    s->iter.sync = nullptr;
+    HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.eta, s->snap_eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(c.z, s->snap_z, Cn, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(c.Xv, s->snap_x, sizeof(double2) * Cn, hipMemcpyDeviceToDevice));
+    for (auto &sc : s->snap_sc) sc.err = 0;
+    if ((rc = write_scalars(s, s->snap_sc))) return rc;
+    s->parity = s->snap_parity;
+    s->need_prologue = true;
+    s->calib_max = 0;
+    s->fused_fallbacks += 1;
+    return OCC_OK;
+}
+
+int occ_step(occ_sampler *s)
+{
+    if (!s) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    const bool fused = s->persistent && s->rsr.m == 0;
+    int rc;
+    if (fused && (rc = snapshot_take(s))) return rc;
+    s->device_timeout = false;
+    rc = step_impl(s);
+    if (rc == OCC_E_HIP && fused && s->device_timeout) {
+        if ((rc = fallback_to_launch_per_step(s))) return rc;
+        rc = step_impl(s);
+    }
+    return rc;
+}
+
+int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
+{
+    if (!s) return OCC_E_BADARG;
+    if (n_iter < 1 || burnin < 0 || burnin >= n_iter) return set_error(s, OCC_E_BADARG, "burnin value cannot be larger than sample size");
+    if (!out_alpha || !out_beta || !out_tau) return set_error(s, OCC_E_BADARG, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    const bool fused = s->persistent && s->rsr.m == 0;
+    int rc;
+    if (fused && (rc = snapshot_take(s))) return rc;
+    s->device_timeout = false;
+    rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
+    if (rc == OCC_E_HIP && fused && s->device_timeout) {
+        if ((rc = fallback_to_launch_per_step(s))) return rc;
+        rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
+    }
+    return rc;
 }
 
 int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, int64_t cap, int64_t *len)
@@ -1382,6 +1586,7 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->persistent_solve = s->persistent ? (s->xcd_local ? 2 : 1) : 0;
     out->solve_workgroups = s->iter.nbg;
     out->main_stream_cus = s->main_cus;
+    out->fused_fallbacks = (int32_t)s->fused_fallbacks;
     out->profile_minres_iterations = s->profile_minres_iterations;
     out->iter_kernel_launches = 0;
     out->iter_kernel_mean_us = 0.0;
@@ -1405,7 +1610,7 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int e, int extr
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    for (int r = 0; r < reps; ++r) launch_kind(s, s->stream, kind, e, extra);
+    for (int r = 0; r < reps; ++r) LAUNCH(s, s->stream, kind, e, extra);
     HIP_TRY(hipStreamEndCapture(s->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, s->stream));  // untimed: instruction cache, clocks
@@ -1418,7 +1623,7 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int e, int extr
     *avg_us = 1000.0 * ms / reps;
     (void)hipGraphExecDestroy(exec);
     (void)hipGraphDestroy(graph);
-    return OCC_OK;
+    return take_launch_rc(s);
 }
 
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS], double total_us[OCC_N_KERNEL_KINDS])
@@ -1436,7 +1641,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     if (s->persistent) {
         std::vector<ChainScalars> h0;
         if ((rc = read_scalars(s, h0))) return rc;
-        if (s->need_prologue) launch_prologue(s);
+        if (s->need_prologue && (rc = launch_prologue(s))) return rc;
         // hand-overs as in occ_run: device counters, or stream events; OCC_EAGER_ONLY (counter collection
         // serialises kernels): everything on the main stream in the reference's order, no hand-overs at all
         const bool one_stream = std::getenv("OCC_EAGER_ONLY") != nullptr || !s->side_enabled;
@@ -1449,16 +1654,16 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             const int pe = s->parity;
             hipStream_t side = one_stream ? s->stream : s->side;
             if (ev) HIP_TRY(hipStreamWaitEvent(side, s->ev_z[pe ^ 1], 0));
-            if (flags) launch_kind(s, side, K_GATE, 0);
-            launch_kind(s, side, K_OMEGA_A, pe);
-            launch_kind(s, side, K_ALPHA_DRAW, pe);
-            launch_kind(s, side, K_NOISE, pe, 1);
+            if (flags) LAUNCH(s, side, K_GATE, 0);
+            LAUNCH(s, side, K_OMEGA_A, pe);
+            LAUNCH(s, side, K_ALPHA_DRAW, pe);
+            LAUNCH(s, side, K_NOISE, pe, 1);
             if (ev) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
             HIP_TRY(hipEventRecord(s->ev0, s->stream));
-            launch_kind(s, s->stream, K_ITER, pe);
+            LAUNCH(s, s->stream, K_ITER, pe);
             HIP_TRY(hipEventRecord(s->ev1, s->stream));
             if (ev) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
-            launch_kind(s, s->stream, K_Z_OB, pe);
+            LAUNCH(s, s->stream, K_Z_OB, pe);
             if (ev) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
             s->parity ^= 1;
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1478,7 +1683,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     const int e = s->parity;
     double us = 0.0;
     // the kernels below are replayed out of sequence: no waits, no counter updates
-    struct NoSync { occ_sampler *s; explicit NoSync(occ_sampler *p) : s(p) { s->launch_sync = false; } ~NoSync() { s->launch_sync = true; } } no_sync(s);
+    struct NoSync { occ_sampler *s; bool old; explicit NoSync(occ_sampler *p) : s(p), old(p->launch_sync) { s->launch_sync = false; } ~NoSync() { s->launch_sync = old; } } no_sync(s);
     auto timed = [&](int kind, int extra) -> int {
         int r = time_kernel_graph(s, kind, reps, e, extra, &us);
         counts[kind] = reps;
@@ -1501,8 +1706,8 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        launch_kind(s, s->stream, K_ETA_INIT, e);
-        for (int k = 1; k <= KRY_TIMED; ++k) launch_kind(s, s->stream, K_MINRES, e, k);
+        LAUNCH(s, s->stream, K_ETA_INIT, e);
+        for (int k = 1; k <= KRY_TIMED; ++k) LAUNCH(s, s->stream, K_MINRES, e, k);
         HIP_TRY(hipStreamEndCapture(s->stream, &graph));
         HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIP_TRY(hipGraphLaunch(exec, s->stream));
@@ -1521,7 +1726,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     }
     // finish that solve so that the tail kernels have real work
     int k_last = 0;
-    launch_kind(s, s->stream, K_ETA_INIT, e);
+    LAUNCH(s, s->stream, K_ETA_INIT, e);
     if ((rc = eager_krylov(s, 1, &k_last))) return rc;
     if ((rc = timed(K_BETA_PARTIAL, k_last))) return rc;
     // k_z_ob advances the control word of the OTHER parity; launched repeatedly with the same parity
@@ -1529,6 +1734,36 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     if ((rc = timed(K_Z_OB, 0))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_prologue = true;
+    return take_launch_rc(s);
+}
+
+// Device draws of the engine's own variate generators (see the header).
+int occ_draw(int32_t device, int32_t kind, uint64_t key, uint32_t iteration, uint32_t stream, int64_t n, const double *param, double *out)
+{
+    if (n < 0 || n > 0x7fffffffLL || !out || kind < 0 || kind > 3 || ((kind == 0 || kind == 1) && !param && n > 0)) {
+        g_create_error = "occ_draw: bad arguments";
+        return OCC_E_BADARG;
+    }
+    if (n == 0) return OCC_OK;
+    double *d_par = nullptr, *d_out = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(double) * (size_t)n);
+    if (e == hipSuccess && param) {
+        e = hipMalloc((void **)&d_par, sizeof(double) * (size_t)n);
+        if (e == hipSuccess) e = hipMemcpy(d_par, param, sizeof(double) * (size_t)n, hipMemcpyDefault);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (int)kind, key, iteration, stream, (long long)n,
+                           (const double *)d_par, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+    if (d_par) (void)hipFree(d_par);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        g_create_error = std::string("occ_draw: ") + hipGetErrorString(e);
+        return OCC_E_HIP;
+    }
     return OCC_OK;
 }
 

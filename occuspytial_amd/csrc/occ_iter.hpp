@@ -45,6 +45,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter, any placement
 constexpr int ITER_WG_XL = 512;                 // ... one XCD per chain: two waves per SIMD IN one workgroup (see k_iter)
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
+constexpr unsigned ITER_PROBE_SPIN_LIMIT = 1u << 14;  // ... in the residency probe at creation (flags bit 1 of k_iter)
 constexpr int BAR_STRIDE = 64;                  // unsigned words per chain in IterArgs::bar: the counter, or one flag per workgroup
 constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch = XCDs the grid's x dimension walks over
 
@@ -111,6 +112,18 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
 // XL form: ARRIVE stores the workgroup's flag = (barrier number << 4) | XCC_ID (plain store); WAIT: the first wave
 // loads all nbg (<= 64) flags of the chain, one per lane (sc1), until every flag has reached the barrier number,
 // then checks that every writer sits on the reader's XCD.
+// A barrier that gives up says so in the chain's error word at once (agent scope): the other workgroups of the chain
+// look at it every 1024 polls, workgroups that start later see it at kernel entry, and every later kernel of the
+// enqueued batch skips the chain -- a failed launch drains in milliseconds and the host re-runs the call on the
+// launch-per-step path (occ_gibbs.hip, run_with_fallback).
+__device__ __forceinline__ int chain_err(const ChainScalars &sc)
+{
+    return __hip_atomic_load(&sc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_fail(ChainScalars &sc)
+{
+    __hip_atomic_store(&sc.err, -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // OCC_E_HIP
+}
 #define BAR_STAMP(pt)
 #define OCC_CHAIN_ARRIVE()                                                                                 \
     do {                                                                                                   \
@@ -135,10 +148,14 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
                     if ((int)threadIdx.x >= ia.nbg) flag_ = want_ | my_xcc;                                \
                     if (__all((int)((flag_ & ~15u) - want_) >= 0)) break;                                  \
                     __builtin_amdgcn_s_sleep(1);                                                           \
-                    if (++spins_ > ITER_SPIN_LIMIT) { fail_ = 1; break; }                                  \
+                    if (++spins_ > spin_limit) { fail_ = 1; break; }                                       \
+                    if ((spins_ & 1023u) == 0u && chain_err(sc) != 0) { fail_ = 1; break; } /* another workgroup gave up */ \
                 }                                                                                          \
                 if (!fail_ && __any((flag_ & 15u) != my_xcc)) fail_ = 1; /* a workgroup of the chain on another XCD */ \
-                if (threadIdx.x == 0) fail_flag = fail_;                                                   \
+                if (threadIdx.x == 0) {                                                                    \
+                    fail_flag = fail_;                                                                     \
+                    if (fail_) chain_fail(sc);                                                             \
+                }                                                                                          \
             }                                                                                              \
         } else if (threadIdx.x == 0) {                                                                     \
             const unsigned target_ = bar_base + nbar * (unsigned)ia.nbg;                                   \
@@ -146,9 +163,11 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
             unsigned spins_ = 0;                                                                           \
             while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target_) < 0) { \
                 __builtin_amdgcn_s_sleep(1);                                                               \
-                if (++spins_ > ITER_SPIN_LIMIT) { fail_ = 1; break; }                                      \
+                if (++spins_ > spin_limit) { fail_ = 1; break; }                                           \
+                if ((spins_ & 1023u) == 0u && chain_err(sc) != 0) { fail_ = 1; break; }                    \
             }                                                                                              \
             fail_flag = fail_;                                                                             \
+            if (fail_) chain_fail(sc);                                                                     \
         }                                                                                                  \
         BAR_STAMP(5)                                                                                       \
         __syncthreads();                                                                                   \
@@ -206,12 +225,6 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
         default: { constexpr int D = 8; CALL; } break;                                                     \
     }
 
-// Placement probe for the XL form: the XCC_ID (+ 1) of every workgroup of a (XL_SLOTS, nbg) grid.
-__global__ void __launch_bounds__(ITER_WG_XL) k_xl_probe(unsigned *out, int nbg)
-{
-    if (threadIdx.x == 0) out[blockIdx.x * nbg + blockIdx.y] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) + 1u;
-}
-
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
 //
@@ -221,9 +234,17 @@ __global__ void __launch_bounds__(ITER_WG_XL) k_xl_probe(unsigned *out, int nbg)
 // the whole recurrence and the second arrived a microsecond late at every barrier.  With both waves of a SIMD in
 // ONE workgroup the uniform work (tau, the re-reduction of the partial sums, minres_pre / minres_post) is done by
 // wave 0 alone, the others sleep at the workgroup barrier, and the step's coefficients travel through LDS.
+//
+// flags: bit 0 = hand over to / from the side stream through the device counters; bit 1 = RESIDENCY PROBE: the launch
+// does nothing but one barrier among the workgroups of every chain, with a short time limit -- the same kernel, grid,
+// registers and LDS as the real launch, so it passes exactly when all workgroups of a chain are resident together
+// (and, XL, sit on one XCD: the flags carry their writers' XCC_ID).  The host runs it at creation (create_impl).
 template <int NW, int XL, int W512>
-__global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512) ? 2 : 1) k_iter(const IterArgs ia, int e, int sync_on)
+__global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512) ? 2 : 1) k_iter(const IterArgs ia, int e, int flags)
 {
+    const bool probe = (flags & 2) != 0;
+    const int sync_on = probe ? 0 : (flags & 1);
+    const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
     constexpr int WGT = W512 ? ITER_WG_XL : ITER_WG;
     constexpr bool SHARE = W512 != 0;  // two waves per SIMD in this workgroup: wave 0 does the uniform work for all
     __shared__ int s_flag, s_noise_ok;
@@ -242,7 +263,8 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     const bool writer = (wg == 0 && threadIdx.x == 0);
-    if (ctl.koff || ctl.it >= sc.it_stop) {  // uniform over the chain's workgroups
+    // (a chain whose error word is set idles like a finished one: see chain_fail)
+    if (!probe && (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0)) {  // uniform over the chain's workgroups
         if (writer) sc.mid[e] = ctl;
         return;
     }
@@ -275,6 +297,12 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const __amdgpu_buffer_rsrc_t pbuf[2] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000)};
+    if (probe) {  // residency / placement probe: one barrier, nothing else
+        ++nbar;
+        OCC_CHAIN_BARRIER(s_flag);
+        if (writer) sc.bar_base = bar_base + nbar * (XL ? 1u : (unsigned)ia.nbg);
+        return;
+    }
 
     // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
     PHASE_STAMP(0, 0)
@@ -543,11 +571,11 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         }
         PHASE_STAMP(STAMP_STEPS - 1, 1)
     } else if (writer) {
-        sc.err = -2;  // OCC_E_HIP: reported by the host as an over-subscribed persistent launch
+        chain_fail(sc);  // OCC_E_HIP: the host falls back to one launch per MINRES step
         s.done = 1; s.istop = 6; s.itn = k;
     }
     double eta = 0.0;
-    if (act) {
+    if (act && !failed) {  // a failed solve leaves the warm start and eta as they were: the host re-runs the iteration
         eta = eta_project(x, proj_a);
         a.Xv[co + i] = x;
         ia.eta[co + i] = eta;

@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
     const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     double beta[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on
         c.sync[SYNC_SIDE_SEQ] = j + 1u;         // read next by k_gate, the next kernel of the stream
     }
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const int i = blk * blockDim.x + threadIdx.x;
     if (i >= c.n) return;
     noise_site(c, sc.key, chain, i, ctl.it + (uint32_t)ahead);
@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
     const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     const uint32_t it = ctl.it;
     double quad[1];
@@ -945,6 +945,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     // ---- level 1: everything whose address is known from the kernel arguments --------------------
     const Ctl ctl = sc.ctl[e];
     const unsigned it_stop = sc.it_stop;
+    const int chain_error = sc.err;  // a chain whose error word is set idles (occ_iter.hpp, chain_fail)
     const double tau = sc.tau;
     Slot s = slot_load(&a.slots[(size_t)chain * NSLOT + ((kl - 1) & (NSLOT - 1))]);
     Slot *out = &a.slots[(size_t)chain * NSLOT + (kl & (NSLOT - 1))];
@@ -1024,7 +1025,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
             if (kk < width) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; n3[kk] = P3[col[kk]]; }
         }
     }
-    if (ctl.it >= it_stop) return;
+    if (ctl.it >= it_stop || chain_error != 0) return;
     const bool writer = (blk == 0 && threadIdx.x == 0);
     if (s.done) {
         if (writer) slot_store(out, s);
@@ -1132,7 +1133,7 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     // the last Krylov kernel of this launch sequence wrote slot k_last_launch & 3
     const Slot *fin = &slots[(size_t)chain * NSLOT + (k_last_launch & (NSLOT - 1))];
     struct { int done, itn, istop; } s = {fin->done, fin->itn, fin->istop};
-    const bool skip = ctl.it >= sc.it_stop;
+    const bool skip = ctl.it >= sc.it_stop || sc.err != 0;
     const bool carry = !skip && !s.done;
     if (blk == 0 && threadIdx.x == 0) {
         Ctl m = ctl;
@@ -1248,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
     const int chain = tile.chain, blk = tile.blk;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     double acc[nacc(Q)];
     omega_a_row<Q>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
     block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
@@ -1263,7 +1264,7 @@ __global__ void __launch_bounds__(512) k_alpha_draw(OCC_KARGS, int sync_on)
     const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (!(ctl.koff || ctl.it >= sc.it_stop)) {
+    if (!(ctl.koff || ctl.it >= sc.it_stop || sc.err != 0)) {
         const int Q = c.q;
         reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
         if (threadIdx.x == 0) {
@@ -1339,7 +1340,7 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     const int chain = tile.chain, blk = tile.blk;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.mid[e];
-    const bool skip = ctl.koff || ctl.it >= sc.it_stop;
+    const bool skip = ctl.koff || ctl.it >= sc.it_stop || sc.err != 0;
     // per_wave: 256-thread blocks over 64-site slices (c.nb_n of them): beta is formed by wave 0 for the block
     const int nb = per_wave ? (c.n + (int)blockDim.x - 1) / (int)blockDim.x : c.nb_n;
     const uint32_t it = ctl.it;
@@ -1416,6 +1417,26 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: s
     // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
     const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
     z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0);
+}
+
+
+// Variates of the generators above, element i from the sub-stream (key, i, iteration, stream) exactly as the kernels of the
+// iteration draw them (occ_draw in the C ABI: known-answer and distributional tests on DEVICE draws).
+enum : int { DRAW_PG1 = 0, DRAW_STD_GAMMA = 1, DRAW_NORMAL = 2, DRAW_UNIFORM = 3 };
+__global__ void __launch_bounds__(256) k_draw(int kind, uint64_t key, uint32_t it, uint32_t stream, long long n, const double *__restrict__ param,
+                                              double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Cursor cur(key, (uint32_t)i, it, stream);
+    double v;
+    switch (kind) {
+        case DRAW_PG1: v = pg1_draw(cur, param[i]); break;
+        case DRAW_STD_GAMMA: v = std_gamma(cur, param[i]); break;
+        case DRAW_NORMAL: v = block_normal(key, (uint32_t)i, 0, it, stream); break;
+        default: v = block_uniform(key, (uint32_t)i, 0, it, stream); break;
+    }
+    out[i] = v;
 }
 
 }  // namespace occ

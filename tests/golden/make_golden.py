@@ -71,14 +71,24 @@ def build_reference():
         with open(os.path.join(shim, 'polyagamma', '__init__.py'), 'w') as fh:
             fh.write(textwrap.dedent('''
                 """Import shim (NOT the polyagamma package): truncated-series PG(1, z) stand-in."""
+                import os
                 import numpy as np
                 calls = []
                 def random_polyagamma(h, z, *, disable_checks=False, random_state=None):
                     z = np.asarray(z, dtype=float)
                     k = np.arange(1, 201) - 0.5
                     g = random_state.standard_exponential((z.size, 200))
-                    out = (g / (k ** 2 + (z.reshape(-1, 1) / (2 * np.pi)) ** 2)).sum(axis=1) / (2 * np.pi ** 2)
-                    calls.append((z.copy(), out.copy()))
+                    c = z.reshape(-1, 1) / (2 * np.pi)
+                    ser = (g / (k ** 2 + c ** 2)).sum(axis=1)
+                    if os.environ.get('OCC_GOLDEN_PG_TAIL'):
+                        # whole-chain runs: add the MEAN of the dropped terms k > 200, sum 1/((k-1/2)^2 + c^2)
+                        # = atan(c/200)/c (midpoint rule, exact to 1e-9), so that E[PG] is exact; what is
+                        # missing is the tail's variance, 3e-9 of the total
+                        cc = np.abs(c.ravel())
+                        ser = ser + np.where(cc > 1e-8, np.arctan(cc / 200.0) / np.maximum(cc, 1e-300), 1.0 / 200.0)
+                    out = ser / (2 * np.pi ** 2)
+                    if not os.environ.get('OCC_GOLDEN_PG_TAIL'):
+                        calls.append((z.copy(), out.copy()))
                     return out
             '''))
         with open(os.path.join(shim, 'arviz', '__init__.py'), 'w') as fh:
@@ -292,6 +302,32 @@ def capture_rsr_case(name, Q, W, X, y, seed, iters=3, **rsr_kw):
     print(name, 'n =', n, 'basis columns =', r)
 
 
+def capture_reference_chains(name, Q, W, X, y, seed, hparams=None, chains=4, size=6000, burnin=1000):
+    """Whole chains of the REFERENCE sampler: ``LogitICARGibbs(...).sample(size, burnin, chains=4)`` exactly as a user
+    calls it (reference gibbs/base.py:243-291 -> gibbs/parallel.py:4-42: one joblib process per chain, chain k on the
+    k-th generator; gibbs/logit.py:254-266 per iteration, dense eigenfactor prior draw logit.py:66-67,77, scipy MINRES).
+    The only stand-in is PG(1, z): the truncated defining series of the import shim plus the mean of the dropped tail
+    (``OCC_GOLDEN_PG_TAIL``).  Stored: the kept alpha / beta / tau draws -- the fixture of the DISTRIBUTIONAL parity
+    tests (tests/test_reference_chains.py, tests/test_gpu_api.py), the only tests that can catch an error shared by the
+    oracle and the device in the edge-form prior term or the Polya-Gamma sampler."""
+    from occuspytial.gibbs.logit import LogitICARGibbs
+    os.environ['OCC_GOLDEN_PG_TAIL'] = '1'
+    try:
+        s = LogitICARGibbs(Q, W, X, y, hparams=hparams, random_state=seed)
+        res = s.sample(size, burnin=burnin, chains=chains, progressbar=False)
+        # float32: the draws feed distributional tests only (half the fixture size)
+        out = {'alpha': np.asarray(res['alpha'], dtype=np.float32), 'beta': np.asarray(res['beta'], dtype=np.float32),
+               'tau': np.asarray(res['tau'], dtype=np.float32),
+               'seed': np.int64(seed), 'size': np.int64(size), 'burnin': np.int64(burnin)}
+        for k, v in (hparams or {}).items():
+            out['hp_' + k] = np.asarray(v, dtype=float)
+    finally:
+        del os.environ['OCC_GOLDEN_PG_TAIL']
+    assert out['alpha'].shape[:2] == (chains, size - burnin) and out['tau'].shape == (chains, size - burnin)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'reference chains', out['alpha'].shape, 'tau mean', out['tau'].mean(axis=1))
+
+
 def capture_native_helpers():
     """precision_mvnorm / ensure_sums_to_zero (reference distributions.pyx:24-110) known answers."""
     from occuspytial.distributions import ensure_sums_to_zero, precision_mvnorm
@@ -322,6 +358,17 @@ def capture_native_helpers():
     print('native_helpers', msg)
 
 
+def weighted_graph_case():
+    from occuspytial_amd.utils import get_generator, make_graph_problem
+    Qg, Wg, Xg, yg, *_ = make_graph_problem(n=300, k=6, visits=4, p=2, q=3, random_state=5)
+    A = -sparse.triu(Qg, k=1).tocoo()
+    wts = get_generator(7).uniform(0.5, 2.0, A.nnz)
+    Aw = sparse.coo_matrix((wts, (A.row, A.col)), shape=A.shape)
+    Aw = Aw + Aw.T
+    Qw = (sparse.diags(np.asarray(Aw.sum(axis=1)).ravel()) - Aw).tocsr()
+    return Qw, Wg, Xg, yg
+
+
 def main():
     build_reference()
     from occuspytial_amd.utils import get_generator, make_graph_problem, rand_precision_mat, _expit
@@ -343,9 +390,30 @@ def main():
         Wi[:, 0] = 1
         W[int(i)] = Wi
         y[int(i)] = rng.binomial(1, z[i] * _expit(Wi @ alpha))
-    capture_case('ref_queen150_ragged', Q, W, X, y, seed=10)
     hyp = {'tau_rate': 1.0, 'tau_shape': 5.0, 'a_mu': np.array([0.3, -0.2]), 'b_mu': np.array([0.1, 0.2, -0.4]),
            'a_prec': np.eye(2), 'b_prec': np.array([[1.0, 0.2, 0.0], [0.2, 2.0, 0.1], [0.0, 0.1, 0.5]])}
+    only_chains = '--chains-only' in sys.argv
+    if only_chains or '--with-chains' in sys.argv:
+        # whole reference chains (default hyper-parameters twice; informative tau prior once, where tau mixes)
+        capture_reference_chains('refchain_queen150_ragged', Q, W, X, y, seed=10)
+        # informative Gamma(25, 25) prior on tau: the conditional's shape is (n - 1)/2 + 1/2 + 25 (gibbs/base.py:177-186
+        # puts the likelihood's (n - 1)/2 into `tau_shape` itself), so tau mixes and is part of the comparison
+        hyp_tau = dict(hyp, tau_rate=25.0, tau_shape=0.5 + 0.5 * (n - 1) + 25.0)
+        capture_reference_chains('refchain_queen150_tauprior', Q, W, X, y, seed=3, hparams=hyp_tau)
+        from occuspytial_amd.utils import make_lattice_problem as _mlp
+        Qb, Wb, Xb, yb, *_ = _mlp(20, 20, visits=3, p=2, q=2, max_neighbors=8, random_state=0)
+        capture_reference_chains('refchain_queen400_v3', Qb, Wb, Xb, yb, seed=10)
+        hyp400 = {'tau_rate': 25.0, 'tau_shape': 0.5 + 0.5 * 399 + 25.0, 'a_mu': np.zeros(2), 'a_prec': np.eye(2) / 10,
+                  'b_mu': np.zeros(2), 'b_prec': np.eye(2) / 10}
+        capture_reference_chains('refchain_queen400_tauprior', Qb, Wb, Xb, yb, seed=11, hparams=hyp400)
+        # irregular graph with WEIGHTED edges (the edge form draws sqrt(w_ij) eps_ij per edge), informative tau prior
+        Qw, Wg, Xg, yg = weighted_graph_case()
+        hyp300 = {'tau_rate': 25.0, 'tau_shape': 0.5 + 0.5 * 299 + 25.0, 'a_mu': np.zeros(3), 'a_prec': np.eye(3) / 10,
+                  'b_mu': np.zeros(2), 'b_prec': np.eye(2) / 10}
+        capture_reference_chains('refchain_graph300_weighted_tauprior', Qw, Wg, Xg, yg, seed=21, hparams=hyp300)
+        if only_chains:
+            return
+    capture_case('ref_queen150_ragged', Q, W, X, y, seed=10)
     capture_case('ref_queen150_hparams', Q, W, X, y, seed=3, hparams=hyp, iters=2)
 
     # case B: BASELINE config 1 -- 20x20 lattice, 3 visits, p=q=2, all surveyed (rook and queen)
@@ -355,12 +423,7 @@ def main():
         capture_case(f'ref_{tag}400_v3', Qb, Wb, Xb, yb, seed=10)
 
     # case C: irregular adjacency, weighted edges (still a graph Laplacian), 300 units
-    Qg, Wg, Xg, yg, *_ = make_graph_problem(n=300, k=6, visits=4, p=2, q=3, random_state=5)
-    A = -sparse.triu(Qg, k=1).tocoo()
-    wts = get_generator(7).uniform(0.5, 2.0, A.nnz)
-    Aw = sparse.coo_matrix((wts, (A.row, A.col)), shape=A.shape)
-    Aw = Aw + Aw.T
-    Qw = (sparse.diags(np.asarray(Aw.sum(axis=1)).ravel()) - Aw).tocsr()
+    Qw, Wg, Xg, yg = weighted_graph_case()
     capture_case('ref_graph300_weighted', Qw, Wg, Xg, yg, seed=21)
 
     capture_native_helpers()

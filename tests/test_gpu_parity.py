@@ -346,6 +346,29 @@ def _lockstep(oracle, prob, start, n_iter, key=KEY):
     eng.close()
 
 
+def _lockstep_chains(oracle, prob, starts, keys, n_iter):
+    """All-conditionals lock step of a BATCH of chains: chain c of the engine against its own oracle sampler."""
+    from occuspytial_amd._engine import Engine
+    eng = Engine(prob, keys)
+    orcs = [oracle.OracleSampler(prob, k) for k in keys]
+    for c, st in enumerate(starts):
+        eng.set_start(c, **st)
+        orcs[c].set_start(**st)
+    worst = {}
+    for _ in range(n_iter):
+        eng.step()
+        for c, orc in enumerate(orcs):
+            orc.step()
+            for k, v in _compare_iteration(eng, orc, prob, chain=c).items():
+                worst[k] = max(worst.get(k, 0.0), v)
+        for c, orc in enumerate(orcs):
+            for name in ('alpha', 'beta', 'tau', 'eta', 'z', 'xz'):
+                eng.set(name, orc.get(name), c)
+    stats = eng.stats()
+    eng.close()
+    return worst, stats
+
+
 def _random_start(prob, seed):
     rng = np.random.default_rng(seed)
     eta = rng.standard_normal(prob.n)
@@ -386,6 +409,39 @@ def test_500x500_lattice_full_size_lockstep(oracle):
     prob = FlatProblem(Q, W, X, y)
     assert prob.n == 250_000 and prob.R == 1_250_000
     _lockstep(oracle, prob, _random_start(prob, 9), 2)
+
+
+def test_headline_config_100x100_four_chains_lockstep(oracle):
+    """BASELINE config 2 / the metric's workload at full size: 100x100 queen lattice, 5 visits, FOUR chains batched
+    (the fused iteration kernel, one XCD per chain, 512-thread workgroups): three lock-step iterations, every
+    conditional of every chain against its oracle; the measured worst-case deviations are asserted, not only the bounds."""
+    from occuspytial_amd._problem import FlatProblem, chain_generators, default_start
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(100, 100, visits=5, p=2, q=2, random_state=0)
+    prob = FlatProblem(Q, W, X, y)
+    gens = chain_generators(10, 4)                      # bench.py's chains: same seeds, same default starts
+    starts = [default_start(g, prob) for g in gens]
+    keys = [int(g.bit_generator.random_raw()) for g in gens]
+    worst, stats = _lockstep_chains(oracle, prob, starts, keys, 3)
+    assert stats['persistent_solve'] == 2 and stats['n_chains'] == 4 and stats['fused_fallbacks'] == 0
+    # the scalar recurrence divides once and multiplies (DESIGN 2.6): measured worst case 1.4e-8 on xz
+    assert worst['xz'] < 3e-8 and worst['eta'] < 6e-8, worst
+    print('100x100 x 4 chains lock step, worst relative deviations:', {k: float('%.2e' % v) for k, v in worst.items()})
+
+
+def test_config5_full_size_four_chains_lockstep(oracle):
+    """BASELINE config 5 at its stated size: irregular areal graph, 3 000 units, mean degree ~ 6 (rows of up to 16
+    off-diagonals: k_iter's 16-wide window), 10 visits per unit, FOUR chains: three lock-step iterations."""
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_graph_problem
+    Q, W, X, y, *_ = make_graph_problem(3000, 6, visits=10, p=2, q=2, random_state=0)
+    deg = np.diff(Q.indptr) - 1
+    assert Q.shape[0] == 3000 and 5.0 < deg.mean() < 8.0
+    prob = FlatProblem(Q, W, X, y)
+    assert prob.R == 30_000
+    starts = [_random_start(prob, 40 + c) for c in range(4)]
+    worst, stats = _lockstep_chains(oracle, prob, starts, [KEY + 13 * c for c in range(4)], 3)
+    assert stats['n_chains'] == 4 and stats['persistent_solve'] >= 1
 
 
 def test_eight_chains_of_config3_run_and_differ():
@@ -502,3 +558,65 @@ def test_reduced_rank_graph_replay_equals_stepping_and_batching(monkeypatch, env
     assert abs(batch.get('eta', 0) - prob.rsr['K'] @ batch.get('theta', 0)).max() < 1e-12
     batch.close()
     solo.close()
+
+
+# ---- residency guard and run-time fallback of the fused iteration kernel -------------------------------------
+def _headline_run(iters=24):
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(100, 100, visits=5, p=2, q=2, random_state=0)
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY + 5 * c for c in range(4)]
+    eng = Engine(prob, keys)
+    for c in range(4):
+        eng.set_start(c, **_random_start(prob, 60 + c))
+    st0 = eng.stats()
+    rec = eng.run(iters, 0)
+    rec2 = eng.run(7, 2)                                  # the engine keeps working after a fallback
+    state = [(eng.get('eta', c), eng.get('z', c), eng.get('xz', c)) for c in range(4)]
+    st1 = eng.stats()
+    eng.close()
+    return rec + rec2, state, st0, st1
+
+
+def test_undersized_cu_partition_is_refused_or_demoted_at_creation(monkeypatch):
+    """OCC_CU_SPLIT that is not a whole-shader-engine partition is a ValueError; a valid but under-sized one (32 CUs
+    for 80 workgroups of 512 threads) is caught by the arithmetic / the residency probe at creation: the engine
+    takes the launch-per-step path on plain streams and returns the same bits as the default configuration."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    ref = _headline_run()
+    assert ref[2]['persistent_solve'] == 2
+    monkeypatch.setenv('OCC_CU_SPLIT', '26')
+    Q, W, X, y, *_ = make_lattice_problem(12, 12, visits=3, p=2, q=2, random_state=1)
+    with pytest.raises(ValueError, match='OCC_CU_SPLIT'):
+        Engine(FlatProblem(Q, W, X, y), [KEY])
+    monkeypatch.setenv('OCC_CU_SPLIT', '32')
+    alt = _headline_run()
+    assert alt[2]['persistent_solve'] == 0 and alt[2]['main_stream_cus'] == 0 and alt[3]['fused_fallbacks'] == 0
+    for u, v in zip(ref[0], alt[0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(ref[1], alt[1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+
+
+def test_barrier_timeout_falls_back_to_launch_per_step_with_the_same_bits(monkeypatch):
+    """The time-out path for real: with the residency probe switched off (debug knob) the one-XCD-per-chain form is
+    launched on a 32-CU partition -- 4 CUs per XCD for a chain's 20 workgroups of one per CU, so 16 of them are never
+    resident with the first 4 and the first barrier gives up.  The call is re-run from its start state on the
+    launch-per-step path: same records, same state, bit for bit; the engine stays usable (second run)."""
+    ref = _headline_run()
+    monkeypatch.setenv('OCC_CU_SPLIT', '32')
+    monkeypatch.setenv('OCC_DEBUG_SKIP_RESIDENCY_PROBE', '1')
+    monkeypatch.setenv('OCC_QUIET', '1')
+    alt = _headline_run()
+    assert alt[2]['persistent_solve'] == 2                       # what creation believed
+    assert alt[3]['persistent_solve'] == 0 and alt[3]['fused_fallbacks'] == 1
+    for u, v in zip(ref[0], alt[0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(ref[1], alt[1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
