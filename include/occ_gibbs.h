@@ -147,6 +147,35 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
 
+/* ---- per-conditional entry points with INJECTED variates ---------------------------------------------------
+ * One conditional update of ONE chain of the ICAR model, run on the device by the kernels of the launch-per-step path
+ * (grid over that chain only), with the random variates the reference would have drawn supplied by the caller instead
+ * of the chain's Philox streams.  Inputs that are not arguments are the chain's current state (occ_set_start /
+ * occ_set_state: alpha, beta, tau, eta, z, xz).  They exist so that a test can feed the inputs and the recorded
+ * variates of the REFERENCE's own run (tests/golden/\*.npz) and compare with the reference's recorded outputs in one
+ * hop (tests/test_gpu_golden.py); the Polya-Gamma variates (omega_b, omega_a) are inputs, since their draw counts are
+ * data dependent.  The chain's iteration number does not advance; results are also left in the chain's state, so the
+ * calls chain like the reference's _update_* methods.  Call occ_set_start before sampling with the handle again.
+ *
+ * occ_cond_tau    logit.py:206-209   tau = gamma_variate / (eta'Q eta / 2 + tau_rate), gamma_variate ~ standard
+ *                                    gamma(tau_shape) (numpy: rng.gamma(shape, 1 / rate) = standard_gamma(shape) / rate)
+ * occ_cond_eta    logit.py:211-217, 73-99   omega_b[n]; eps_site[n] = the first n standard normals; prior_term[n] = the
+ *                                    N(0, Q) vector E eps_2 of logit.py:77 BEFORE the sqrt(tau) factor (the engine draws
+ *                                    it in edge form, a test passes the reference's).  Uses the chain's beta, z, tau
+ *                                    and warm start xz.  Outputs (each may be NULL): the right-hand side y[n],
+ *                                    [x z][2n], eta[n], the MINRES iteration count.
+ * occ_cond_beta   logit.py:226-232, distributions.pyx:42-110   omega_b[n], eps[p] standard normals; the chain's eta, z
+ * occ_cond_alpha  logit.py:180-190, 219-224   omega_a[R] in flat visit-row order (rows of sites that do not exist --
+ *                                    no detection and z = 0 -- are ignored), eps[q]; the chain's z
+ * occ_cond_z      logit.py:234-252   u[n]: the uniform of site i (sites with a detection ignore theirs); the chain's
+ *                                    alpha, beta, eta.  z_out[n] in {0, 1}. */
+int occ_cond_tau(occ_sampler *s, int32_t chain, double gamma_variate, double *tau_out);
+int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const double *eps_site, const double *prior_term,
+                 double *rhs_out, double *xz_out, double *eta_out, int32_t *itn_out);
+int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const double *eps, double *beta_out);
+int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const double *eps, double *alpha_out);
+int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out);
+
 /* Variates of the engine's own generators, drawn ON THE DEVICE by the device functions the kernels use, for the
  * known-answer and distributional tests of the samplers that stand where the reference calls the third-party
  * polyagamma package (logit.py:191-193, 202-204) and numpy's Generator.gamma (logit.py:209): out[i] comes from the

@@ -132,6 +132,42 @@ class Engine:
         v = np.ascontiguousarray(np.atleast_1d(value), dtype=np.float64)
         self._check(self._lib.occ_set_state(self._h, chain, name.encode(), _ptr(v), v.size))
 
+    # ---- per-conditional updates with injected variates (C ABI occ_cond_*; parity tests against the reference's fixtures)
+    @staticmethod
+    def _vec(a, size):
+        v = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        if v.size != size:
+            raise ValueError('wrong length: %d, expected %d' % (v.size, size))
+        return v
+
+    def cond_tau(self, gamma_variate, chain=0):
+        out = C.c_double(0.0)
+        self._check(self._lib.occ_cond_tau(self._h, chain, float(gamma_variate), C.byref(out)))
+        return out.value
+
+    def cond_eta(self, omega_b, eps_site, prior_term, chain=0):
+        """-> (rhs, xz, eta, minres iterations) from the chain's beta, z, tau and warm start."""
+        n = self.prob.n
+        ob, e1, pt = self._vec(omega_b, n), self._vec(eps_site, n), self._vec(prior_term, n)
+        rhs, xz, eta, itn = np.empty(n), np.empty(2 * n), np.empty(n), C.c_int32(0)
+        self._check(self._lib.occ_cond_eta(self._h, chain, _ptr(ob), _ptr(e1), _ptr(pt), _ptr(rhs), _ptr(xz), _ptr(eta), C.byref(itn)))
+        return rhs, xz, eta, itn.value
+
+    def cond_beta(self, omega_b, eps, chain=0):
+        ob, ep, out = self._vec(omega_b, self.prob.n), self._vec(eps, self.prob.p), np.empty(self.prob.p)
+        self._check(self._lib.occ_cond_beta(self._h, chain, _ptr(ob), _ptr(ep), _ptr(out)))
+        return out
+
+    def cond_alpha(self, omega_a, eps, chain=0):
+        oa, ep, out = self._vec(omega_a, self.prob.R), self._vec(eps, self.prob.q), np.empty(self.prob.q)
+        self._check(self._lib.occ_cond_alpha(self._h, chain, _ptr(oa), _ptr(ep), _ptr(out)))
+        return out
+
+    def cond_z(self, u, chain=0):
+        uu, out = self._vec(u, self.prob.n), np.empty(self.prob.n)
+        self._check(self._lib.occ_cond_z(self._h, chain, _ptr(uu), _ptr(out)))
+        return out
+
     def stats(self):
         st = _lib.OccStats()
         self._check(self._lib.occ_get_stats(self._h, C.byref(st)))

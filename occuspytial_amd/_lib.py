@@ -58,6 +58,12 @@ SYMBOLS = (
     ('occ_set_state', C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64]),
     ('occ_get_stats', C.c_int, [C.c_void_p, C.POINTER(OccStats)]),
     ('occ_profile', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ('occ_cond_tau', C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
+    ('occ_cond_eta', C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int32)]),
+    ('occ_cond_beta', C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('occ_cond_alpha', C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('occ_cond_z', C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     ('occ_draw', C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
 )
 

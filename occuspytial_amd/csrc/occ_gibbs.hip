@@ -63,6 +63,8 @@ struct occ_sampler {
     double2 *snap_x = nullptr;
     double *snap_theta = nullptr;
     std::vector<ChainScalars> snap_sc;
+    Inject *inj_dev = nullptr;  // injected variates of the occ_cond_* entry points
+    double *inj_u = nullptr;    // [n] uniforms of occ_cond_z
     int snap_parity = 0;
     int64_t fused_fallbacks = 0;  // occ_run calls that were re-run on the launch-per-step path after a device-side time-out
     bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
@@ -237,11 +239,11 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     switch (kind) {
         case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(c.p), gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0); break;
-        case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, OCC_ARGS); break;
+        case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
-        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
+        case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
             hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
@@ -1735,6 +1737,198 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_prologue = true;
     return take_launch_rc(s);
+}
+
+// ---- per-conditional entry points with injected variates ---------------------------------
+// One conditional of ONE chain with the kernels of the launch-per-step path (grid over that chain only), the variates
+// coming from the caller.  cond_begin gives the chain a one-iteration window at its current iteration number and
+// returns that number; the control words are not advanced by any of the entry points.
+namespace {
+
+#define OCC_CARGS s->ctx_dev, s->ctx.sc, s->ctx.slots, chain, e
+
+int cond_begin(occ_sampler *s, int chain, const Inject &inj, uint32_t *it_out)
+{
+    Ctx &c = s->ctx;
+    if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
+    if (s->rsr.m > 0) return set_error(s, OCC_E_BADARG, "the per-conditional entry points cover the ICAR model");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc;
+    if (!s->inj_dev) {
+        if ((rc = dev_alloc(s, &s->inj_dev, 1))) return rc;
+        if ((rc = dev_alloc(s, &s->inj_u, (size_t)c.n))) return rc;
+        c.inj = s->inj_dev;
+        HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    }
+    std::vector<ChainScalars> h;
+    if ((rc = read_scalars(s, h))) return rc;  // (synchronises both streams)
+    ChainScalars &sc = h[chain];
+    Ctl &ctl = sc.ctl[s->parity];
+    ctl.koff = 0;
+    sc.it_base = ctl.it;
+    sc.it_stop = ctl.it + 1u;
+    sc.burnin = 0; sc.keep = 0; sc.err = 0;
+    *it_out = ctl.it;
+    if ((rc = write_scalars(s, h))) return rc;
+    Inject hinj = inj;
+    hinj.z_u = s->inj_u;
+    HIP_TRY(hipMemcpy(s->inj_dev, &hinj, sizeof(Inject), hipMemcpyHostToDevice));
+    s->need_prologue = true;  // whatever follows, omega_b of the coming iteration must be redrawn from the state
+    return OCC_OK;
+}
+
+int cond_end(occ_sampler *s, int chain, ChainScalars *out)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { s->err = std::string("kernel launch failed: ") + hipGetErrorString(le); return OCC_E_HIP; }
+    std::vector<ChainScalars> h;
+    int rc = read_scalars(s, h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(s, h))) return rc;
+    if (out) *out = h[chain];
+    return OCC_OK;
+}
+
+int copy_in(occ_sampler *s, double *dst, const double *src, size_t count)
+{
+    if (!src) return set_error(s, OCC_E_BADARG, "null input pointer");
+    HIP_TRY(hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDefault));
+    return OCC_OK;
+}
+int copy_out(occ_sampler *s, double *dst, const double *src, size_t count)
+{
+    if (dst) HIP_TRY(hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return OCC_OK;
+}
+
+}  // namespace
+
+int occ_cond_tau(occ_sampler *s, int32_t chain, double gamma_variate, double *tau_out)
+{
+    if (!s) return OCC_E_BADARG;
+    Inject inj{};
+    inj.gamma = gamma_variate;
+    inj.tau_from_gamma = 1;
+    uint32_t it;
+    int rc = cond_begin(s, chain, inj, &it);
+    if (rc) return rc;
+    const Ctx &c = s->ctx;
+    const int e = s->parity;
+    const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
+    hipLaunchKernelGGL(k_quad, gs, blk, 0, s->stream, OCC_CARGS);
+    hipLaunchKernelGGL(k_eta_init<1>, gs, blk, 0, s->stream, OCC_CARGS);  // tau = (1 / rate) gamma; its right-hand side is not used
+    ChainScalars sc;
+    if ((rc = cond_end(s, chain, &sc))) return rc;
+    if (tau_out) *tau_out = sc.tau;
+    return OCC_OK;
+}
+
+int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const double *eps_site, const double *prior_term, double *rhs_out,
+                 double *xz_out, double *eta_out, int32_t *itn_out)
+{
+    if (!s) return OCC_E_BADARG;
+    Inject inj{};
+    inj.tau_from_gamma = 0;  // tau is the chain's
+    uint32_t it;
+    int rc = cond_begin(s, chain, inj, &it);
+    if (rc) return rc;
+    const Ctx &c = s->ctx;
+    const size_t n = (size_t)c.n, co = (size_t)chain * n;
+    if ((rc = copy_in(s, c.omega_b[it & 1] + co, omega_b, n))) return rc;
+    if ((rc = copy_in(s, c.enorm[it & 1] + co, eps_site, n))) return rc;
+    if ((rc = copy_in(s, c.uprior[it & 1] + co, prior_term, n))) return rc;
+    const int e = s->parity;
+    const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
+    hipLaunchKernelGGL(k_eta_init<1>, gs, blk, 0, s->stream, OCC_CARGS);
+    int k_last = 0;
+    Slot slot;
+    for (int k = 1;; ++k) {  // one launch per MINRES step, the host watching this chain's `done` flag
+        hipLaunchKernelGGL(k_minres, gs, blk, 0, s->stream, s->kry, chain, e, k);
+        if (k < 4) continue;
+        HIP_TRY(hipMemcpyAsync(&slot, c.slots + (size_t)chain * NSLOT + (k & (NSLOT - 1)), sizeof(Slot), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (slot.done) { k_last = k; break; }
+        if ((long long)k > c.maxiter + 3) return set_error(s, OCC_E_MINRES, "MINRES solver did not converge!");
+    }
+    hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, s->stream, OCC_CARGS, k_last);
+    ChainScalars sc;
+    if ((rc = cond_end(s, chain, &sc))) return rc;
+    if ((rc = copy_out(s, rhs_out, c.rhs + co, n))) return rc;
+    if ((rc = copy_out(s, eta_out, c.eta + co, n))) return rc;
+    if (xz_out) {
+        std::vector<double2> x(n);
+        HIP_TRY(hipMemcpy(x.data(), c.Xv + co, sizeof(double2) * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) { xz_out[i] = x[i].x; xz_out[n + i] = x[i].y; }
+    }
+    if (itn_out) *itn_out = sc.minres_itn_last;
+    return OCC_OK;
+}
+
+int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const double *eps, double *beta_out)
+{
+    if (!s || !eps) return OCC_E_BADARG;
+    Inject inj{};
+    inj.do_beta = 1;
+    HIP_TRY(hipMemcpy(inj.beta_eps, eps, sizeof(double) * s->ctx.p, hipMemcpyDefault));
+    uint32_t it;
+    int rc = cond_begin(s, chain, inj, &it);
+    if (rc) return rc;
+    const Ctx &c = s->ctx;
+    const size_t n = (size_t)c.n, co = (size_t)chain * n;
+    if ((rc = copy_in(s, c.omega_b[it & 1] + co, omega_b, n))) return rc;
+    const int e = s->parity;
+    const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
+    hipLaunchKernelGGL(OCC_PICK_P(k_beta_sums, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    ChainScalars sc;
+    if ((rc = cond_end(s, chain, &sc))) return rc;
+    if (beta_out) std::copy(sc.beta, sc.beta + c.p, beta_out);
+    return OCC_OK;
+}
+
+int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const double *eps, double *alpha_out)
+{
+    if (!s || !eps) return OCC_E_BADARG;
+    Inject inj{};
+    HIP_TRY(hipMemcpy(inj.alpha_eps, eps, sizeof(double) * s->ctx.q, hipMemcpyDefault));
+    uint32_t it;
+    int rc = cond_begin(s, chain, inj, &it);
+    if (rc) return rc;
+    const Ctx &c = s->ctx;
+    if ((rc = copy_in(s, c.omega_a + (size_t)chain * c.R, omega_a, (size_t)c.R))) return rc;
+    const int e = s->parity;
+    const dim3 blk((unsigned)s->tpb), gr((unsigned)c.nb_r, 1u);
+#define OCC_OMEGA_A_INJ(q) ((q) == 1 ? k_omega_a<1, 1> : (q) == 2 ? k_omega_a<2, 1> : (q) == 3 ? k_omega_a<3, 1> : (q) == 4 ? k_omega_a<4, 1> : (q) == 5 ? k_omega_a<5, 1> : (q) == 6 ? k_omega_a<6, 1> : (q) == 7 ? k_omega_a<7, 1> : k_omega_a<8, 1>)
+    hipLaunchKernelGGL(OCC_OMEGA_A_INJ(c.q), gr, blk, 0, s->stream, OCC_CARGS);
+    hipLaunchKernelGGL(k_alpha_draw<1>, dim3(1), dim3(512), 0, s->stream, OCC_CARGS, 0);
+    ChainScalars sc;
+    if ((rc = cond_end(s, chain, &sc))) return rc;
+    if (alpha_out) std::copy(sc.alpha, sc.alpha + c.q, alpha_out);
+    return OCC_OK;
+}
+
+int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out)
+{
+    if (!s) return OCC_E_BADARG;
+    Inject inj{};
+    inj.do_z = 1;
+    uint32_t it;
+    int rc = cond_begin(s, chain, inj, &it);
+    if (rc) return rc;
+    const Ctx &c = s->ctx;
+    const size_t n = (size_t)c.n;
+    if ((rc = copy_in(s, s->inj_u, u, n))) return rc;
+    const int e = s->parity;
+    const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
+    hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    if ((rc = cond_end(s, chain, nullptr))) return rc;
+    if (z_out) {
+        std::vector<uint8_t> z(n);
+        HIP_TRY(hipMemcpy(z.data(), c.z + (size_t)chain * n, n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) z_out[i] = (double)z[i];
+    }
+    return OCC_OK;
 }
 
 // Device draws of the engine's own variate generators (see the header).

@@ -107,6 +107,20 @@ struct ChainScalars {
     unsigned long long krylov_total, krylov_sq_total, solves, carries;
 };
 
+// Variates handed in by the caller instead of the chain's Philox streams: the per-conditional entry points of the C ABI
+// (occ_cond_*, include/occ_gibbs.h) run the kernels below in their INJ instantiation, which take the standard gamma variate
+// of tau, the standard normals of the beta / alpha draws and the uniforms of the z update from here (and omega_a / omega_b
+// from the state buffers instead of drawing them).  Production launches never read it.
+struct Inject {
+    double gamma;             // standard gamma variate of shape tau_shape                          logit.py:209
+    double beta_eps[MAXC];    // standard normals of precision_mvnorm                               distributions.pyx:95-96
+    double alpha_eps[MAXC];
+    const double *z_u;        // [n] uniform of site i (sites with a detection ignore theirs)        logit.py:247-251
+    int tau_from_gamma;       // k_eta_init: 1 = tau = gamma / rate, 0 = keep the chain's tau
+    int do_beta, do_z;        // k_z_ob: draw beta / update z
+    int pad_;
+};
+
 // The problem/state descriptor lives in device memory and kernels receive a POINTER to it (plus the
 // two hot per-chain tables): a by-value 360-byte kernel argument costs every wave several serialized
 // kernarg-segment fetches at kernel entry -- measured 12-25 us per launch on MI355X for kernels whose
@@ -151,6 +165,7 @@ struct Ctx {
     // (only when the two streams own disjoint sets of CUs, so that a workgroup spinning on one of them can
     // never keep the producer it waits for off the device); null: not used.  See "Stream hand-overs" below.
     unsigned *sync;
+    const Inject *inj;  // injected variates of the occ_cond_* entry points (INJ kernels only); null otherwise
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -375,7 +390,7 @@ __device__ __forceinline__ double beta_rhs_term(double om, double eta, double z)
 // work is 2d doubles.  Returns false when a pivot is not positive.
 __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d): upper then rhs */,
                                             const double *prec0, const double *pbm, uint64_t key, uint32_t it,
-                                            uint32_t stream, double *U, double *work, double *out)
+                                            uint32_t stream, double *U, double *work, double *out, const double *eps_inj = nullptr)
 {
     double *r = work, *o = work + d;
     int t = 0;
@@ -399,7 +414,7 @@ __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d):
         o[i] = 0.0;
     }
     for (int k = 0; k < d; ++k) {
-        const double e = block_normal(key, (uint32_t)k, 0, it, stream);
+        const double e = eps_inj ? eps_inj[k] : block_normal(key, (uint32_t)k, 0, it, stream);
         for (int i = k; i < d; ++i) o[i] += U[k * d + i] * e;
     }
     for (int i = 0; i < d; ++i) o[i] += r[i];
@@ -421,7 +436,8 @@ __device__ inline bool precision_mvnorm_dev(int d, const double *acc /* nacc(d):
 // every lane (uniform inputs, uniform control flow), so no broadcast is needed afterwards.
 template <int D>
 __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)], const double *prec0, const double *pbm,
-                                                     uint64_t key, uint32_t it, uint32_t stream, double (&out)[D])
+                                                     uint64_t key, uint32_t it, uint32_t stream, double (&out)[D],
+                                                     const double *eps_inj = nullptr)
 {
     double U[D][D], r[D], o[D];
     int t = 0;
@@ -452,7 +468,7 @@ __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)
     for (int i = 0; i < D; ++i) o[i] = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const double e = block_normal(key, (uint32_t)k, 0, it, stream);
+        const double e = eps_inj ? eps_inj[k] : block_normal(key, (uint32_t)k, 0, it, stream);
 #pragma unroll
         for (int i = k; i < D; ++i) o[i] += U[k][i] * e;
     }
@@ -532,6 +548,17 @@ __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainSc
 // =================================================================================================
 #define OCC_KARGS const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int e
 
+// eta_i (Q eta)_i: site i's term of eta'Q eta (logit.py:208)
+__device__ __forceinline__ double quad_site(const Ctx &c, const double *eta, int i, double eta_i)
+{
+    const int lane = i & 63;
+    int base, width;
+    slice_of(c, i, base, width);
+    double qe = c.qdiag[i] * eta_i;
+    for (int k = 0; k < width; ++k) qe = fma(c.sell_val[base + k * 64 + lane], eta[c.sell_col[base + k * 64 + lane]], qe);
+    return eta_i * qe;
+}
+
 // omega_b ~ PG(1, x_i'beta + eta_i) of iteration `it` into omega_b[it & 1], and the partials of eta'Q eta
 // (logit.py:195-204, 208).  `blk` is the block index within the role's own grid.
 template <int P>
@@ -549,12 +576,7 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
         const double eta_i = eta[i];
         Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
         c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
-        const int lane = i & 63;
-        int base, width;
-        slice_of(c, i, base, width);
-        double qe = c.qdiag[i] * eta_i;
-        for (int k = 0; k < width; ++k) qe = fma(c.sell_val[base + k * 64 + lane], eta[c.sell_col[base + k * 64 + lane]], qe);
-        quad[0] = eta_i * qe;
+        quad[0] = quad_site(c, eta, i, eta_i);
     }
     if (per_wave) {  // several waves per block, partial sums still per 64-site slice (c.nb_n counts slices)
         const double t = wave_sum(quad[0]);
@@ -580,6 +602,19 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
 #pragma unroll
     for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
     omega_b_body<P>(c, sc, beta, chain, ctl.it, blk);
+}
+
+// The partial sums of eta'Q eta alone, from the chain's current eta (occ_cond_tau: no Polya-Gamma draw).
+__global__ void __launch_bounds__(256) k_quad(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+    const double *eta = c.eta + (size_t)chain * n;
+    double quad[1] = {0.0};
+    if (i < n) quad[0] = quad_site(c, eta, i, eta[i]);
+    block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
 }
 
 // Variates of the eta right-hand side that depend only on (key, iteration): the site normals eps_1
@@ -624,6 +659,7 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on
     noise_site(c, sc.key, chain, i, ctl.it + (uint32_t)ahead);
 }
 
+template <int INJ>
 __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
 {
     __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
@@ -639,8 +675,13 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
     reduce_partials<1>(c.part_quad + (size_t)chain * c.nb_n, c.nb_n, quad);
     // every lane draws the same tau from the same sub-stream (uniform control flow, no broadcast)
     const double rate = 0.5 * quad[0] + c.tau_rate;
-    Cursor g(sc.key, 0u, it, STREAM_TAU);
-    const double tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
+    double tau;
+    if (INJ) {  // the caller's gamma variate (rng.gamma(shape, 1 / rate) = standard_gamma(shape) * (1 / rate)), or the chain's tau as it is
+        tau = c.inj->tau_from_gamma ? (1.0 / rate) * c.inj->gamma : sc.tau;
+    } else {
+        Cursor g(sc.key, 0u, it, STREAM_TAU);
+        tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
+    }
     if (blk == 0 && threadIdx.x == 0) {
         sc.tau = tau;
         Slot s = {};
@@ -1121,6 +1162,28 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     OCC_STAMP(5)
 }
 
+// Site i's terms of X' Omega X (upper triangle, row by row) and X'(k - omega eta) (logit.py:229-231)
+template <int P>
+__device__ __forceinline__ void beta_site_terms(const Ctx &c, int chain, int i, uint32_t it, double eta, double (&acc)[nacc(P)])
+{
+    const int n = c.n;
+    const size_t ci = (size_t)chain * n + i;
+    const double om = c.omega_b[it & 1][ci];
+    const double tt = beta_rhs_term(om, eta, (double)c.z[ci]);
+    double x[P];
+#pragma unroll
+    for (int aa = 0; aa < P; ++aa) x[aa] = c.Xt[(size_t)aa * n + i];
+    int t = 0;
+#pragma unroll
+    for (int aa = 0; aa < P; ++aa) {
+        const double xo = x[aa] * om;
+#pragma unroll
+        for (int bb = aa; bb < P; ++bb) acc[t++] = xo * x[bb];
+    }
+#pragma unroll
+    for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
+}
+
 template <int P>
 __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_launch)
 {
@@ -1187,27 +1250,30 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
         const double2 xz = c.Xv[ci];
         const double eta = eta_project(xz, a);
         c.eta[ci] = eta;
-        const double om = c.omega_b[ctl.it & 1][ci];
-        const double tt = beta_rhs_term(om, eta, (double)c.z[ci]);
-        double x[P];
-#pragma unroll
-        for (int aa = 0; aa < P; ++aa) x[aa] = c.Xt[(size_t)aa * n + i];
-        int t = 0;
-#pragma unroll
-        for (int aa = 0; aa < P; ++aa) {
-            const double xo = x[aa] * om;
-#pragma unroll
-            for (int bb = aa; bb < P; ++bb) acc[t++] = xo * x[bb];
-        }
-#pragma unroll
-        for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
+        beta_site_terms<P>(c, chain, i, ctl.it, eta, acc);
     }
+    block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
+}
+
+// The partial sums of beta's system from the chain's current eta, omega_b and z (occ_cond_beta: no projection).
+template <int P>
+__global__ void __launch_bounds__(256) k_beta_sums(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    const Ctl ctl = scs[chain].ctl[e];
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+    double acc[nacc(P)];
+#pragma unroll
+    for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
+    if (i < n) beta_site_terms<P>(c, chain, i, ctl.it, c.eta[(size_t)chain * n + i], acc);
     block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
 }
 
 // One visit row of the omega_a update: omega_a ~ PG(1, w'alpha) when the site exists (z = 1 or a detection
 // was seen, base.py:116-119), and the row's terms of alpha's system W'Omega W, W'(y - 1/2) (logit.py:216-224).
-template <int Q>
+template <int Q, int INJ = 0>
 __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int r, double (&acc)[nacc(Q)])
 {
     const int R = c.R;
@@ -1224,9 +1290,14 @@ __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc
                 w[a] = c.Wt[(size_t)a * R + r];
                 wa = fma(w[a], sc.alpha[a], wa);
             }
-            Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
-            const double om = pg1_draw(cur, wa);
-            c.omega_a[(size_t)chain * R + r] = om;
+            double om;
+            if (INJ) {  // omega_a as the caller left it in the state buffer
+                om = c.omega_a[(size_t)chain * R + r];
+            } else {
+                Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
+                om = pg1_draw(cur, wa);
+                c.omega_a[(size_t)chain * R + r] = om;
+            }
             const double tt = (double)c.yrow[r] - 0.5;
             int t = 0;
 #pragma unroll
@@ -1241,7 +1312,7 @@ __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc
     }
 }
 
-template <int Q>
+template <int Q, int INJ = 0>
 __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 {
     const Ctx &c = *cp;
@@ -1251,12 +1322,13 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     double acc[nacc(Q)];
-    omega_a_row<Q>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
+    omega_a_row<Q, INJ>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
     block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
 }
 
 // alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one block per chain, one wave per
 // quantity of the system (512 threads: with one wave the reduction of 5 x 4 883 partial sums took 135 us at 500x500).
+template <int INJ>
 __global__ void __launch_bounds__(512) k_alpha_draw(OCC_KARGS, int sync_on)
 {
     __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
@@ -1269,7 +1341,8 @@ __global__ void __launch_bounds__(512) k_alpha_draw(OCC_KARGS, int sync_on)
         reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
         if (threadIdx.x == 0) {
             const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
-            const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha);
+            const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, sc.alpha,
+                                                 INJ ? c.inj->alpha_eps : nullptr);
             if (!ok) sc.err = -4;
         }
     }
@@ -1284,7 +1357,7 @@ __global__ void __launch_bounds__(512) k_alpha_draw(OCC_KARGS, int sync_on)
 // roles, so the two run concurrently without a second stream.
 // The z update of one site (logit.py:234-252) and the record of one iteration (base.py:238-239): shared by k_z_ob
 // and by the last phase of k_iter (occ_iter.hpp), contractions explicit so that both evaluate the same operations.
-template <int P>
+template <int P, int INJ = 0>
 __device__ __forceinline__ void z_update_site(const Ctx &c, uint64_t key, int chain, int i, uint32_t it, const double (&beta)[P],
                                               const double (&alpha)[MAXC], double eta_i)
 {
@@ -1311,7 +1384,7 @@ __device__ __forceinline__ void z_update_site(const Ctx &c, uint64_t key, int ch
         const double num = num1 * prod;
         pr = num / ((1.0 - num1) + num);
     }
-    const double u = block_uniform(key, (uint32_t)i, 0, it, STREAM_Z);
+    const double u = INJ ? c.inj->z_u[i] : block_uniform(key, (uint32_t)i, 0, it, STREAM_Z);
     c.z[(size_t)chain * n + i] = (u < pr) ? 1 : 0;
 }
 template <int P>
@@ -1419,6 +1492,41 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: s
     z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0);
 }
 
+
+// beta draw and / or z update of one chain with INJECTED variates (occ_cond_beta, occ_cond_z): the arithmetic is k_z_ob's,
+// through the same device functions (reduce_partials in the same order, precision_mvnorm_reg, z_update_site); nothing is
+// recorded and the iteration number does not advance.
+template <int P>
+__global__ void __launch_bounds__(256) k_cond_beta_z(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    ChainScalars &sc = scs[chain];
+    const Inject &inj = *c.inj;
+    const Ctl ctl = sc.ctl[e];
+    double beta[P];
+    if (inj.do_beta) {
+        double sums[nacc(P)];
+        reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);
+        const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
+        const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, beta, inj.beta_eps);
+        if (blk == 0 && threadIdx.x == 0) {
+            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+#pragma unroll
+            for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
+    }
+    if (!inj.do_z) return;
+    double alpha[MAXC];
+#pragma unroll
+    for (int a = 0; a < MAXC; ++a) alpha[a] = (a < c.q) ? sc.alpha[a] : 0.0;
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+    if (i < n) z_update_site<P, 1>(c, sc.key, chain, i, ctl.it, beta, alpha, c.eta[(size_t)chain * n + i]);
+}
 
 // Variates of the generators above, element i from the sub-stream (key, i, iteration, stream) exactly as the kernels of the
 // iteration draw them (occ_draw in the C ABI: known-answer and distributional tests on DEVICE draws).
