@@ -7,18 +7,22 @@ A "step" is ONE Gibbs iteration of every chain resident on a GPU (all seven cond
 the reference's LogitICARGibbs.step(), logit.py:254-266, for C chains batched in each kernel).
 Workload (BASELINE.json metric / SURVEY.md 8d): 100x100 queen lattice, 10 000 sites, 5 visits per
 site, p = q = 2, synthetic data (data seed 0, sampler seed 10), default hyper-parameters, 4 chains
-per GPU.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own
-4 chains -- chains are the natural shard, weak scaling -- after ONE RCCL broadcast of the fixed design
-arrays from rank 0; there is no per-iteration collective.  value = chain-iterations of all ranks /
-max-over-ranks wall time of exactly K timed steps.
+per GPU.  For N > 1 (launched by torch.distributed.run -- used as a process launcher only: this script does not import
+torch -- one rank per GPU) every rank runs its own 4 chains -- chains are the natural shard, weak scaling -- after ONE
+RCCL broadcast (ncclCommInitRank / ncclBroadcast through the engine's C ABI) of the laid-out problem arrays from rank
+0's device to the other devices; there is no per-iteration collective.  value = chain-iterations of all ranks /
+max-over-ranks wall time of exactly K timed steps.  The same line carries `split_4_chains`: SURVEY 8(e)'s split of
+the metric's 4 chains over the N GPUs (4 / 2 / 1 / <= 1 per GPU).  Without a launcher, `--gpus N` drives the N GPUs
+from this one process, a host thread each (EngineGroup).
 
 The JSON line also carries
   roofline     : the dominant kernel (k_iter: tau, right-hand side, the whole MINRES solve of eta, projection
                  and beta sums of one iteration, all chains): algorithmic bytes per launch / its mean launch
                  time, measured live right after the timed region with two HIP events around each of 200
                  k_iter launches on the engine's main stream while the chains keep running (occ_profile);
-  cpu_baseline : the CPU oracle (C restatement of the reference loop, oracle/) timed on one host core
-                 for a bounded number of iterations of the same workload (rank 0, N = 1 only).
+  cpu_baseline : the CPU oracle (C restatement of the reference loop, oracle/) in reference-faithful mode (dense
+                 eigenfactor prior draw, one thread per chain): 4 chains on 4 threads, and one chain per host core
+                 (rank 0, N = 1 only; bounded samples).
 """
 import argparse
 import json
@@ -63,8 +67,27 @@ def iter_bytes_per_launch(prob, n_chains, sell_entries, steps_per_chain):
     return int(n_chains * (steps_per_chain * per_step_chain + rhs + tail) + steps_per_chain * shared_per_step)
 
 
+def whole_iteration_bytes(prob, K, n_no_frac=0.4):
+    """SURVEY 8(d), algorithmic bytes of one Gibbs iteration of ONE chain at K MINRES iterations (R_e = R)."""
+    n, p, q, R = prob.n, prob.p, prob.q, prob.R
+    m = prob.Q.nnz
+    csr = 12 * m + 4 * (n + 1)
+    n_no = n_no_frac * n
+    R_no = n_no_frac * R
+    terms = [8 * n * (p + 2),                               # omega_b
+             8 * n + csr,                                   # tau
+             8 * n * (p + 3) + 4 * m + 4 * (n + 1),         # eta rhs (edge-form prior term)
+             K * (csr + 8 * n + 2 * 15 * 8 * n),            # eta Krylov
+             24 * n,                                        # projection
+             8 * n * (p + 3),                               # beta
+             8 * R * q + 8 * R + n,                         # omega_a
+             8 * R * q + 9 * R,                             # alpha
+             8 * n_no * (p + 1) + 8 * R_no * q + n_no]      # z
+    return int(sum(terms))
+
+
 def pmc_traffic(kernel, workload_key):
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_pmc_hbm_traffic.json: separate
+    """HBM bytes per launch from the committed PMC pass (profiles/r02_pmc_hbm_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied).
     Counters cannot be read from inside this process; the value is only reported for the workload the
     pass was taken on, else null."""
@@ -89,24 +112,115 @@ def sell_entry_count(prob):
     return int(d.max(axis=1).sum() * 64)
 
 
-def cpu_baseline(prob, target_seconds=12.0):
-    """Oracle (CPU port) iterations/sec on one host core, bounded sample of the same workload."""
+def _oracle_chain(prob, gen, E=None):
     from oracle.occ_oracle import OracleSampler
-    from occuspytial_amd._problem import chain_generators, default_start
-    gen = chain_generators(10, 1)[0]
+    from occuspytial_amd._problem import default_start
     st = default_start(gen, prob)
     orc = OracleSampler(prob, int(gen.bit_generator.random_raw()))
+    if E is not None:
+        orc.set_dense_eigen(E)
     orc.set_start(st['alpha'], st['beta'], st['tau'], st['eta'])
+    return orc
+
+
+def _timed_threads(chains, iters):
+    """`iters` iterations of every oracle chain, one OS thread per chain (ctypes releases the GIL): the reference's
+    one-process-per-chain fan-out (gibbs/parallel.py:38-41).  Returns wall seconds."""
+    import threading
+    ths = [threading.Thread(target=c.run, args=(iters, iters - 1)) for c in chains]
     t0 = time.perf_counter()
-    orc.run(5, 4)
-    per = (time.perf_counter() - t0) / 5
-    iters = int(max(20, min(5000, target_seconds / max(per, 1e-6))))
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(prob, mode='auto', target_seconds=10.0):
+    """the CPU restatement (oracle/, kind "port") in REFERENCE-FAITHFUL mode on the host cores of this box:
+    dense eigenfactor prior draw (logit.py:64-67, 77: E from numpy eigh, n x (n-1), one dense matvec per iteration),
+    joint MINRES rtol 1e-5, one OS thread per chain -- `value` = the metric's 4 chains on 4 threads; beside it the same
+    with one chain per host core (a throughput ceiling) and the build's own edge-form prior on one core.  Bounded
+    samples of the same workload (about `target_seconds` each); the eigh set-up is timed separately and is not part
+    of any rate (the reference pays it at construction: 50.8 s at 100x100 in the survey container)."""
+    from oracle.occ_oracle import dense_eigenfactor
+    from occuspytial_amd._problem import chain_generators
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    ncore = min(ncore, 16)   # a one-GPU box's CPU share (the host may show every core of a multi-GPU node)
+    dense = mode == 'dense_eigen' or (mode == 'auto' and prob.n <= 10000)
+    out = {'unit': 'iterations/s', 'kind': 'port'}
+
+    def rate(n_threads, E, seed):
+        chains = [_oracle_chain(prob, g, E) for g in chain_generators(seed, n_threads)]
+        per = _timed_threads(chains, 3) / 3          # every thread runs 3 iterations: seconds per iteration under this load
+        iters = int(max(5, min(5000, target_seconds / max(per, 1e-6))))
+        dt = _timed_threads(chains, iters)
+        return n_threads * iters / dt, iters, dt
+
+    v1, it1, dt1 = rate(1, None, 10)
+    out['edge_form_1_thread'] = {'value': v1, 'threads': 1, 'sample': f'1 chain x {it1} iterations, edge-form prior draw (the build\'s own algorithm), {dt1:.1f} s'}
+    if not dense:
+        out.update({'value': v1, 'cores': 1, 'threads': 1, 'mode': 'edge',
+                    'sample': out['edge_form_1_thread']['sample'] + ' -- no reference-faithful baseline exists at this size '
+                              '(the dense eigenfactor is O(n^2) memory: the reference cannot construct the problem)'})
+        return out
     t0 = time.perf_counter()
-    orc.run(iters, iters - 1)
-    dt = time.perf_counter() - t0
-    return {'value': iters / dt, 'unit': 'iterations/s', 'cores': 1, 'kind': 'port',
-            'sample': f'1 chain x {iters} iterations of the same 100x100 workload, oracle/occ_oracle.c '
-                      f'(sequential C restatement of the reference loop), {dt:.1f} s'}
+    E = dense_eigenfactor(prob.Q)
+    t_eigh = time.perf_counter() - t0
+    v4, it4, dt4 = rate(4, E, 10)
+    out.update({'value': v4, 'cores': 4, 'threads': 4, 'mode': 'dense_eigen',
+                'sample': f'4 chains x {it4} iterations on 4 threads (one per chain), oracle/occ_oracle.c with the reference\'s dense '
+                          f'eigenfactor prior draw ({E.nbytes / 1e6:.0f} MB matrix, one dense matvec per iteration), {dt4:.1f} s; '
+                          f'eigh set-up {t_eigh:.1f} s on the host, not counted'})
+    if ncore > 4:
+        va, ita, dta = rate(ncore, E, 11)
+        out['all_cores'] = {'value': va, 'threads': ncore, 'mode': 'dense_eigen',
+                            'sample': f'{ncore} chains x {ita} iterations, one thread per core of this GPU\'s CPU share (at most 16), {dta:.1f} s'}
+    out['eigh_setup_s'] = round(t_eigh, 1)
+    return out
+
+
+class _Solo:
+    """The communicator of a one-process run."""
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def allreduce_max(self, x):
+        return x
+
+    def bcast_obj(self, obj, root=0):
+        return obj
+
+    def allgather_obj(self, obj):
+        return [obj]
+
+    def close(self):
+        pass
+
+
+def timed_run(eng, comm, steps, warmup):
+    """W untimed steps (graph capture included), then exactly K timed steps bracketed by a barrier and a device
+    synchronisation on both sides; the elapsed time is the MAX over ranks.  `eng` may be None (a rank without chains
+    in the 4-chain split): it still takes part in the barriers."""
+    stats_warm = None
+    if eng is not None and warmup > 0:
+        eng.run(warmup, warmup - 1)
+    if eng is not None:
+        stats_warm = eng.stats()
+        eng.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    rec = eng.run(steps, steps - 1) if eng is not None else None
+    if eng is not None:
+        eng.synchronize()
+    comm.barrier()
+    elapsed = float(comm.allreduce_max(time.perf_counter() - t0))
+    if rec is not None:
+        a, b, t = rec
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(t > 0)
+    return elapsed, stats_warm, (eng.stats() if eng is not None else None)
 
 
 def main():
@@ -118,92 +232,127 @@ def main():
     ap.add_argument('--lattice', type=int, nargs=2, default=[100, 100])
     ap.add_argument('--visits', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-mode', choices=['auto', 'dense_eigen', 'edge'], default='auto')
+    ap.add_argument('--no-split', action='store_true', help='skip the second measurement of N > 1 (the metric\'s 4 chains split over the GPUs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    in_process = world == 1 and args.gpus > 1   # no launcher: ONE process drives the N GPUs, a host thread each
+    if world > 1:
         args.gpus = world
 
-    import torch
-    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._engine import Engine, EngineGroup
     from occuspytial_amd._problem import FlatProblem, chain_generators, default_start
     from occuspytial_amd.utils import make_lattice_problem
 
-    dist = None
-    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
-        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl" backend) for the set-up traffic
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # RCCL prints a version banner on C-level stdout at communicator creation: keep stdout for the
-        # one JSON line by pointing fd 1 at stderr until the first collective has run
+    # ---- process group: RCCL called directly (no PyTorch); launched by torch.distributed.run or any launcher that
+    # sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT.  RCCL prints a banner on C-level stdout at communicator
+    # creation: keep stdout for the one JSON line by pointing fd 1 at stderr meanwhile.
+    comm, comm_note = _Solo(), 'single process'
+    if world > 1:
+        from occuspytial_amd.distributed import init_comm
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-            dist.barrier()
-            torch.cuda.synchronize()
+            comm, comm_note = init_comm(device=local_rank)
+            comm.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    # ---- inputs: rank 0 generates, every other rank receives them over RCCL -----------------------
+    # ---- inputs: rank 0 generates them; the other ranks' DEVICES receive the laid-out arrays over RCCL ----------
     rows, cols = args.lattice
     prob = None
     if rank == 0:
         Q, W, X, y, *_ = make_lattice_problem(rows, cols, visits=args.visits, p=2, q=2, random_state=0)
         prob = FlatProblem(Q, W, X, y)
-    if dist is not None:
-        from occuspytial_amd.distributed import broadcast_problem
-        prob = broadcast_problem(prob, src=0, device=torch.device('cuda', local_rank))
+
+    def make_engine(chain_ids, gens, problem):
+        """Engine of this rank for the global chains `chain_ids` (None when it has none)."""
+        if world > 1:
+            from occuspytial_amd.distributed import distributed_engine
+            # (collective: every rank takes part in the broadcast even when it runs no chain of this split)
+            keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids] or [1]
+            eng, mine = distributed_engine(problem, comm, keys)
+            if not chain_ids:
+                eng.close()
+                return None, mine
+        elif in_process:
+            mine = problem
+            keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids]
+            eng = EngineGroup(problem, keys, list(range(args.gpus)))
+        else:
+            mine = problem
+            keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids]
+            eng = Engine(problem, keys, device=local_rank)
+        return eng, mine
+
+    def start_engine(eng, mine, chain_ids, gens, starts=None):
+        for i, c in enumerate(chain_ids):
+            st = starts[c] if starts else default_start(gens[c], mine)
+            eng.set_start(i, st['alpha'], st['beta'], st['tau'], st['eta'])
 
     C = args.chains_per_gpu
-    total_chains = C * world
+    n_dev = args.gpus
+    total_chains = C * n_dev
+    # chain c of the whole job owns the generator the reference would give its c-th copy (gibbs/base.py:293-306);
+    # start values come from it first, then the Philox key (its next raw word)
     gens = chain_generators(10, total_chains)
-    mine = list(range(rank * C, rank * C + C))
-    starts = [default_start(gens[c], prob) for c in mine]
-    keys = [int(gens[c].bit_generator.random_raw()) for c in mine]
-    eng = Engine(prob, keys, device=local_rank)
-    for i, st in enumerate(starts):
-        eng.set_start(i, st['alpha'], st['beta'], st['tau'], st['eta'])
+    if world > 1:
+        mine_ids = list(range(rank * C, rank * C + C))
+        meta_prob = comm.bcast_obj(None if rank else {k: getattr(prob, k) for k in ('n', 'p', 'q', 'S', 'R', 'tau_rate', 'tau_shape', 'a_mu', 'a_prec', 'b_mu', 'b_prec')}, 0)
+        from occuspytial_amd._engine import ProblemMeta
+        host_prob = prob if rank == 0 else ProblemMeta(**meta_prob)
+    else:
+        mine_ids = list(range(total_chains))
+        host_prob = prob
+    starts = {c: default_start(gens[c], host_prob) for c in mine_ids}
+    eng, mine = make_engine(mine_ids, gens, prob)
+    start_engine(eng, mine, mine_ids, gens, starts)
+    transport = eng.transport
+    elapsed, stats_warm, stats = timed_run(eng, comm, args.steps, args.warmup)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warm-up (includes the hipGraph capture), then K timed steps ------------------------------
-    if args.warmup > 0:
-        eng.run(args.warmup, args.warmup - 1)
-    stats_warm = eng.stats()
-    barrier()
-    t0 = time.perf_counter()
-    a, b, t = eng.run(args.steps, args.steps - 1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(t > 0)
-    stats = eng.stats()
+    # ---- N > 1: SURVEY 8(e)'s split of the metric's 4 chains (4 / 2 / 1 / <= 1 per GPU), same steps ---------------
+    split = None
+    if n_dev > 1 and not args.no_split:
+        gens4 = chain_generators(10, 4)
+        if world > 1:
+            ids4 = [c for c in range(4) if c % world == rank]
+        else:
+            ids4 = list(range(4))
+        st4 = {c: default_start(gens4[c], host_prob) for c in ids4}
+        if in_process:
+            keys4 = [int(gens4[c].bit_generator.random_raw()) for c in ids4]
+            eng4, mine4 = EngineGroup(prob, keys4, list(range(min(n_dev, 4)))), prob
+        else:
+            eng4, mine4 = make_engine(ids4, gens4, prob)
+        if eng4 is not None:
+            start_engine(eng4, mine4, ids4, gens4, st4)
+        el4, _, _ = timed_run(eng4, comm, args.steps, args.warmup)
+        if eng4 is not None:
+            eng4.close()
+        per = [sum(1 for c in range(4) if c % n_dev == g) for g in range(n_dev)]
+        split = {'value': 4 * args.steps / el4, 'unit': 'iterations/s', 'scaling': 'strong', 'total_chains': 4,
+                 'chains_per_gpu': per, 'ms_per_step': 1e3 * el4 / args.steps,
+                 'note': 'the metric\'s 4 chains, chain c on GPU c % N; one chain alone still pays the whole latency-bound '
+                         'iteration (about 85 us at 100x100), so this split gains little over 1 GPU -- the weak line above '
+                         '(4 chains on every GPU) is what more GPUs buy'}
 
     if rank == 0:
         # ---- roofline of the dominant kernel, live, HIP events on the engine's stream --------------
-        prof = eng.profile(reps=200)
-        st1 = eng.stats()
+        eng0 = eng.engines[0] if in_process else eng
+        if in_process:
+            stats, stats_warm = stats['per_device'][0], stats_warm['per_device'][0]
+        prof = eng0.profile(reps=200)
         sell = sell_entry_count(prob)
         fused = bool(stats['persistent_solve']) and prof['iter']['launches'] > 0
         if fused:
-            # the timed region itself: every k_iter launch is clocked from inside (first workgroup in to last chain
-            # out, constant-rate device wall clock), and its MINRES iterations are counted on the device
+            # the timed region itself: every k_iter launch is clocked from inside (first workgroup in to last chain out,
+            # constant-rate device wall clock), and its MINRES iterations are counted on the device
             d_solves = max(1, stats['solves'] - stats_warm['solves'])
             steps = (stats['krylov_total'] - stats_warm['krylov_total']) / d_solves + 3.0
             kname = 'k_iter'
@@ -228,11 +377,14 @@ def main():
                       'k_eta_init subtracted; = kernel duration + one dependent-launch boundary')
         achieved = bytes_launch / (ka['avg_us'] * 1e-6) / 1e9 if ka['avg_us'] > 0 else 0.0
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
+        # SURVEY 8(d)'s whole-iteration accounting beside the dominant kernel's: B_iter(measured K, R_e = R, n_no = 0.4 n)
+        kmean = stats['krylov_mean']
+        whole = whole_iteration_bytes(prob, kmean) * C
         out = {
             'metric': 'Gibbs iterations/sec on 100x100 ICAR lattice, 4 chains; 1/2/4/8 GPUs',
             'value': total_chains * args.steps / elapsed,
             'unit': 'iterations/s',
-            'n_gpus': world,
+            'n_gpus': n_dev,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
@@ -246,10 +398,13 @@ def main():
                             f'p=q=2, {C} chains per GPU batched in every kernel (BASELINE configs[1] data, '
                             'the metric\'s 4 chains)',
                 'chains_per_gpu': C, 'total_chains': total_chains, 'sites': prob.n, 'visit_rows': prob.R,
-                'parallelism': f'chains sharded {C}/GPU, no data-path collective',
+                'parallelism': (f'chains sharded {C}/GPU, no data-path collective; '
+                                + ('one process, one host thread per GPU' if in_process else 'one process per GPU' if world > 1 else 'one GPU')),
+                'communicator': comm_note, 'problem_transport': transport,
                 'krylov_iterations_mean': round(stats['krylov_mean'], 2),
                 'krylov_cap': stats['krylov_cap'], 'stalls': stats['stalls'],
                 'fused_iteration_kernel': bool(stats['persistent_solve']), 'main_stream_cus': stats['main_stream_cus'],
+                'fused_fallbacks': stats['fused_fallbacks'],
                 'threads_per_block': stats['threads_per_block'],
                 'device_ms_last_run': round(stats['last_run_ms'], 3),
             },
@@ -258,7 +413,7 @@ def main():
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else None,
-                'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)',
+                'traffic_source': 'profiles/r02_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)',
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
                 'timing': timing,
@@ -266,15 +421,21 @@ def main():
                 'algorithmic_bytes_per_minres_step': minres_bytes_per_launch(prob, C, sell),
                 'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['iter' if fused else 'minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},
+                'whole_iteration': {
+                    'note': 'SURVEY 8(d) accounting of ONE WHOLE Gibbs iteration (all seven conditionals, 15 vector passes per '
+                            'MINRES iteration at the measured K) x chains per GPU / measured time per iteration on one GPU',
+                    'bytes_per_iteration': whole, 'krylov_iterations_mean': round(kmean, 2),
+                    'achieved': round(whole / (elapsed / args.steps) / 1e9, 1), 'unit': 'GB/s',
+                    'frac': round(whole / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(prob)
+        if split is not None:
+            out['split_4_chains'] = split
+        if n_dev == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(prob, args.cpu_baseline_mode)
         print(json.dumps(out), flush=True)
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -15,7 +15,8 @@
  *    frees or keeps caller memory; outputs are host buffers owned by the caller;
  *  - all real data is IEEE float64, C-contiguous; index arrays are int32;
  *  - a handle is driven by one host thread at a time; different handles (one per GPU) are
- *    independent, and ctypes releases the GIL so host threads can drive several GPUs;
+ *    independent, and ctypes releases the GIL so host threads can drive several GPUs (occ_create_group;
+ *    occuspytial_amd.gibbs.LogitICARGibbs(..., devices=[...]) does exactly that);
  *  - there is NO CPU fallback: creation fails with OCC_E_HIP when no gfx950 device is usable.
  */
 #ifndef OCC_GIBBS_H
@@ -146,6 +147,37 @@ int occ_get_stats(occ_sampler *s, occ_stats *out);
 #define OCC_N_KERNEL_KINDS 9
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS],
                 double total_us[OCC_N_KERNEL_KINDS]);
+
+/* ---- chains sharded over GPUs (reference gibbs/parallel.py:4-42 runs one process per chain) -----------
+ * Chains are independent: the only communication is ONE broadcast of the fixed problem arrays at set-up, device to
+ * device over RCCL (xGMI), called directly -- librccl is opened with dlopen when one of these entry points is first
+ * used -- and never a host round trip on the receiving side.  There is no per-iteration collective.
+ *
+ * In-process (what LogitICARGibbs(..., devices=[...]).sample(chains=N) does; chain c lives on devices[c % G]):
+ *   occ_create_group lays the problem out once, uploads it to devices[0], creates one sampler per device and broadcasts
+ *   the fixed arrays from devices[0] (ncclCommInitAll + grouped ncclBroadcast; hipMemcpyPeer if librccl is unusable or
+ *   OCC_GROUP_TRANSPORT=peer).  keys: the chains' keys, device after device.  Each handle is then driven by its own
+ *   host thread (the C ABI holds no global state; ctypes releases the GIL).
+ * One process per GPU (bench.py --gpus N under torch.distributed.run, or any launcher that sets RANK / WORLD_SIZE):
+ *   occ_comm_unique_id on rank 0 -> the 128 bytes reach the other ranks by any side channel -> occ_comm_create on every
+ *   rank (ncclCommInitRank) -> occ_create_distributed: the root lays the problem out and uploads it, the other ranks
+ *   (problem = NULL) size their arrays from a small header and receive them by ncclBroadcast.  occ_comm_barrier /
+ *   occ_comm_allreduce_max / occ_comm_broadcast_host are the host-side collectives a benchmark needs (staged through
+ *   a device buffer).  occ_group_transport says how a handle got its arrays. */
+typedef struct occ_comm occ_comm;
+int occ_create_group(const occ_problem *problem, int32_t n_devices, const int32_t *devices, const int32_t *chains_per_device,
+                     const uint64_t *keys, occ_sampler **out /* n_devices handles */);
+int occ_comm_unique_id(uint8_t id[128]);
+int occ_comm_create(int32_t world, int32_t rank, const uint8_t id[128], int32_t device, occ_comm **out);
+int occ_comm_destroy(occ_comm *comm);
+int occ_comm_barrier(occ_comm *comm);
+int occ_comm_allreduce_max(occ_comm *comm, double *inout, int32_t n);
+int occ_comm_broadcast_host(occ_comm *comm, void *buf, int64_t bytes, int32_t root);
+const char *occ_comm_last_error(const occ_comm *comm); /* NULL: error of the last failed occ_comm_create / _unique_id */
+int occ_create_distributed(const occ_problem *problem /* root only */, occ_comm *comm, int32_t root, int32_t n_chains,
+                           const uint64_t *keys, occ_sampler **out);
+const char *occ_group_transport(const occ_sampler *s);
+int occ_synchronize(occ_sampler *s); /* hipDeviceSynchronize on the handle's device */
 
 /* ---- per-conditional entry points with INJECTED variates ---------------------------------------------------
  * One conditional update of ONE chain of the ICAR model, run on the device by the kernels of the launch-per-step path

@@ -10,6 +10,52 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data)
 
 
+def _keys_array(keys):
+    return (C.c_uint64 * len(keys))(*[int(v) & (2 ** 64 - 1) for v in keys])
+
+
+def problem_struct(prob):
+    """``occ_problem`` of a :class:`FlatProblem` plus the arrays that must outlive the call."""
+    Q = prob.Q
+    k = dict(
+        indptr=np.ascontiguousarray(Q.indptr, dtype=np.int32),
+        indices=np.ascontiguousarray(Q.indices, dtype=np.int32),
+        data=np.ascontiguousarray(Q.data, dtype=np.float64),
+        site_id=np.ascontiguousarray(prob.site_id, dtype=np.int32),
+        site_ptr=np.ascontiguousarray(prob.site_ptr, dtype=np.int32),
+    )
+    pb = _lib.OccProblem(
+        n=prob.n, n_surveyed=prob.S, n_rows=prob.R, p=prob.p, q=prob.q,
+        q_indptr=_ptr(k['indptr']), q_indices=_ptr(k['indices']), q_data=_ptr(k['data']),
+        X=_ptr(prob.X), site_id=_ptr(k['site_id']), site_ptr=_ptr(k['site_ptr']),
+        W=_ptr(prob.W), y=_ptr(prob.y), a_mu=_ptr(prob.a_mu), a_prec=_ptr(prob.a_prec),
+        b_mu=_ptr(prob.b_mu), b_prec=_ptr(prob.b_prec), tau_rate=prob.tau_rate, tau_shape=prob.tau_shape)
+    rsr = getattr(prob, 'rsr', None)
+    if rsr is not None:   # LogitRSRGibbs: eta = K theta
+        pb.rsr_dim = int(rsr['dim'])
+        pb.rsr_K, pb.rsr_Q, pb.rsr_E = _ptr(rsr['K']), _ptr(rsr['Q']), _ptr(rsr['E'])
+    return pb, k
+
+
+class ProblemMeta:
+    """Sizes and hyper-parameters of a problem -- all a rank of a distributed group needs on the HOST when the design
+    arrays themselves arrive on its device by broadcast (start values, output shapes)."""
+
+    FIELDS = ('n', 'p', 'q', 'S', 'R', 'tau_rate', 'tau_shape', 'a_mu', 'a_prec', 'b_mu', 'b_prec')
+    rsr = None
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    @classmethod
+    def of(cls, prob):
+        return cls(**{f: getattr(prob, f) for f in cls.FIELDS})
+
+    def to_dict(self):
+        return {f: getattr(self, f) for f in self.FIELDS}
+
+
 class Engine:
     """Device-resident sampler state for ``n_chains`` chains of one :class:`FlatProblem`.
 
@@ -18,35 +64,67 @@ class Engine:
 
     def __init__(self, prob, keys, device=0):
         lib = _lib.load()
-        self.prob = prob
-        self.n_chains = len(keys)
-        Q = prob.Q
-        self._keep = dict(
-            indptr=np.ascontiguousarray(Q.indptr, dtype=np.int32),
-            indices=np.ascontiguousarray(Q.indices, dtype=np.int32),
-            data=np.ascontiguousarray(Q.data, dtype=np.float64),
-            site_id=np.ascontiguousarray(prob.site_id, dtype=np.int32),
-            site_ptr=np.ascontiguousarray(prob.site_ptr, dtype=np.int32),
-        )
-        k = self._keep
-        pb = _lib.OccProblem(
-            n=prob.n, n_surveyed=prob.S, n_rows=prob.R, p=prob.p, q=prob.q,
-            q_indptr=_ptr(k['indptr']), q_indices=_ptr(k['indices']), q_data=_ptr(k['data']),
-            X=_ptr(prob.X), site_id=_ptr(k['site_id']), site_ptr=_ptr(k['site_ptr']),
-            W=_ptr(prob.W), y=_ptr(prob.y), a_mu=_ptr(prob.a_mu), a_prec=_ptr(prob.a_prec),
-            b_mu=_ptr(prob.b_mu), b_prec=_ptr(prob.b_prec), tau_rate=prob.tau_rate, tau_shape=prob.tau_shape)
-        self.rsr = getattr(prob, 'rsr', None)
-        if self.rsr is not None:   # LogitRSRGibbs: eta = K theta
-            pb.rsr_dim = int(self.rsr['dim'])
-            pb.rsr_K, pb.rsr_Q, pb.rsr_E = _ptr(self.rsr['K']), _ptr(self.rsr['Q']), _ptr(self.rsr['E'])
-        karr = (C.c_uint64 * self.n_chains)(*[int(v) & (2 ** 64 - 1) for v in keys])
+        pb, keep = problem_struct(prob)
+        karr = _keys_array(keys)
         h = C.c_void_p()
-        code = lib.occ_create(C.byref(pb), self.n_chains, karr, int(device), C.byref(h))
+        code = lib.occ_create(C.byref(pb), len(keys), karr, int(device), C.byref(h))
         _lib.raise_for(code, None)
-        self._h = h
+        self._adopt(lib, h, prob, keys, device)
+        del keep
+
+    def _adopt(self, lib, handle, prob, keys, device):
+        self._h = handle
         self._lib = lib
+        self.prob = prob
+        self.rsr = getattr(prob, 'rsr', None)
+        self.n_chains = len(keys)
         self.device = int(device)
         self.keys = [int(v) & (2 ** 64 - 1) for v in keys]
+        return self
+
+    @classmethod
+    def group(cls, prob, keys_per_device, devices):
+        """One engine per entry of ``devices`` (``occ_create_group``): the problem is laid out once, uploaded to
+        ``devices[0]`` and broadcast to the others device-to-device (RCCL).  ``keys_per_device[g]`` are the Philox keys
+        of the chains that live on ``devices[g]``.  Each engine is then driven by its own host thread."""
+        lib = _lib.load()
+        pb, keep = problem_struct(prob)
+        G = len(devices)
+        if G < 1 or len(keys_per_device) != G or any(len(k) < 1 for k in keys_per_device):
+            raise ValueError('every device of a group needs at least one chain')
+        dev = (C.c_int32 * G)(*[int(d) for d in devices])
+        cnt = (C.c_int32 * G)(*[len(k) for k in keys_per_device])
+        karr = _keys_array([k for ks in keys_per_device for k in ks])
+        hs = (C.c_void_p * G)()
+        code = lib.occ_create_group(C.byref(pb), G, dev, cnt, karr, hs)
+        _lib.raise_for(code, None)
+        del keep
+        return [cls.__new__(cls)._adopt(lib, C.c_void_p(hs[g]), prob, keys_per_device[g], devices[g]) for g in range(G)]
+
+    @classmethod
+    def distributed(cls, prob, comm, keys, root=0):
+        """This process's engine of a one-process-per-GPU group (``occ_create_distributed``): ``prob`` is the full
+        :class:`FlatProblem` on rank ``root`` and a :class:`ProblemMeta` (sizes and hyper-parameters only) elsewhere;
+        the design arrays reach the other ranks' devices by RCCL broadcast, never their hosts.  ``comm``: an
+        ``occuspytial_amd.distributed.RcclComm``."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        if comm.rank == root:
+            pb, keep = problem_struct(prob)
+            code = lib.occ_create_distributed(C.byref(pb), comm.handle, root, len(keys), _keys_array(keys), C.byref(h))
+            del keep
+        else:
+            code = lib.occ_create_distributed(None, comm.handle, root, len(keys), _keys_array(keys), C.byref(h))
+        _lib.raise_for(code, None)
+        return cls.__new__(cls)._adopt(lib, h, prob, keys, comm.device)
+
+    @property
+    def transport(self):
+        """How this engine's fixed arrays reached its device (``occ_group_transport``)."""
+        return self._lib.occ_group_transport(self._h).decode()
+
+    def synchronize(self):
+        self._check(self._lib.occ_synchronize(self._h))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -200,3 +278,107 @@ def device_draw(kind, param=None, n=None, key=1, it=0, stream=1, device=0):
                         _ptr(par) if par is not None else None, _ptr(out))
     _lib.raise_for(code, None)
     return out
+
+
+class EngineGroup:
+    """Several :class:`Engine` s -- one per GPU of this process -- behind the interface of one: chain ``c`` lives on
+    ``devices[c % G]`` (the reference's ``gibbs/parallel.py:20-41`` gives every chain a process of its
+    own).  The problem is uploaded once and broadcast device to device (``Engine.group``); ``run`` drives every device
+    from its own host thread (the C ABI holds no global state and ctypes releases the GIL)."""
+
+    def __init__(self, prob, keys, devices, engine_factory=None):
+        devices = [int(d) for d in devices]
+        G = min(len(devices), len(keys))
+        self.devices = devices[:G]
+        self.prob = prob
+        self.rsr = getattr(prob, 'rsr', None)
+        self.n_chains = len(keys)
+        self.where = [(c % G, c // G) for c in range(self.n_chains)]        # chain -> (engine, local index)
+        per_dev = [[keys[c] for c in range(self.n_chains) if c % G == g] for g in range(G)]
+        if engine_factory is None:
+            self.engines = Engine.group(prob, per_dev, self.devices)
+        else:   # tests: any object with the Engine interface
+            self.engines = [engine_factory(prob, per_dev[g], self.devices[g]) for g in range(G)]
+        self.keys = [int(k) & (2 ** 64 - 1) for k in keys]
+        self.device = self.devices[0]
+
+    @property
+    def transport(self):
+        return getattr(self.engines[0], 'transport', 'n/a')
+
+    def _each(self, fn):
+        """``fn(engine)`` on every engine, one host thread per engine; results in engine order."""
+        if len(self.engines) == 1:
+            return [fn(self.engines[0])]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(self.engines)) as pool:
+            return list(pool.map(fn, self.engines))
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def set_keys(self, keys):
+        if len(keys) != self.n_chains:
+            raise ValueError('one key per chain is required')
+        G = len(self.engines)
+        for g, e in enumerate(self.engines):
+            e.set_keys([keys[c] for c in range(self.n_chains) if c % G == g])
+        self.keys = [int(k) & (2 ** 64 - 1) for k in keys]
+
+    def set_start(self, chain, alpha, beta, tau, eta):
+        g, i = self.where[chain]
+        self.engines[g].set_start(i, alpha, beta, tau, eta)
+
+    def get(self, name, chain=0):
+        g, i = self.where[chain]
+        return self.engines[g].get(name, i)
+
+    def set(self, name, value, chain=0):
+        g, i = self.where[chain]
+        self.engines[g].set(name, value, i)
+
+    def step(self):
+        self._each(lambda e: e.step())
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def run(self, n_iter, burnin=0):
+        parts = self._each(lambda e: e.run(n_iter, burnin))
+        keep = max(n_iter - burnin, 0)
+        a = np.zeros((self.n_chains, keep, self.prob.q))
+        b = np.zeros((self.n_chains, keep, self.prob.p))
+        t = np.zeros((self.n_chains, keep))
+        for c, (g, i) in enumerate(self.where):
+            a[c], b[c], t[c] = parts[g][0][i], parts[g][1][i], parts[g][2][i]
+        return a, b, t
+
+    def stats(self):
+        per = [e.stats() for e in self.engines]
+        out = dict(per[0])
+        out['n_chains'] = self.n_chains
+        out['devices'] = list(self.devices)
+        out['per_device'] = per
+        return out
+
+    def checkpoint(self):
+        parts = [e.checkpoint() for e in self.engines]
+        out = {'n_chains': np.int64(self.n_chains), 'shape': parts[0]['shape']}
+        for name in parts[0]:
+            if name in ('n_chains', 'shape'):
+                continue
+            out[name] = np.stack([np.asarray(parts[g][name])[i] for g, i in self.where])
+        return out
+
+    def restore(self, ckpt):
+        if int(ckpt['n_chains']) != self.n_chains:
+            raise ValueError('checkpoint holds %d chains, this engine %d' % (int(ckpt['n_chains']), self.n_chains))
+        G = len(self.engines)
+        for g, e in enumerate(self.engines):
+            idx = [c for c in range(self.n_chains) if c % G == g]
+            part = {k: (np.asarray(v)[idx] if k not in ('n_chains', 'shape') else v) for k, v in ckpt.items()}
+            part['n_chains'] = np.int64(len(idx))
+            e.restore(part)
+        self.keys = [int(k) for k in np.asarray(ckpt['keys'])]

@@ -58,6 +58,19 @@ SYMBOLS = (
     ('occ_set_state', C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64]),
     ('occ_get_stats', C.c_int, [C.c_void_p, C.POINTER(OccStats)]),
     ('occ_profile', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ('occ_create_group', C.c_int, [C.POINTER(OccProblem), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]),
+    ('occ_comm_unique_id', C.c_int, [C.c_void_p]),
+    ('occ_comm_create', C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('occ_comm_destroy', C.c_int, [C.c_void_p]),
+    ('occ_comm_barrier', C.c_int, [C.c_void_p]),
+    ('occ_comm_allreduce_max', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ('occ_comm_broadcast_host', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    ('occ_comm_last_error', C.c_char_p, [C.c_void_p]),
+    ('occ_create_distributed', C.c_int, [C.POINTER(OccProblem), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_void_p)]),
+    ('occ_group_transport', C.c_char_p, [C.c_void_p]),
+    ('occ_synchronize', C.c_int, [C.c_void_p]),
     ('occ_cond_tau', C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
     ('occ_cond_eta', C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_int32)]),

@@ -1,0 +1,72 @@
+// occ_comm.hpp -- RCCL, called directly (no PyTorch): the one-shot broadcast of the fixed problem arrays to the other
+// GPUs of a group (chains are independent, so set-up is the only communication) and the few host-side
+// collectives a multi-process launch needs (barrier, max over ranks, small metadata).  librccl is opened at run time
+// (dlopen), so the engine itself does not depend on it: a single-GPU user never loads it.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <string>
+
+namespace occ {
+
+struct RcclApi {
+    void *lib = nullptr;
+    std::string err;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok() const { return lib != nullptr; }
+};
+
+inline RcclApi &rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        const char *names[] = {std::getenv("OCC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            a.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) {
+            a.err = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "not found");
+            return a;
+        }
+#define OCC_RCCL_SYM(field, name)                                                           \
+        a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, #name));                 \
+        if (!a.field) { a.err = "librccl lacks " #name; dlclose(a.lib); a.lib = nullptr; return a; }
+        OCC_RCCL_SYM(GetUniqueId, ncclGetUniqueId)
+        OCC_RCCL_SYM(CommInitRank, ncclCommInitRank)
+        OCC_RCCL_SYM(CommInitAll, ncclCommInitAll)
+        OCC_RCCL_SYM(CommDestroy, ncclCommDestroy)
+        OCC_RCCL_SYM(Broadcast, ncclBroadcast)
+        OCC_RCCL_SYM(AllReduce, ncclAllReduce)
+        OCC_RCCL_SYM(GroupStart, ncclGroupStart)
+        OCC_RCCL_SYM(GroupEnd, ncclGroupEnd)
+        OCC_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef OCC_RCCL_SYM
+        return a;
+    }();
+    return api;
+}
+
+}  // namespace occ
+
+// One rank of a multi-process group (one process per GPU).
+struct occ_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    void *stage = nullptr;  // device staging buffer for host-side collectives
+    size_t stage_bytes = 0;
+    std::string err;
+};

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "occ_comm.hpp"
 #include "occ_iter.hpp"
 #include "occ_rsr.hpp"
 
@@ -63,6 +64,11 @@ struct occ_sampler {
     double2 *snap_x = nullptr;
     double *snap_theta = nullptr;
     std::vector<ChainScalars> snap_sc;
+    // fixed problem arrays on the device, in upload order: what a group broadcasts from its root (occ_create_group /
+    // occ_create_distributed); defer_fixed: allocate only, the bytes arrive by broadcast
+    std::vector<std::pair<void *, size_t>> fixed_list;
+    bool defer_fixed = false;
+    std::string group_transport = "none";
     Inject *inj_dev = nullptr;  // injected variates of the occ_cond_* entry points
     double *inj_u = nullptr;    // [n] uniforms of occ_cond_z
     int snap_parity = 0;
@@ -146,7 +152,8 @@ int upload(occ_sampler *s, const T **out, const std::vector<T> &h)
     T *d = nullptr;
     int rc = dev_alloc(s, &d, h.size(), false);
     if (rc) return rc;
-    if (!h.empty()) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!h.empty() && !s->defer_fixed) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!h.empty()) s->fixed_list.emplace_back((void *)d, h.size() * sizeof(T));
     *out = d;
     return OCC_OK;
 }
@@ -682,9 +689,33 @@ int occ_destroy(occ_sampler *s)
     return OCC_OK;
 }
 
-static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, const uint64_t *keys)
+// z = 1 everywhere except surveyed sites without a detection (base.py:113-119), every chain
+static int init_occupancy(occ_sampler *s)
 {
-    if (!pb || !keys || n_chains < 1) return set_error(s, OCC_E_BADARG, "bad problem / keys / n_chains");
+    const Ctx &c = s->ctx;
+    std::vector<uint8_t> z0((size_t)c.C * c.n, 1);
+    for (int ch = 0; ch < c.C; ++ch)
+        for (int t = 0; t < c.S; ++t) z0[(size_t)ch * c.n + s->site_id[t]] = s->obs_site[t];
+    HIP_TRY(hipMemcpy(c.z, z0.data(), z0.size(), hipMemcpyHostToDevice));
+    return OCC_OK;
+}
+
+// Everything the host derives from the caller's problem, once: checked inputs in the layouts the kernels read (SELL-64 /
+// diagonal form of Q, structure-of-arrays designs, index sets of base.py:112-152, prior products).  A group of
+// samplers -- one per device, or one per process -- is built from ONE layout: the root uploads it, the others receive
+// the device arrays by RCCL broadcast (occ_create_group, occ_create_distributed).
+struct HostLayout {
+    int n = 0, S = 0, R = 0, p = 0, q = 0, ell_w = 0, rsr_dim = 0;
+    double tau_rate = 0.0, tau_shape = 0.0;
+    std::vector<int> sell_ptr, sell_col, dia_off, row_site, site_sidx;
+    std::vector<double> sell_val, qdiag, dia_val, Xt, Wt, hyp, Kh, Qh, Eh;
+    std::vector<uint8_t> dia_mask, yrow, obs_site;
+    std::vector<int32_t> site_id, site_ptr;
+};
+
+static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
+{
+    if (!pb) return set_error(s, OCC_E_BADARG, "null problem");
     if (pb->n < 1 || pb->n > 0x7fffffff || pb->n_rows > 0x7fffffff || pb->n_surveyed > pb->n)
         return set_error(s, OCC_E_BADARG, "problem sizes out of range");
     if (pb->p < 1 || pb->p > OCC_MAX_COVARIATES || pb->q < 1 || pb->q > OCC_MAX_COVARIATES)
@@ -692,24 +723,12 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_MAX_DIM || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
         return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 128 columns (rsr_K, rsr_Q, rsr_E)");
     if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipEventCreate(&s->ev0));
-    HIP_TRY(hipEventCreate(&s->ev1));
-    for (int e = 0; e < 2; ++e) {
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_z[e], hipEventDisableTiming | hipEventReleaseToDevice));
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming | hipEventReleaseToDevice));
-    }
-    s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
-    s->event_nodes = s->side_enabled && std::getenv("OCC_STREAM_EVENTS") == nullptr;  // diagnostic: fork/join by stream calls
-
-    const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q, C = n_chains;
-    Ctx &c = s->ctx;
-    c.n = n; c.S = S; c.R = R; c.p = p; c.q = q; c.C = C;
-    c.tau_rate = pb->tau_rate; c.tau_shape = pb->tau_shape;
-    c.maxiter = 10LL * n;  // scipy default 5 * (2n)  (minres.py, called at logit.py:87)
+    const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q;
+    L.n = n; L.S = S; L.R = R; L.p = p; L.q = q; L.rsr_dim = pb->rsr_dim;
+    L.tau_rate = pb->tau_rate; L.tau_shape = pb->tau_shape;
+    auto &sell_ptr = L.sell_ptr; auto &sell_col = L.sell_col; auto &sell_val = L.sell_val; auto &qdiag = L.qdiag;
+    auto &dia_off = L.dia_off; auto &dia_val = L.dia_val; auto &dia_mask = L.dia_mask;
+    auto &Xt = L.Xt; auto &Wt = L.Wt; auto &yrow = L.yrow; auto &row_site = L.row_site; auto &site_sidx = L.site_sidx; auto &hyp = L.hyp;
 
     // ---- fetch and check the inputs on the host -------------------------------------------------
     std::vector<int32_t> indptr, indices;
@@ -721,22 +740,22 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     if ((rc = fetch(s, indices, pb->q_indices, nnz))) return rc;
     if ((rc = fetch(s, qdata, pb->q_data, nnz))) return rc;
     if ((rc = fetch(s, X, pb->X, (size_t)n * p))) return rc;
-    if ((rc = fetch(s, s->site_id, pb->site_id, (size_t)S))) return rc;
-    if ((rc = fetch(s, s->site_ptr, pb->site_ptr, (size_t)S + 1))) return rc;
+    if ((rc = fetch(s, L.site_id, pb->site_id, (size_t)S))) return rc;
+    if ((rc = fetch(s, L.site_ptr, pb->site_ptr, (size_t)S + 1))) return rc;
     if ((rc = fetch(s, W, pb->W, (size_t)R * q))) return rc;
     if ((rc = fetch(s, y, pb->y, (size_t)R))) return rc;
     if ((rc = fetch(s, a_mu, pb->a_mu, (size_t)q))) return rc;
     if ((rc = fetch(s, a_prec, pb->a_prec, (size_t)q * q))) return rc;
     if ((rc = fetch(s, b_mu, pb->b_mu, (size_t)p))) return rc;
     if ((rc = fetch(s, b_prec, pb->b_prec, (size_t)p * p))) return rc;
-    if (S > 0 && (s->site_ptr[0] != 0 || s->site_ptr[S] != R)) return set_error(s, OCC_E_BADARG, "site_ptr does not span the rows");
+    if (S > 0 && (L.site_ptr[0] != 0 || L.site_ptr[S] != R)) return set_error(s, OCC_E_BADARG, "site_ptr does not span the rows");
 
     // ---- Q: CSR -> diagonal + SELL-64 off-diagonals (coalesced per-wave slices) -------------------
     // Also checks what the edge form of the prior term needs: zero row sums, non-positive
     // off-diagonals (Q = D - W), the singular ICAR precision of gibbs/base.py:166-170.
     const int nslice = (n + 63) / 64;
-    std::vector<int> sell_ptr((size_t)nslice + 1, 0);
-    std::vector<double> qdiag((size_t)n, 0.0);
+    sell_ptr.assign((size_t)nslice + 1, 0);
+    qdiag.assign((size_t)n, 0.0);
     double scale = 0.0;
     for (int i = 0; i < n; ++i) {
         double rowsum = 0.0, rowabs = 0.0;
@@ -769,13 +788,13 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         int wmax = 0;
         for (int sl = 0; sl < nslice; ++sl) wmax = std::max(wmax, (sell_ptr[sl + 1] - sell_ptr[sl]) / 64);
         const long long ell_slots = (long long)wmax * 64 * nslice;
-        c.ell_w = (wmax > 0 && ell_slots <= (long long)(1.25 * sell_ptr[nslice]) + 64) ? wmax : 0;
-        if (c.ell_w)
+        L.ell_w = (wmax > 0 && ell_slots <= (long long)(1.25 * sell_ptr[nslice]) + 64) ? wmax : 0;
+        if (L.ell_w)
             for (int sl = 0; sl <= nslice; ++sl) sell_ptr[sl] = sl * wmax * 64;
     }
     // 64 spare slots: k_iter reads slot `base + lane` of a slice even when the slice has no off-diagonals
-    std::vector<int> sell_col((size_t)sell_ptr[nslice] + 64, 0);
-    std::vector<double> sell_val((size_t)sell_ptr[nslice] + 64, 0.0);
+    sell_col.assign((size_t)sell_ptr[nslice] + 64, 0);
+    sell_val.assign((size_t)sell_ptr[nslice] + 64, 0.0);
     for (int sl = 0; sl < nslice; ++sl) {
         const int base = sell_ptr[sl], width = (sell_ptr[sl + 1] - base) / 64;
         for (int lane = 0; lane < 64; ++lane) {
@@ -793,9 +812,6 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     }
 
     // ---- diagonal form, when the off-diagonals lie on at most NPRE diagonals with one value each (lattices) -----
-    std::vector<int> dia_off;
-    std::vector<double> dia_val;
-    std::vector<uint8_t> dia_mask;
     {
         std::vector<long long> offs;
         bool ok = true;
@@ -830,31 +846,32 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
             dia_val.clear();
         }
     }
-    const uint8_t *dia_mask_dev = nullptr;
 
     // ---- design matrices as structure-of-arrays; ragged visits; index sets (base.py:112-152) -----
-    std::vector<double> Xt((size_t)n * p), Wt((size_t)R * q);
+    Xt.assign((size_t)n * p, 0.0);
+    Wt.assign((size_t)R * q, 0.0);
     for (int i = 0; i < n; ++i)
         for (int a = 0; a < p; ++a) Xt[(size_t)a * n + i] = X[(size_t)i * p + a];
     for (int r = 0; r < R; ++r)
         for (int a = 0; a < q; ++a) Wt[(size_t)a * R + r] = W[(size_t)r * q + a];
-    std::vector<uint8_t> yrow((size_t)R);
-    std::vector<int> row_site((size_t)R), site_sidx((size_t)n, -1);
-    s->obs_site.assign((size_t)S, 0);
+    yrow.assign((size_t)R, 0);
+    row_site.assign((size_t)R, 0);
+    site_sidx.assign((size_t)n, -1);
+    L.obs_site.assign((size_t)S, 0);
     for (int t = 0; t < S; ++t) {
-        const int site = s->site_id[t];
+        const int site = L.site_id[t];
         if (site < 0 || site >= n || site_sidx[site] != -1) return set_error(s, OCC_E_BADARG, "site_id entries must be unique and in [0, n)");
-        if (s->site_ptr[t + 1] < s->site_ptr[t]) return set_error(s, OCC_E_BADARG, "site_ptr must be non-decreasing");
+        if (L.site_ptr[t + 1] < L.site_ptr[t]) return set_error(s, OCC_E_BADARG, "site_ptr must be non-decreasing");
         site_sidx[site] = t;
         uint8_t any = 0;
-        for (int r = s->site_ptr[t]; r < s->site_ptr[t + 1]; ++r) {
+        for (int r = L.site_ptr[t]; r < L.site_ptr[t + 1]; ++r) {
             yrow[r] = (y[r] != 0.0) ? 1 : 0;
             any |= yrow[r];
         }
-        s->obs_site[t] = any;
-        for (int r = s->site_ptr[t]; r < s->site_ptr[t + 1]; ++r) row_site[r] = site | (any ? (int)0x80000000 : 0);
+        L.obs_site[t] = any;
+        for (int r = L.site_ptr[t]; r < L.site_ptr[t + 1]; ++r) row_site[r] = site | (any ? (int)0x80000000 : 0);
     }
-    std::vector<double> hyp((size_t)q * q + q + (size_t)p * p + p, 0.0);
+    hyp.assign((size_t)q * q + q + (size_t)p * p + p, 0.0);
     {
         double *ap = hyp.data(), *apm = ap + q * q, *bp = apm + q, *bpm = bp + p * p;
         std::copy(a_prec.begin(), a_prec.end(), ap);
@@ -864,6 +881,47 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
         for (int a = 0; a < p; ++a)
             for (int b = 0; b < p; ++b) bpm[a] += b_prec[(size_t)a * p + b] * b_mu[b];  // base.py:162
     }
+
+    if (pb->rsr_dim > 0) {  // reduced-rank model: the basis K (n x m), K'QK and its eigenfactor (m x m), row-major
+        const int m = pb->rsr_dim;
+        if ((rc = fetch(s, L.Kh, pb->rsr_K, (size_t)n * m))) return rc;
+        if ((rc = fetch(s, L.Qh, pb->rsr_Q, (size_t)m * m))) return rc;
+        if ((rc = fetch(s, L.Eh, pb->rsr_E, (size_t)m * m))) return rc;
+    }
+    return OCC_OK;
+}
+
+static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, const uint64_t *keys)
+{
+    if (!keys || n_chains < 1) return set_error(s, OCC_E_BADARG, "bad keys / n_chains");
+    struct { int rsr_dim; } pbv = {L.rsr_dim}, *pb = &pbv;  // (the body below reads pb->rsr_dim)
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    for (int e = 0; e < 2; ++e) {
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_z[e], hipEventDisableTiming | hipEventReleaseToDevice));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming | hipEventReleaseToDevice));
+    }
+    s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
+    s->event_nodes = s->side_enabled && std::getenv("OCC_STREAM_EVENTS") == nullptr;  // diagnostic: fork/join by stream calls
+
+    const int n = L.n, S = L.S, R = L.R, p = L.p, q = L.q, C = n_chains;
+    Ctx &c = s->ctx;
+    c.n = n; c.S = S; c.R = R; c.p = p; c.q = q; c.C = C;
+    c.tau_rate = L.tau_rate; c.tau_shape = L.tau_shape;
+    c.maxiter = 10LL * n;  // scipy default 5 * (2n)  (minres.py, called at logit.py:87)
+    c.ell_w = L.ell_w;
+    s->site_id = L.site_id; s->site_ptr = L.site_ptr; s->obs_site = L.obs_site;
+    const auto &sell_ptr = L.sell_ptr; const auto &sell_col = L.sell_col; const auto &sell_val = L.sell_val; const auto &qdiag = L.qdiag;
+    const auto &dia_off = L.dia_off; const auto &dia_val = L.dia_val; const auto &dia_mask = L.dia_mask;
+    const auto &Xt = L.Xt; const auto &Wt = L.Wt; const auto &yrow = L.yrow; const auto &row_site = L.row_site;
+    const auto &site_sidx = L.site_sidx; const auto &hyp = L.hyp;
+    const int nslice = (n + 63) / 64;
+    const uint8_t *dia_mask_dev = nullptr;
+    int rc;
 
     // ---- launch geometry: one site (or visit row) per thread; enough blocks to spread over the CUs
     int tpb = 256;
@@ -1032,10 +1090,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     }
 
     // initial occupancy state (base.py:113-119) and chain keys
-    std::vector<uint8_t> z0(Cn, 1);
-    for (int ch = 0; ch < C; ++ch)
-        for (int t = 0; t < S; ++t) z0[(size_t)ch * n + s->site_id[t]] = s->obs_site[t];
-    HIP_TRY(hipMemcpy(c.z, z0.data(), z0.size(), hipMemcpyHostToDevice));
+    if ((rc = init_occupancy(s))) return rc;
     std::vector<ChainScalars> sc((size_t)C);
     std::memset(sc.data(), 0, sizeof(ChainScalars) * sc.size());
     for (int ch = 0; ch < C; ++ch) sc[ch].key = keys[ch];
@@ -1094,10 +1149,7 @@ static int create_impl(occ_sampler *s, const occ_problem *pb, int32_t n_chains, 
     }
     if (pb->rsr_dim > 0) {  // reduced-rank model
         const int m = pb->rsr_dim;
-        std::vector<double> Kh, Qh, Eh;
-        if ((rc = fetch(s, Kh, pb->rsr_K, (size_t)n * m))) return rc;
-        if ((rc = fetch(s, Qh, pb->rsr_Q, (size_t)m * m))) return rc;
-        if ((rc = fetch(s, Eh, pb->rsr_E, (size_t)m * m))) return rc;
+        const std::vector<double> &Kh = L.Kh, &Qh = L.Qh, &Eh = L.Eh;
         std::vector<double> Kth((size_t)m * n);
         for (int i = 0; i < n; ++i)
             for (int a = 0; a < m; ++a) Kth[(size_t)a * n + i] = Kh[(size_t)i * m + a];
@@ -1138,7 +1190,10 @@ int occ_create(const occ_problem *problem, int32_t n_chains, const uint64_t *key
     *out = nullptr;
     occ_sampler *s = new occ_sampler();
     s->device = device;
-    int rc = create_impl(s, problem, n_chains, keys);
+    HostLayout L;
+    int rc = hipSetDevice(device) == hipSuccess ? OCC_OK : set_error(s, OCC_E_HIP, "no such HIP device");
+    if (rc == OCC_OK) rc = build_layout(s, problem, L);
+    if (rc == OCC_OK) rc = create_impl(s, L, n_chains, keys);
     if (rc != OCC_OK) {
         g_create_error = s->err;
         occ_destroy(s);
@@ -1147,6 +1202,332 @@ int occ_create(const occ_problem *problem, int32_t n_chains, const uint64_t *key
     *out = s;
     return OCC_OK;
 }
+
+// ---- groups of samplers: one per device (in-process) or one per process, the fixed arrays broadcast over RCCL ---------
+namespace {
+
+#define NCCL_TRY(owner, expr)                                                                                 \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) {                                                                              \
+            (owner)->err = std::string(#expr) + ": " + rccl().GetErrorString(r_);                             \
+            return OCC_E_HIP;                                                                                 \
+        }                                                                                                     \
+    } while (0)
+
+thread_local std::string g_comm_error;
+
+int comm_stage(occ_comm *cm, size_t bytes)
+{
+    if (bytes <= cm->stage_bytes) return OCC_OK;
+    if (cm->stage) (void)hipFree(cm->stage);
+    cm->stage = nullptr;
+    cm->stage_bytes = 0;
+    if (hipMalloc(&cm->stage, bytes) != hipSuccess) { cm->err = "hipMalloc of the staging buffer failed"; return OCC_E_HIP; }
+    cm->stage_bytes = bytes;
+    return OCC_OK;
+}
+
+int comm_bcast_dev(occ_comm *cm, void *dev_ptr, size_t bytes, int root)
+{
+    if (bytes == 0) return OCC_OK;
+    NCCL_TRY(cm, rccl().Broadcast(dev_ptr, dev_ptr, bytes, ncclChar, root, cm->comm, cm->stream));
+    return OCC_OK;
+}
+
+int comm_bcast_host(occ_comm *cm, void *buf, size_t bytes, int root)
+{
+    if (bytes == 0) return OCC_OK;
+    int rc = comm_stage(cm, bytes);
+    if (rc) return rc;
+    if (cm->rank == root && hipMemcpyAsync(cm->stage, buf, bytes, hipMemcpyHostToDevice, cm->stream) != hipSuccess) { cm->err = "H2D copy failed"; return OCC_E_HIP; }
+    if ((rc = comm_bcast_dev(cm, cm->stage, bytes, root))) return rc;
+    if (hipMemcpyAsync(buf, cm->stage, bytes, hipMemcpyDeviceToHost, cm->stream) != hipSuccess || hipStreamSynchronize(cm->stream) != hipSuccess) {
+        cm->err = "D2H copy after the broadcast failed";
+        return OCC_E_HIP;
+    }
+    return OCC_OK;
+}
+
+int comm_allreduce(occ_comm *cm, double *inout, int n, ncclRedOp_t op)
+{
+    int rc = comm_stage(cm, sizeof(double) * (size_t)n);
+    if (rc) return rc;
+    if (hipMemcpyAsync(cm->stage, inout, sizeof(double) * n, hipMemcpyHostToDevice, cm->stream) != hipSuccess) { cm->err = "H2D copy failed"; return OCC_E_HIP; }
+    NCCL_TRY(cm, rccl().AllReduce(cm->stage, cm->stage, (size_t)n, ncclDouble, op, cm->comm, cm->stream));
+    if (hipMemcpyAsync(inout, cm->stage, sizeof(double) * n, hipMemcpyDeviceToHost, cm->stream) != hipSuccess || hipStreamSynchronize(cm->stream) != hipSuccess) {
+        cm->err = "D2H copy after the reduction failed";
+        return OCC_E_HIP;
+    }
+    return OCC_OK;
+}
+
+// What a peer needs to size its arrays before the broadcast
+struct LayoutHeader {
+    int32_t ok, n, S, R, p, q, ell_w, ndia, nsell_ptr, pad_;
+    double tau_rate, tau_shape;
+    int32_t dia_off[8];
+    double dia_val[8];
+};
+
+void size_peer_layout(HostLayout &L, const LayoutHeader &h)
+{
+    L.n = h.n; L.S = h.S; L.R = h.R; L.p = h.p; L.q = h.q; L.ell_w = h.ell_w; L.rsr_dim = 0;
+    L.tau_rate = h.tau_rate; L.tau_shape = h.tau_shape;
+    L.dia_off.assign(h.dia_off, h.dia_off + h.ndia);
+    L.dia_val.assign(h.dia_val, h.dia_val + h.ndia);
+    const size_t slots = (size_t)L.sell_ptr.back() + 64;
+    L.sell_col.assign(slots, 0);
+    L.sell_val.assign(slots, 0.0);
+    L.qdiag.assign((size_t)h.n, 0.0);
+    if (h.ndia > 0) L.dia_mask.assign((size_t)h.n, 0);
+    L.Xt.assign((size_t)h.n * h.p, 0.0);
+    L.Wt.assign((size_t)h.R * h.q, 0.0);
+    L.yrow.assign((size_t)h.R, 0);
+    L.row_site.assign((size_t)h.R, 0);
+    L.site_sidx.assign((size_t)h.n, -1);
+    L.hyp.assign((size_t)h.q * h.q + h.q + (size_t)h.p * h.p + h.p, 0.0);
+    L.site_id.assign((size_t)h.S, 0);
+    for (int t = 0; t < h.S; ++t) L.site_id[t] = t;  // placeholders (unique, in range) until the real arrays arrive
+    L.site_ptr.assign((size_t)h.S + 1, 0);
+    L.obs_site.assign((size_t)h.S, 0);
+}
+
+// A peer's host mirrors (site numbers, row offsets, detection flags) from the device arrays it has just received
+int refresh_host_mirrors(occ_sampler *s)
+{
+    const Ctx &c = s->ctx;
+    std::vector<int> sidx((size_t)c.n), sp((size_t)c.S + 1);
+    s->obs_site.assign((size_t)c.S, 0);
+    HIP_TRY(hipMemcpy(sidx.data(), c.site_sidx, sizeof(int) * sidx.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sp.data(), c.site_ptr, sizeof(int) * sp.size(), hipMemcpyDeviceToHost));
+    if (c.S > 0) HIP_TRY(hipMemcpy(s->obs_site.data(), c.obs_site, (size_t)c.S, hipMemcpyDeviceToHost));
+    s->site_id.assign((size_t)c.S, 0);
+    for (int i = 0; i < c.n; ++i)
+        if (sidx[i] >= 0 && sidx[i] < c.S) s->site_id[sidx[i]] = i;
+    s->site_ptr.assign(sp.begin(), sp.end());
+    return init_occupancy(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *occ_comm_last_error(const occ_comm *cm) { return cm ? cm->err.c_str() : g_comm_error.c_str(); }
+
+int occ_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return OCC_E_BADARG;
+    if (!rccl().ok()) { g_comm_error = rccl().err; return OCC_E_HIP; }
+    ncclUniqueId u;
+    const ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r); return OCC_E_HIP; }
+    static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id, &u, 128);
+    return OCC_OK;
+}
+
+int occ_comm_create(int32_t world, int32_t rank, const uint8_t id[128], int32_t device, occ_comm **out)
+{
+    if (!out || !id || world < 1 || rank < 0 || rank >= world) return OCC_E_BADARG;
+    *out = nullptr;
+    if (!rccl().ok()) { g_comm_error = rccl().err; return OCC_E_HIP; }
+    occ_comm *cm = new occ_comm();
+    cm->world = world; cm->rank = rank; cm->device = device;
+    auto fail = [&](const std::string &msg) { g_comm_error = msg; delete cm; return OCC_E_HIP; };
+    if (hipSetDevice(device) != hipSuccess) return fail("no such HIP device");
+    if (hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    const ncclResult_t r = rccl().CommInitRank(&cm->comm, world, u, rank);
+    if (r != ncclSuccess) return fail(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    *out = cm;
+    return OCC_OK;
+}
+
+int occ_comm_destroy(occ_comm *cm)
+{
+    if (!cm) return OCC_OK;
+    (void)hipSetDevice(cm->device);
+    if (cm->stream) (void)hipStreamSynchronize(cm->stream);
+    if (cm->comm) (void)rccl().CommDestroy(cm->comm);
+    if (cm->stage) (void)hipFree(cm->stage);
+    if (cm->stream) (void)hipStreamDestroy(cm->stream);
+    delete cm;
+    return OCC_OK;
+}
+
+int occ_comm_barrier(occ_comm *cm)
+{
+    if (!cm) return OCC_E_BADARG;
+    (void)hipSetDevice(cm->device);
+    double one = 1.0;
+    return comm_allreduce(cm, &one, 1, ncclSum);
+}
+
+int occ_comm_allreduce_max(occ_comm *cm, double *inout, int32_t n)
+{
+    if (!cm || !inout || n < 1) return OCC_E_BADARG;
+    (void)hipSetDevice(cm->device);
+    return comm_allreduce(cm, inout, n, ncclMax);
+}
+
+int occ_comm_broadcast_host(occ_comm *cm, void *buf, int64_t bytes, int32_t root)
+{
+    if (!cm || (!buf && bytes > 0) || bytes < 0 || root < 0 || root >= cm->world) return OCC_E_BADARG;
+    (void)hipSetDevice(cm->device);
+    return comm_bcast_host(cm, buf, (size_t)bytes, root);
+}
+
+// Everything enqueued on the handle's device has completed (benchmarks bracket their timed region with it).
+int occ_synchronize(occ_sampler *s)
+{
+    if (!s) return OCC_E_BADARG;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return OCC_OK;
+}
+
+const char *occ_group_transport(const occ_sampler *s) { return s ? s->group_transport.c_str() : ""; }
+
+// One sampler per PROCESS (one process per GPU): the root lays the problem out and uploads it; every other rank sizes its
+// arrays from a small header and receives the fixed arrays device-to-device over RCCL (xGMI) -- no host copy of the
+// design matrices exists on the peers at any time.  `problem` is read on the root only.
+int occ_create_distributed(const occ_problem *problem, occ_comm *cm, int32_t root, int32_t n_chains, const uint64_t *keys, occ_sampler **out)
+{
+    if (!out || !cm || root < 0 || root >= cm->world) return OCC_E_BADARG;
+    *out = nullptr;
+    occ_sampler *s = new occ_sampler();
+    s->device = cm->device;
+    auto fail = [&](int rc) { g_create_error = s->err.empty() ? cm->err : s->err; occ_destroy(s); return rc; };
+    if (hipSetDevice(cm->device) != hipSuccess) return fail(set_error(s, OCC_E_HIP, "no such HIP device"));
+    HostLayout L;
+    LayoutHeader h{};
+    int rc = OCC_OK;
+    if (cm->rank == root) {
+        rc = build_layout(s, problem, L);
+        if (rc == OCC_OK && L.rsr_dim > 0) rc = set_error(s, OCC_E_BADARG, "occ_create_distributed covers the ICAR model");
+        h.ok = rc == OCC_OK;
+        if (h.ok) {
+            h.n = L.n; h.S = L.S; h.R = L.R; h.p = L.p; h.q = L.q; h.ell_w = L.ell_w;
+            h.ndia = (int32_t)L.dia_off.size(); h.nsell_ptr = (int32_t)L.sell_ptr.size();
+            h.tau_rate = L.tau_rate; h.tau_shape = L.tau_shape;
+            for (int d = 0; d < h.ndia; ++d) { h.dia_off[d] = L.dia_off[d]; h.dia_val[d] = L.dia_val[d]; }
+        }
+    }
+    int crc = comm_bcast_host(cm, &h, sizeof(h), root);  // (a root that failed says so: nobody waits for arrays that never come)
+    if (crc) return fail(crc);
+    if (!h.ok) return fail(rc ? rc : set_error(s, OCC_E_BADARG, "the root rank rejected the problem"));
+    if (cm->rank != root) L.sell_ptr.assign((size_t)h.nsell_ptr, 0);
+    if ((crc = comm_bcast_host(cm, L.sell_ptr.data(), sizeof(int) * L.sell_ptr.size(), root))) return fail(crc);
+    if (cm->rank != root) {
+        size_peer_layout(L, h);
+        s->defer_fixed = true;
+    }
+    rc = create_impl(s, L, n_chains, keys);
+    double bad = rc != OCC_OK ? 1.0 : 0.0;  // all ranks or none go on to the broadcasts
+    if ((crc = comm_allreduce(cm, &bad, 1, ncclMax))) return fail(crc);
+    if (bad != 0.0) return fail(rc ? rc : set_error(s, OCC_E_HIP, "another rank failed to create its sampler"));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto &fa : s->fixed_list)
+        if ((crc = comm_bcast_dev(cm, fa.first, fa.second, root))) return fail(crc);
+    if (hipStreamSynchronize(cm->stream) != hipSuccess) return fail(set_error(s, OCC_E_HIP, "the broadcast stream failed"));
+    if (cm->rank != root && (rc = refresh_host_mirrors(s))) return fail(rc);
+    s->group_transport = "rccl broadcast (ncclCommInitRank), " + std::to_string(cm->world) + " ranks";
+    *out = s;
+    return OCC_OK;
+}
+
+// One sampler per DEVICE of this process (driven by one host thread each): the problem is laid out once, uploaded to
+// devices[0] and broadcast from there to the other devices -- RCCL (ncclCommInitAll + grouped ncclBroadcast), or, when
+// librccl cannot be used (or OCC_GROUP_TRANSPORT=peer), hipMemcpyPeer, device to device either way.
+// keys: the chains' keys, device after device.  On failure no handle is returned.
+int occ_create_group(const occ_problem *problem, int32_t n_devices, const int32_t *devices, const int32_t *chains_per_device,
+                     const uint64_t *keys, occ_sampler **out)
+{
+    if (!out || !devices || !chains_per_device || !keys || n_devices < 1) return OCC_E_BADARG;
+    for (int g = 0; g < n_devices; ++g) out[g] = nullptr;
+    std::vector<occ_sampler *> ss((size_t)n_devices, nullptr);
+    auto fail = [&](int rc, const std::string &msg) {
+        g_create_error = msg;
+        for (auto *p : ss) occ_destroy(p);
+        return rc;
+    };
+    HostLayout L;
+    {
+        occ_sampler tmp;
+        tmp.device = devices[0];
+        if (hipSetDevice(devices[0]) != hipSuccess) return fail(OCC_E_HIP, "no such HIP device");
+        const int rc = build_layout(&tmp, problem, L);
+        if (rc) return fail(rc, tmp.err);
+    }
+    size_t koff = 0;
+    for (int g = 0; g < n_devices; ++g) {
+        ss[g] = new occ_sampler();
+        ss[g]->device = devices[g];
+        ss[g]->defer_fixed = g > 0;
+        if (hipSetDevice(devices[g]) != hipSuccess) return fail(OCC_E_HIP, "no such HIP device");
+        const int rc = create_impl(ss[g], L, chains_per_device[g], keys + koff);
+        if (rc) return fail(rc, ss[g]->err);
+        if (hipDeviceSynchronize() != hipSuccess) return fail(OCC_E_HIP, "device synchronisation failed");
+        koff += (size_t)chains_per_device[g];
+    }
+    const size_t narr = ss[0]->fixed_list.size();
+    for (int g = 1; g < n_devices; ++g) {
+        if (ss[g]->fixed_list.size() != narr) return fail(OCC_E_HIP, "internal: the samplers of a group disagree on their arrays");
+        for (size_t i = 0; i < narr; ++i)
+            if (ss[g]->fixed_list[i].second != ss[0]->fixed_list[i].second) return fail(OCC_E_HIP, "internal: the samplers of a group disagree on their arrays");
+    }
+    std::string transport = "single device";
+    if (n_devices > 1) {
+        const char *force = std::getenv("OCC_GROUP_TRANSPORT");
+        bool done = false;
+        std::string why;
+        if (!(force && std::string(force) == "peer") && rccl().ok()) {
+            std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+            ncclResult_t r = rccl().CommInitAll(comms.data(), n_devices, devices);
+            if (r == ncclSuccess) {
+                for (size_t i = 0; i < narr && r == ncclSuccess; ++i) {
+                    r = rccl().GroupStart();
+                    for (int g = 0; g < n_devices && r == ncclSuccess; ++g) {
+                        void *ptr = ss[g]->fixed_list[i].first;
+                        r = rccl().Broadcast(ptr, ptr, ss[0]->fixed_list[i].second, ncclChar, 0, comms[g], ss[g]->stream);
+                    }
+                    const ncclResult_t re = rccl().GroupEnd();
+                    if (r == ncclSuccess) r = re;
+                }
+                for (int g = 0; g < n_devices; ++g) {
+                    (void)hipSetDevice(devices[g]);
+                    if (hipStreamSynchronize(ss[g]->stream) != hipSuccess && r == ncclSuccess) r = ncclUnhandledCudaError;
+                }
+                for (auto cmm : comms)
+                    if (cmm) (void)rccl().CommDestroy(cmm);
+                if (r != ncclSuccess) return fail(OCC_E_HIP, std::string("RCCL broadcast of the problem failed: ") + rccl().GetErrorString(r));
+                done = true;
+                transport = "rccl broadcast (ncclCommInitAll), " + std::to_string(n_devices) + " devices";
+            } else {
+                why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
+                (void)hipGetLastError();
+            }
+        } else {
+            why = force ? "OCC_GROUP_TRANSPORT=peer" : rccl().err;
+        }
+        if (!done) {  // device-to-device copies from the root
+            for (int g = 1; g < n_devices; ++g)
+                for (size_t i = 0; i < narr; ++i)
+                    if (hipMemcpyPeer(ss[g]->fixed_list[i].first, devices[g], ss[0]->fixed_list[i].first, devices[0], ss[0]->fixed_list[i].second) != hipSuccess)
+                        return fail(OCC_E_HIP, "hipMemcpyPeer of the problem failed (" + why + ")");
+            transport = "hipMemcpyPeer (" + why + ")";
+        }
+    }
+    for (int g = 0; g < n_devices; ++g) {
+        ss[g]->group_transport = transport;
+        out[g] = ss[g];
+    }
+    return OCC_OK;
+}
+
+}  // extern "C"
 
 // theta of one chain (caller pointer), and eta = K theta computed on the host (set-up path only)
 static int set_theta(occ_sampler *s, int chain, const double *theta_in)

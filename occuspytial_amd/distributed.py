@@ -1,17 +1,33 @@
-"""Chains sharded over GPUs: one process per GPU, ``torch.distributed`` for the set-up traffic.
+"""Chains sharded over GPUs, one PROCESS per GPU -- without PyTorch.
 
-Chains are independent (reference ``gibbs/parallel.py:20-41`` runs each in its own process), so the
-only communication is (1) ONE broadcast of the fixed design arrays from rank 0 -- RCCL over xGMI when
-the backend is ``nccl``, each array moved as a device tensor -- and (2) a gather of the recorded
-``(alpha, beta, tau)`` rows at the end.  There is no per-iteration collective.
+Chains are independent (reference ``gibbs/parallel.py:20-41`` runs each in its own joblib process), so a multi-GPU run
+is replicas plus ONE broadcast of the fixed problem arrays at set-up: the root rank lays the problem out
+and uploads it, the other ranks receive the device arrays over RCCL / xGMI (``occ_create_distributed`` in the C ABI,
+librccl opened with dlopen by the engine library).  There is no per-iteration collective; the recorded
+``(alpha, beta, tau)`` rows are gathered at the end.
 
-``torch`` is plumbing here (process group, broadcast); the sampler itself is the HIP engine.  The
-compute backend is injected (``engine_factory``) so that the sharding logic can be exercised on CPU
-with ``gloo`` in the test-suite; the default factory is the HIP engine and raises without a GPU.
+Two communicators with one interface (``rank``, ``world``, ``barrier``, ``allreduce_max``, ``bcast_obj``,
+``allgather_obj``):
+
+* :class:`FileComm` -- a rendezvous directory on the node (``/dev/shm`` or ``/tmp``): enough for everything the host
+  side of a single-node launch needs, used for the one thing RCCL cannot do for itself (handing rank 0's
+  ``ncclUniqueId`` to the other ranks), by the CPU tests, and as the fallback when librccl cannot be used;
+* :class:`RcclComm` -- ``ncclCommInitRank`` through the C ABI (``occ_comm_*``): the communicator the device broadcast
+  runs on; its host-side collectives are staged through a device buffer.
+
+(The in-process alternative -- one process driving several GPUs with a host thread each -- is
+``LogitICARGibbs(..., devices=[...])``; it needs none of this.)
 """
+import ctypes as C
+import os
+import pickle
+import shutil
+import threading
+import time
+
 import numpy as np
 
-from ._problem import FlatProblem, chain_generators, default_start
+from ._problem import chain_generators, default_start
 
 
 def shard_chains(n_chains, world_size, rank):
@@ -19,34 +35,175 @@ def shard_chains(n_chains, world_size, rank):
     return [c for c in range(n_chains) if c % world_size == rank]
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
+# ---------------------------------------------------------------------------------------------------------------
+class FileComm:
+    """Collectives of a single-node process group through files in a rendezvous directory.
+
+    Every collective is an all-gather of pickled objects: rank r writes ``<op>.<r>`` (atomically, by rename) and reads
+    the files of the ranks it needs.  Operation numbers advance in lock step on all ranks (every rank must make the
+    same calls in the same order, as with any communicator)."""
+
+    def __init__(self, rank, world, path, timeout=300.0):
+        self.rank, self.world, self.path, self.timeout = int(rank), int(world), path, float(timeout)
+        self._op = 0
+        os.makedirs(path, exist_ok=True)
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        """Rank / world size from the launcher's environment (``RANK``, ``WORLD_SIZE`` as torch.distributed.run and
+        most MPI-style launchers set them).  The directory is keyed by the rendezvous port and the launcher's PID --
+        all ranks of one launch are children of the same agent process -- so stale files of an earlier launch on the
+        same port are never read."""
+        rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+        base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
+        tag = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.getppid())
+        return cls(rank, world, os.path.join(base, 'occ_rdv_' + tag), timeout)
+
+    def _file(self, op, r):
+        return os.path.join(self.path, '%06d.%d' % (op, r))
+
+    def _put(self, op, obj):
+        tmp = self._file(op, self.rank) + '.tmp'
+        with open(tmp, 'wb') as fh:
+            pickle.dump(obj, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(tmp, self._file(op, self.rank))
+
+    def _get(self, op, r):
+        f = self._file(op, r)
+        t0 = time.monotonic()
+        while not os.path.exists(f):
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError('rank %d waited %.0f s for rank %d (operation %d) in %s' % (self.rank, self.timeout, r, op, self.path))
+            time.sleep(0.0005)
+        with open(f, 'rb') as fh:
+            return pickle.load(fh)
+
+    def allgather_obj(self, obj):
+        op, self._op = self._op, self._op + 1
+        self._put(op, obj)
+        return [obj if r == self.rank else self._get(op, r) for r in range(self.world)]
+
+    def bcast_obj(self, obj, root=0):
+        # (every rank writes a token so that the root cannot run ahead and be overtaken by a later operation's files)
+        return self.allgather_obj(obj if self.rank == root else None)[root]
+
+    def barrier(self):
+        self.allgather_obj(None)
+
+    def allreduce_max(self, x):
+        return np.max(np.stack([np.asarray(v, dtype=np.float64) for v in self.allgather_obj(np.asarray(x, dtype=np.float64))]), axis=0)
+
+    def close(self):
+        """Collective: the last operation of the group; rank 0 removes the directory."""
+        self.barrier()
+        if self.rank == 0:
+            time.sleep(0.05)   # the others have read this barrier's files or are about to
+            shutil.rmtree(self.path, ignore_errors=True)
 
 
-def broadcast_problem(prob, src=0, device=None):
-    """Broadcast a :class:`FlatProblem` from rank ``src``; every rank returns an equal problem.
+class RcclComm:
+    """``ncclCommInitRank`` through the engine library (``occ_comm_*``).  ``side`` is any communicator that can
+    broadcast a small object (the 128-byte unique id): a :class:`FileComm`."""
 
-    ``prob`` is ignored on the other ranks (may be None).  With ``device`` (a ``torch.device`` of the
-    local GPU) the arrays travel as device tensors, i.e. over RCCL/xGMI with the ``nccl`` backend.
-    """
-    import torch
-    dist = _dist()
-    rank = dist.get_rank()
-    arrays = prob.to_arrays() if rank == src else None
-    meta = [[(k, v.shape, str(v.dtype)) for k, v in arrays.items()]] if rank == src else [None]
-    dist.broadcast_object_list(meta, src=src)
-    out = {}
-    for name, shape, dtype in meta[0]:
-        if rank == src:
-            t = torch.from_numpy(arrays[name].reshape(-1).copy())
-        else:
-            t = torch.empty(int(np.prod(shape)), dtype=getattr(torch, np.dtype(dtype).name))
-        if device is not None:
-            t = t.to(device)
-        dist.broadcast(t, src=src)
-        out[name] = t.cpu().numpy().reshape(shape)
-    return prob if rank == src else FlatProblem.from_arrays(out)
+    def __init__(self, side, device, init_timeout=180.0):
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.device, self.side = side.rank, side.world, int(device), side
+        uid = (C.c_uint8 * 128)()
+        ok = True
+        if self.rank == 0:
+            ok = self._lib.occ_comm_unique_id(uid) == 0
+        # all ranks or none: a rank that cannot open librccl must not leave the others inside ncclCommInitRank
+        word = side.bcast_obj(bytes(uid) if ok else None, 0)
+        if word is None:
+            raise RuntimeError('RCCL is not usable on rank 0: ' + self._err(None))
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(word)
+        box = {}
+
+        def init():
+            box['code'] = self._lib.occ_comm_create(self.world, self.rank, buf, self.device, C.byref(h))
+
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(init_timeout)
+        good = (not th.is_alive()) and box.get('code') == 0
+        if not all(side.allgather_obj(bool(good))):
+            raise RuntimeError('ncclCommInitRank did not succeed on every rank (this rank: %s)'
+                               % ('ok' if good else ('timed out' if th.is_alive() else self._err(None))))
+        self.handle = h
+
+    def _err(self, h):
+        msg = self._lib.occ_comm_last_error(h)
+        return msg.decode() if msg else ''
+
+    def _check(self, code):
+        if code != 0:
+            raise RuntimeError('RCCL communicator failure: ' + self._err(self.handle))
+
+    def barrier(self):
+        self._check(self._lib.occ_comm_barrier(self.handle))
+
+    def allreduce_max(self, x):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        self._check(self._lib.occ_comm_allreduce_max(self.handle, C.c_void_p(v.ctypes.data), v.size))
+        return v if np.ndim(x) else float(v[0])
+
+    def bcast_bytes(self, data, root=0):
+        n = np.array([len(data) if self.rank == root else 0], dtype=np.int64)
+        self._check(self._lib.occ_comm_broadcast_host(self.handle, C.c_void_p(n.ctypes.data), 8, root))
+        buf = np.frombuffer(data, dtype=np.uint8).copy() if self.rank == root else np.empty(int(n[0]), dtype=np.uint8)
+        if buf.size:
+            self._check(self._lib.occ_comm_broadcast_host(self.handle, C.c_void_p(buf.ctypes.data), buf.size, root))
+        return buf.tobytes()
+
+    def bcast_obj(self, obj, root=0):
+        return pickle.loads(self.bcast_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if self.rank == root else b'', root))
+
+    def allgather_obj(self, obj):
+        return [self.bcast_obj(obj if self.rank == r else None, r) for r in range(self.world)]
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.occ_comm_destroy(self.handle)
+            self.handle = None
+        self.side.close()
+
+
+def init_comm(device=None, prefer_rccl=True, timeout=300.0):
+    """The process group of this launch: an :class:`RcclComm` when ``device`` is given and librccl works on every rank,
+    else the :class:`FileComm` (all ranks take the same branch).  Returns ``(comm, note)``."""
+    side = FileComm.from_env(timeout)
+    if device is None or not prefer_rccl:
+        return side, 'file rendezvous (no device communicator requested)'
+    try:
+        return RcclComm(side, device), 'rccl (ncclCommInitRank over a file rendezvous of the unique id)'
+    except Exception as exc:   # every rank raises or none does (see RcclComm.__init__)
+        return side, 'file rendezvous (RCCL unusable: %s)' % exc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def broadcast_problem(prob, comm, root=0):
+    """The full :class:`FlatProblem` on every rank, through the communicator's object broadcast (host data).  This is
+    the generic route (CPU tests, engines that are not the HIP engine); the HIP engine does not need it:
+    :func:`distributed_engine` moves the design arrays device to device and gives the other ranks' hosts only the sizes
+    and hyper-parameters."""
+    from ._problem import FlatProblem
+    arrays = comm.bcast_obj(prob.to_arrays() if comm.rank == root else None, root)
+    return prob if comm.rank == root else FlatProblem.from_arrays(arrays)
+
+
+def distributed_engine(prob, comm, keys, root=0):
+    """This rank's HIP engine for ``keys``; ``prob`` is needed on ``root`` only.  Returns ``(engine, meta)`` where
+    ``meta`` (a :class:`ProblemMeta` everywhere but on the root, which keeps its problem) has what start values need."""
+    from ._engine import Engine, ProblemMeta
+    meta = comm.bcast_obj(ProblemMeta.of(prob).to_dict() if comm.rank == root else None, root)
+    mine = prob if comm.rank == root else ProblemMeta(**meta)
+    if isinstance(comm, RcclComm):
+        return Engine.distributed(mine, comm, keys, root), mine
+    # no device communicator: every rank builds its own engine from the host arrays
+    full = broadcast_problem(prob, comm, root)
+    return Engine(full, keys, device=int(os.environ.get('LOCAL_RANK', '0'))), full
 
 
 def _hip_engine_factory(prob, keys, device):
@@ -55,16 +212,17 @@ def _hip_engine_factory(prob, keys, device):
 
 
 def run_sharded(prob, n_chains, size, burnin=0, random_state=None, start=None, device=0,
-                engine_factory=None, gather=True):
-    """Run ``n_chains`` chains of ``size`` iterations split over the ranks of the default process group.
+                engine_factory=None, gather=True, comm=None):
+    """Run ``n_chains`` chains of ``size`` iterations split over the ranks of ``comm``.
 
-    Every rank derives the same per-chain generators from ``random_state`` (chain k's generator is
-    the one the reference would give its k-th copy), draws start values and Philox keys for ITS chains
-    only, and runs them as one device batch.  Returns ``(alpha, beta, tau)`` with a leading chain axis
-    in global chain order on every rank when ``gather`` (else only this rank's chains).
-    """
-    dist = _dist()
-    world, rank = dist.get_world_size(), dist.get_rank()
+    Every rank derives the same per-chain generators from ``random_state`` (chain k's generator is the one the
+    reference would give its k-th copy, ``gibbs/base.py:293-306``), draws start values and Philox keys for ITS chains
+    only -- chain c lives on rank ``c % world`` -- and runs them as one device batch.  Returns ``(alpha, beta, tau)``
+    with a leading chain axis in global chain order on every rank when ``gather`` (else only this rank's chains).
+    ``engine_factory(prob, keys, device)`` builds the compute backend (default: the HIP engine)."""
+    if comm is None:
+        comm = FileComm.from_env()
+    world, rank = comm.world, comm.rank
     mine = shard_chains(n_chains, world, rank)
     gens = chain_generators(random_state, n_chains)
     keep = size - burnin
@@ -85,8 +243,7 @@ def run_sharded(prob, n_chains, size, burnin=0, random_state=None, start=None, d
             eng.close()
     if not gather:
         return a, b, t
-    parts = [None] * world
-    dist.all_gather_object(parts, (mine, a, b, t))
+    parts = comm.allgather_obj((mine, a, b, t))
     A = np.zeros((n_chains, keep, prob.q))
     B = np.zeros((n_chains, keep, prob.p))
     T = np.zeros((n_chains, keep))

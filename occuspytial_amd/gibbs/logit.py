@@ -1,7 +1,7 @@
 """``LogitICARGibbs`` on the MI355X engine (API of reference ``occuspytial/gibbs/logit.py:102-266``)."""
 import numpy as np
 
-from .._engine import Engine
+from .._engine import Engine, EngineGroup
 from ..chain import Chain
 from .base import GibbsBase
 
@@ -28,12 +28,18 @@ class LogitICARGibbs(GibbsBase):
     * the prior term of the :math:`\eta` conditional uses the edge factorisation
       :math:`Q = B^\top B` instead of a dense eigenfactor (``logit.py:66-67``): no O(n^2) memory, no
       O(n^3) set-up; ``Q`` must be an ICAR precision (zero row sums, non-positive off-diagonals);
-    * ``device`` selects the HIP device; all chains of one ``sample`` call run batched on it.
+    * ``device`` selects the HIP device; all chains of one ``sample`` call run batched on it.  ``devices=[...]``
+      instead fans the chains of ``sample(chains=N)`` out over several GPUs from this process, chain ``c`` on
+      ``devices[c % len(devices)]`` -- the reference's one-process-per-chain fan-out (``gibbs/parallel.py:20-41``) with
+      GPUs for processes: the problem is uploaded once and broadcast device to device over RCCL, every GPU is driven by
+      its own host thread, and chain ``k`` still owns the generator the reference would give it, so the draws do not
+      depend on how many devices share the work.
     """
 
-    def __init__(self, Q, W, X, y, hparams=None, random_state=None, device=0):
+    def __init__(self, Q, W, X, y, hparams=None, random_state=None, device=0, devices=None):
         super().__init__(Q, W, X, y, hparams, random_state)
-        self.device = device
+        self.devices = [int(d) for d in devices] if devices is not None else None
+        self.device = self.devices[0] if self.devices else device
         self._configure(Q, hparams)
 
     def _configure(self, Q, hparams):
@@ -45,7 +51,10 @@ class LogitICARGibbs(GibbsBase):
         if eng is None or eng.n_chains != len(keys):
             if eng is not None:
                 eng.close()
-            eng = Engine(self._problem, keys, device=self.device)
+            if self.devices and len(self.devices) > 1 and len(keys) > 1:   # chains sharded over the GPUs of this process
+                eng = EngineGroup(self._problem, keys, self.devices)
+            else:
+                eng = Engine(self._problem, keys, device=self.device)
             self.__dict__['_engine'] = eng
         else:
             eng.set_keys(keys)
@@ -210,8 +219,8 @@ class LogitRSRGibbs(LogitICARGibbs):
     basis columns.  ``device`` selects the HIP device.
     """
 
-    def __init__(self, Q, W, X, y, hparams=None, random_state=None, r=0.5, q=None, device=0):
-        super().__init__(Q, W, X, y, hparams, random_state, device=device)
+    def __init__(self, Q, W, X, y, hparams=None, random_state=None, r=0.5, q=None, device=0, devices=None):
+        super().__init__(Q, W, X, y, hparams, random_state, device=device, devices=devices)
         self._configure_rsr(r, q, hparams)
 
     def _configure_rsr(self, r, q, hparams):

@@ -589,6 +589,9 @@ struct orc_sampler {
     /* reduced-rank model (LogitRSRGibbs): rdim > 0 */
     int rdim;
     double *K, *Qr, *Er, *theta;
+    /* reference-faithful prior draw (logit.py:66-67,77): dense eigenfactor E, n x (n-1) row-major, BORROWED from the
+     * caller (800 MB at 100x100: shared by all chains of a baseline run); NULL: edge form */
+    const double *dense_E;
 };
 
 static void *dupmem(const void *src, size_t bytes)
@@ -799,13 +802,43 @@ static int update_eta_rsr(orc_sampler *s)
     return 0;
 }
 
+/* u = E v, E row-major n x m: the dense matvec the reference pays every iteration (logit.py:77; numpy hands it to BLAS
+ * dgemv).  Eight independent partial sums so that the compiler can keep the FMA pipes full without reassociating. */
+__attribute__((optimize("O3"))) static void dense_matvec(long n, long m, const double *E, const double *v, double *u)
+{
+    for (long i = 0; i < n; ++i) {
+        const double *row = E + (size_t)i * (size_t)m;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+        long j = 0;
+        for (; j + 8 <= m; j += 8) {
+            a0 += row[j] * v[j];         a1 += row[j + 1] * v[j + 1]; a2 += row[j + 2] * v[j + 2]; a3 += row[j + 3] * v[j + 3];
+            a4 += row[j + 4] * v[j + 4]; a5 += row[j + 5] * v[j + 5]; a6 += row[j + 6] * v[j + 6]; a7 += row[j + 7] * v[j + 7];
+        }
+        for (; j < m; ++j) a0 += row[j] * v[j];
+        u[i] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    }
+}
+
+/* Switch the prior term of the eta conditional to the reference's own form (logit.py:64-67, 77): u = E (sqrt(tau) eps_2)
+ * with E the n x (n-1) eigenfactor of Q the caller computed (E E' = Q; numpy eigh on the host) and eps_2 the n-1 standard
+ * normals of Philox stream ORC_STREAM_ETA_DENSE.  E is borrowed, not copied.  NULL switches back to the edge form. */
+void orc_set_dense_eigen(orc_sampler *s, const double *E) { s->dense_E = E; }
+
 int orc_update_eta(orc_sampler *s)
 {
     if (s->rdim) return update_eta_rsr(s);
     long n = s->n;
     double *u = (double *)malloc(sizeof(double) * (size_t)n);
-    orc_edge_prior_term(n, s->indptr, s->indices, s->qdata, s->key, s->iter, u);
     double st = sqrt(s->tau);
+    if (s->dense_E) {  /* reference-faithful: y = b + sqrt(omega) eps_1 + E (sqrt(tau) eps_2) */
+        double *v = (double *)malloc(sizeof(double) * (size_t)(n - 1));
+        for (long j = 0; j < n - 1; ++j) v[j] = st * orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_ETA_DENSE);
+        dense_matvec(n, n - 1, s->dense_E, v, u);
+        free(v);
+        st = 1.0;
+    } else {
+        orc_edge_prior_term(n, s->indptr, s->indices, s->qdata, s->key, s->iter, u);
+    }
     for (long i = 0; i < n; ++i) {
         double b = s->k[i] - s->omega_b[i] * xdot(s, i, s->beta);
         double e = orc_block_normal(s->key, (uint32_t)i, 0, s->iter, ORC_STREAM_ETA_SITE);

@@ -35,7 +35,8 @@ enum {
     ORC_STREAM_OMEGA_A = 6,
     ORC_STREAM_ALPHA = 7,
     ORC_STREAM_Z = 8,
-    ORC_STREAM_RSR = 9 /* standard normals of the reduced-rank (RSR) prior term: c0 = basis column */
+    ORC_STREAM_RSR = 9, /* standard normals of the reduced-rank (RSR) prior term: c0 = basis column */
+    ORC_STREAM_ETA_DENSE = 10 /* the n - 1 standard normals of the dense-eigenfactor prior draw: c0 = column */
 };
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -117,5 +118,8 @@ int orc_rsr_theta(long n, int r, const double *K, const double *Qr, const double
 /* switch a sampler to the RSR model: eta becomes K theta, tau's rate 1/2 theta' Qr theta (logit.py:206-209 with
  * fixed.Q = K'QK, logit.py:453-455); state names "theta" (r) and "eta" (= spatial, n). */
 int orc_set_rsr(orc_sampler *s, int r, const double *K, const double *Qr, const double *Er);
+/* reference-faithful prior draw of the eta conditional (logit.py:64-67, 77): dense eigenfactor E (n x (n-1), row-major,
+ * E E' = Q, borrowed); the build's own form is the edge factorisation (orc_edge_prior_term).  Same law either way. */
+void orc_set_dense_eigen(orc_sampler *s, const double *E);
 
 #endif

@@ -76,6 +76,8 @@ def lib():
         L.orc_rsr_theta.restype = C.c_int
         L.orc_set_rsr.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.orc_set_rsr.restype = C.c_int
+        L.orc_set_dense_eigen.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_dense_eigen.restype = None
         L.orc_run.argtypes = [C.c_void_p, C.c_long, C.c_long, _dp, _dp, _dp]
         L.orc_run.restype = C.c_int
         L.orc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
@@ -185,6 +187,13 @@ def edge_prior_term(Q, key, it):
     return u
 
 
+def dense_eigenfactor(Q):
+    """``E = U[:, 1:] sqrt(s[1:])`` from the dense ``eigh`` of ``Q`` exactly as the reference's
+    ``_EtaICARPosterior.__init__`` forms it (logit.py:66-67): O(n^3) time, O(n^2) memory."""
+    s, u = np.linalg.eigh(Q.toarray() if hasattr(Q, 'toarray') else np.asarray(Q))
+    return np.ascontiguousarray(u[:, 1:] * np.sqrt(np.clip(s[1:], 0.0, None)))
+
+
 # ---- whole sampler --------------------------------------------------------------------------------
 class OracleSampler:
     """One chain of the CPU restatement, driven from a ``FlatProblem`` (occuspytial_amd._problem)."""
@@ -205,6 +214,19 @@ class OracleSampler:
         if getattr(self, '_h', None):
             lib().orc_destroy(self._h)
             self._h = None
+
+    def set_dense_eigen(self, E):
+        """Reference-faithful prior draw (logit.py:64-67, 77): ``E`` is the n x (n-1) eigenfactor of Q
+        (:func:`dense_eigenfactor`), shared read-only between samplers; ``None`` returns to the edge form."""
+        if E is None:
+            self._E = None
+            lib().orc_set_dense_eigen(self._h, None)
+            return
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        if E.shape != (self.prob.n, self.prob.n - 1):
+            raise ValueError('E must be n x (n - 1)')
+        self._E = E   # keep it alive: the C side borrows the pointer
+        lib().orc_set_dense_eigen(self._h, E.ctypes.data_as(C.c_void_p))
 
     @staticmethod
     def _check(code):

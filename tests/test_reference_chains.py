@@ -113,3 +113,43 @@ def test_oracle_chains_agree_with_reference_chains(oracle, case):
         A.append(a); B.append(b); T.append(t)
     rep = compare_with_reference(case, np.stack(A), np.stack(B), np.stack(T))
     print(case, {k: tuple(round(x, 2) for x in v) for k, v in rep.items()})
+
+
+def test_oracle_dense_eigenfactor_mode_is_the_references_prior_draw(oracle):
+    """The oracle's ``dense_eigen`` mode -- the prior term exactly as the reference forms it, ``E (sqrt(tau) eps_2)`` with
+    ``E`` from the dense ``eigh`` of Q (logit.py:64-67, 77); it is what bench.py's ``cpu_baseline`` times: (1) the
+    right-hand side it builds equals the numpy expression on the same normals; (2) its chains agree with the
+    reference's chains like the edge-form chains do (same law, N(0, tau Q), by ``E E' = Q = B'B``)."""
+    from occuspytial_amd._problem import FlatProblem, chain_generators, default_start
+    case = 'refchain_queen150_tauprior'
+    Q, W, X, y, hp, ch = problem_of(case)
+    prob = FlatProblem(Q, W, X, y, hp)
+    E = oracle.dense_eigenfactor(prob.Q)
+    assert E.shape == (prob.n, prob.n - 1) and np.abs(E @ E.T - prob.Q.toarray()).max() < 1e-10
+    # (1) one eta update by hand
+    g = chain_generators(7, 1)[0]
+    st = default_start(g, prob)
+    key = int(g.bit_generator.random_raw())
+    orc = oracle.OracleSampler(prob, key)
+    orc.set_dense_eigen(E)
+    orc.set_start(st['alpha'], st['beta'], st['tau'], st['eta'])
+    orc.update('omega_b'); orc.update('tau'); orc.update('eta')
+    L = oracle.lib()
+    n, it = prob.n, int(orc.get('iter'))
+    eps1 = np.array([L.orc_block_normal(key, i, 0, it, 3) for i in range(n)])
+    eps2 = np.array([L.orc_block_normal(key, j, 0, it, 10) for j in range(n - 1)])
+    om, tau = orc.get('omega_b'), orc.get('tau')
+    want = (orc.get('k') - om * (prob.X @ st['beta'])) + np.sqrt(om) * eps1 + E @ (np.sqrt(tau) * eps2)
+    assert np.abs(orc.get('rhs') - want).max() <= 1e-12 * np.abs(want).max()
+    assert abs(orc.get('eta').sum()) < 1e-9
+    # (2) whole chains in dense mode against the reference's
+    size, burnin = int(ch['size']), int(ch['burnin'])
+    A, B, T = [], [], []
+    for g in chain_generators(99, 4):
+        st = default_start(g, prob)
+        orc = oracle.OracleSampler(prob, int(g.bit_generator.random_raw()))
+        orc.set_dense_eigen(E)
+        orc.set_start(st['alpha'], st['beta'], st['tau'], st['eta'])
+        a, b, t = orc.run(size, burnin)
+        A.append(a); B.append(b); T.append(t)
+    compare_with_reference(case, np.stack(A), np.stack(B), np.stack(T))
