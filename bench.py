@@ -240,6 +240,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     in_process = world == 1 and args.gpus > 1   # no launcher: ONE process drives the N GPUs, a host thread each
+    from occuspytial_amd import _lib
+    n_visible = max(1, _lib.load().occ_device_count())   # (counting devices does not initialise the GPU)
+    local_rank %= n_visible   # one rank per GPU on a full node; lets a 2-rank rehearsal share a one-GPU box
     if world > 1:
         args.gpus = world
 
@@ -277,14 +280,14 @@ def main():
             from occuspytial_amd.distributed import distributed_engine
             # (collective: every rank takes part in the broadcast even when it runs no chain of this split)
             keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids] or [1]
-            eng, mine = distributed_engine(problem, comm, keys)
+            eng, mine = distributed_engine(problem, comm, keys, device=local_rank)
             if not chain_ids:
                 eng.close()
                 return None, mine
         elif in_process:
             mine = problem
             keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids]
-            eng = EngineGroup(problem, keys, list(range(args.gpus)))
+            eng = EngineGroup(problem, keys, [g % n_visible for g in range(args.gpus)])
         else:
             mine = problem
             keys = [int(gens[c].bit_generator.random_raw()) for c in chain_ids]
@@ -327,7 +330,7 @@ def main():
         st4 = {c: default_start(gens4[c], host_prob) for c in ids4}
         if in_process:
             keys4 = [int(gens4[c].bit_generator.random_raw()) for c in ids4]
-            eng4, mine4 = EngineGroup(prob, keys4, list(range(min(n_dev, 4)))), prob
+            eng4, mine4 = EngineGroup(prob, keys4, [g % n_visible for g in range(min(n_dev, 4))]), prob
         else:
             eng4, mine4 = make_engine(ids4, gens4, prob)
         if eng4 is not None:

@@ -1215,7 +1215,7 @@ namespace {
         }                                                                                                     \
     } while (0)
 
-thread_local std::string g_comm_error;
+std::string g_comm_error;  // (not thread_local: the Python side may run occ_comm_create on a helper thread and ask from another)
 
 int comm_stage(occ_comm *cm, size_t bytes)
 {

@@ -193,7 +193,7 @@ def broadcast_problem(prob, comm, root=0):
     return prob if comm.rank == root else FlatProblem.from_arrays(arrays)
 
 
-def distributed_engine(prob, comm, keys, root=0):
+def distributed_engine(prob, comm, keys, root=0, device=None):
     """This rank's HIP engine for ``keys``; ``prob`` is needed on ``root`` only.  Returns ``(engine, meta)`` where
     ``meta`` (a :class:`ProblemMeta` everywhere but on the root, which keeps its problem) has what start values need."""
     from ._engine import Engine, ProblemMeta
@@ -203,7 +203,9 @@ def distributed_engine(prob, comm, keys, root=0):
         return Engine.distributed(mine, comm, keys, root), mine
     # no device communicator: every rank builds its own engine from the host arrays
     full = broadcast_problem(prob, comm, root)
-    return Engine(full, keys, device=int(os.environ.get('LOCAL_RANK', '0'))), full
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+    return Engine(full, keys, device=device), full
 
 
 def _hip_engine_factory(prob, keys, device):
