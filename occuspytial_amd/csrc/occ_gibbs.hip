@@ -57,6 +57,8 @@ struct occ_sampler {
     int nbg_any = 0;         // its workgroups per chain
     int tpb_plain = 256;     // threads per block of the launch-per-step path when no fused form applies
     int iter_flags_extra = 0;  // OR-ed into k_iter's flags (2: residency probe)
+    bool beta_split = false;   // beta drawn by k_beta_draw (one wave per chain) in front of k_z_ob: many blocks, launch-per-step path
+    int zob_debug = 0;         // OCC_DEBUG_ZOB_SKIP (timing experiments with occ_profile only): 8 = no z update, 16 = no omega_b draw
     bool device_timeout = false;  // the last error was a device-side wait that gave up (not a HIP API failure)
     // state of every chain at the start of the running occ_run / occ_step (fused engines only): what the call is re-run from
     double *snap_eta = nullptr;
@@ -134,6 +136,22 @@ constexpr int GRAPH_SEQ = 2;  // (16 per graph measured the same: the boundary b
         }                                                                                          \
     } while (0)
 
+// Copies and fills are ordered on the engine's OWN stream, never on the legacy default stream: a default-stream operation
+// synchronises implicitly with every blocking stream of the device (the CU-masked streams are blocking), which
+// invalidates a stream capture that another host thread -- another engine on the same device -- has open at that moment.
+static hipError_t copy_on(occ_sampler *s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (!s->stream) return hipMemcpy(dst, src, bytes, kind);
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(s->stream);
+}
+static hipError_t fill_on(occ_sampler *s, void *dst, int value, size_t bytes)
+{
+    if (!s->stream) return hipMemset(dst, value, bytes);
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, s->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(s->stream);
+}
+
 template <class T>
 int dev_alloc(occ_sampler *s, T **out, size_t count, bool zero = true)
 {
@@ -141,7 +159,7 @@ int dev_alloc(occ_sampler *s, T **out, size_t count, bool zero = true)
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     HIP_TRY(hipMalloc(&p, bytes));
     s->allocs.push_back(p);
-    if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+    if (zero) HIP_TRY(fill_on(s, p, 0, bytes));
     *out = (T *)p;
     return OCC_OK;
 }
@@ -152,7 +170,7 @@ int upload(occ_sampler *s, const T **out, const std::vector<T> &h)
     T *d = nullptr;
     int rc = dev_alloc(s, &d, h.size(), false);
     if (rc) return rc;
-    if (!h.empty() && !s->defer_fixed) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!h.empty() && !s->defer_fixed) HIP_TRY(copy_on(s, d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     if (!h.empty()) s->fixed_list.emplace_back((void *)d, h.size() * sizeof(T));
     *out = d;
     return OCC_OK;
@@ -168,7 +186,7 @@ int fetch(occ_sampler *s, std::vector<T> &h, const T *src, size_t count)
         s->err = "null input pointer";
         return OCC_E_BADARG;
     }
-    HIP_TRY(hipMemcpy(h.data(), src, count * sizeof(T), hipMemcpyDefault));
+    HIP_TRY(copy_on(s, h.data(), src, count * sizeof(T), hipMemcpyDefault));
     return OCC_OK;
 }
 
@@ -268,9 +286,11 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         default:
             if (s->tpb == 64) {  // 64-site slices (fused paths): 256-thread blocks, beta once per block, partial sums still per slice
                 const unsigned nb4 = (unsigned)((c.n + 255) / 256);
-                hipLaunchKernelGGL(pick_z_ob(c.p), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2);
+                hipLaunchKernelGGL(pick_z_ob(c.p), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2 | s->zob_debug);
             } else {
-                hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS, s->launch_sync ? 1 : 0);
+                if (s->beta_split) hipLaunchKernelGGL(OCC_PICK_P(k_beta_draw, c.p), dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS);
+                hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS,
+                                   (s->launch_sync ? 1 : 0) | s->zob_debug | (s->beta_split ? 4 : 0));
             }
             break;
     }
@@ -650,7 +670,7 @@ int residency_probe(occ_sampler *s, bool *ok)
             if (sc.err != 0) *ok = false;
     }
     // the barrier state starts from scratch whatever the probes left behind
-    HIP_TRY(hipMemset(s->ctx.bar, 0, sizeof(unsigned) * (size_t)s->ctx.C * BAR_STRIDE));
+    HIP_TRY(fill_on(s, s->ctx.bar, 0, sizeof(unsigned) * (size_t)s->ctx.C * BAR_STRIDE));
     if ((rc = read_scalars(s, h))) return rc;
     for (auto &sc : h) { sc.bar_base = 0; sc.err = 0; }
     return write_scalars(s, h);
@@ -696,7 +716,7 @@ static int init_occupancy(occ_sampler *s)
     std::vector<uint8_t> z0((size_t)c.C * c.n, 1);
     for (int ch = 0; ch < c.C; ++ch)
         for (int t = 0; t < c.S; ++t) z0[(size_t)ch * c.n + s->site_id[t]] = s->obs_site[t];
-    HIP_TRY(hipMemcpy(c.z, z0.data(), z0.size(), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, c.z, z0.data(), z0.size(), hipMemcpyHostToDevice));
     return OCC_OK;
 }
 
@@ -906,6 +926,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         HIP_TRY(hipEventCreateWithFlags(&s->ev_side[e], hipEventDisableTiming | hipEventReleaseToDevice));
     }
     s->side_enabled = std::getenv("OCC_NO_SIDE_STREAM") == nullptr;
+    if (const char *zd = std::getenv("OCC_DEBUG_ZOB_SKIP")) s->zob_debug = (std::atoi(zd) & 3) << 3;
     s->event_nodes = s->side_enabled && std::getenv("OCC_STREAM_EVENTS") == nullptr;  // diagnostic: fork/join by stream calls
 
     const int n = L.n, S = L.S, R = L.R, p = L.p, q = L.q, C = n_chains;
@@ -1029,6 +1050,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     }
     s->tpb = tpb;
     c.nb_n = (n + tpb - 1) / tpb;
+    s->beta_split = tpb != 64 && c.nb_n >= 128 && !std::getenv("OCC_NO_BETA_SPLIT");
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
 
     // ---- device memory ------------------------------------------------------------------------------
@@ -1085,7 +1107,8 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
         s->iter.clock = c.iter_clock;
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
-        if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 2 * c.nb_n * 4))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 3 * c.nb_n * 4))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.rec, (size_t)C * 3 * XL_MAX_WG * 4))) return rc;
         s->iter.bar = c.bar;
     }
 
@@ -1094,7 +1117,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     std::vector<ChainScalars> sc((size_t)C);
     std::memset(sc.data(), 0, sizeof(ChainScalars) * sc.size());
     for (int ch = 0; ch < C; ++ch) sc[ch].key = keys[ch];
-    HIP_TRY(hipMemcpy(c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, c.sc, sc.data(), sizeof(ChainScalars) * sc.size(), hipMemcpyHostToDevice));
     {
         KryArgs &k = s->kry;
         k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.maxiter = c.maxiter;
@@ -1179,7 +1202,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
     }
-    HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
     return OCC_OK;
 }
@@ -1299,9 +1322,9 @@ int refresh_host_mirrors(occ_sampler *s)
     const Ctx &c = s->ctx;
     std::vector<int> sidx((size_t)c.n), sp((size_t)c.S + 1);
     s->obs_site.assign((size_t)c.S, 0);
-    HIP_TRY(hipMemcpy(sidx.data(), c.site_sidx, sizeof(int) * sidx.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sp.data(), c.site_ptr, sizeof(int) * sp.size(), hipMemcpyDeviceToHost));
-    if (c.S > 0) HIP_TRY(hipMemcpy(s->obs_site.data(), c.obs_site, (size_t)c.S, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(s, sidx.data(), c.site_sidx, sizeof(int) * sidx.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(s, sp.data(), c.site_ptr, sizeof(int) * sp.size(), hipMemcpyDeviceToHost));
+    if (c.S > 0) HIP_TRY(copy_on(s, s->obs_site.data(), c.obs_site, (size_t)c.S, hipMemcpyDeviceToHost));
     s->site_id.assign((size_t)c.S, 0);
     for (int i = 0; i < c.n; ++i)
         if (sidx[i] >= 0 && sidx[i] < c.S) s->site_id[sidx[i]] = i;
@@ -1542,8 +1565,8 @@ static int set_theta(occ_sampler *s, int chain, const double *theta_in)
         for (int a = 0; a < m; ++a) t = std::fma(s->rsr_K_host[(size_t)i * m + a], th[a], t);
         eta[i] = t;
     }
-    HIP_TRY(hipMemcpy(s->rsr.theta + (size_t)chain * m, th.data(), sizeof(double) * m, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->ctx.eta + (size_t)chain * n, eta.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, s->rsr.theta + (size_t)chain * m, th.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, s->ctx.eta + (size_t)chain * n, eta.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     return OCC_OK;
 }
 
@@ -1572,9 +1595,9 @@ int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const doub
     if (s->rsr.m > 0) {  // `eta` holds theta; the spatial effects follow (logit.py:457-460)
         if ((rc = set_theta(s, chain, eta))) return rc;
     } else {
-        HIP_TRY(hipMemcpy(c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
+        HIP_TRY(copy_on(s, c.eta + (size_t)chain * c.n, eta, sizeof(double) * c.n, hipMemcpyDefault));
     }
-    HIP_TRY(hipMemset(c.Xv + (size_t)chain * c.n, 0, sizeof(double2) * c.n));  // x0 = None (logit.py:71)
+    HIP_TRY(fill_on(s, c.Xv + (size_t)chain * c.n, 0, sizeof(double2) * c.n));  // x0 = None (logit.py:71)
     s->need_prologue = true;
     return OCC_OK;
 }
@@ -1620,7 +1643,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     }
     if (c.rec != s->rec_buf) {
         c.rec = s->rec_buf;
-        HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     }
     int rc = set_window(s, n_iter, burnin, keep);
     if (rc) return rc;
@@ -1727,7 +1750,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     s->krylov_last = h[0].minres_itn_last;
 
     std::vector<double> host((size_t)C * keep * rw);
-    HIP_TRY(hipMemcpy(host.data(), s->rec_buf, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(s, host.data(), s->rec_buf, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
     for (int ch = 0; ch < C; ++ch)
         for (int64_t t = 0; t < keep; ++t) {
             const double *row = host.data() + ((size_t)ch * keep + t) * rw;
@@ -1785,10 +1808,10 @@ static int fallback_to_launch_per_step(occ_sampler *s)
     s->flag_sync = false;
     c.sync = nullptr;
     s->iter.sync = nullptr;
-    HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c.eta, s->snap_eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(c.z, s->snap_z, Cn, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(c.Xv, s->snap_x, sizeof(double2) * Cn, hipMemcpyDeviceToDevice));
+    HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, c.eta, s->snap_eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice));
+    HIP_TRY(copy_on(s, c.z, s->snap_z, Cn, hipMemcpyDeviceToDevice));
+    HIP_TRY(copy_on(s, c.Xv, s->snap_x, sizeof(double2) * Cn, hipMemcpyDeviceToDevice));
     for (auto &sc : s->snap_sc) sc.err = 0;
     if ((rc = write_scalars(s, s->snap_sc))) return rc;
     s->parity = s->snap_parity;
@@ -1844,7 +1867,7 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     std::vector<double> v;
     auto pull = [&](const double *src, size_t count) -> int {
         v.resize(count);
-        if (count) HIP_TRY(hipMemcpy(v.data(), src, sizeof(double) * count, hipMemcpyDeviceToHost));
+        if (count) HIP_TRY(copy_on(s, v.data(), src, sizeof(double) * count, hipMemcpyDeviceToHost));
         return OCC_OK;
     };
     int rc = OCC_OK;
@@ -1858,7 +1881,7 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     else if (nm == "rhs") rc = pull(c.rhs + chain * n, n);
     else if (nm == "z" || nm == "k" || nm == "exists") {
         std::vector<uint8_t> z(n);
-        HIP_TRY(hipMemcpy(z.data(), c.z + chain * n, n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, z.data(), c.z + chain * n, n, hipMemcpyDeviceToHost));
         if (nm == "exists") {
             v.resize((size_t)c.S);
             for (int t = 0; t < c.S; ++t) v[t] = (s->obs_site[t] || z[s->site_id[t]]) ? 1.0 : 0.0;
@@ -1868,7 +1891,7 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
         }
     } else if (nm == "xz") {
         std::vector<double2> x(n);
-        HIP_TRY(hipMemcpy(x.data(), c.Xv + chain * n, sizeof(double2) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, x.data(), c.Xv + chain * n, sizeof(double2) * n, hipMemcpyDeviceToHost));
         v.resize(2 * n);
         for (size_t i = 0; i < n; ++i) { v[i] = x[i].x; v[n + i] = x[i].y; }
     } else if (nm == "alpha") v.assign(sc.alpha, sc.alpha + c.q);
@@ -1878,11 +1901,11 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     else if (nm == "iter") v.assign(1, (double)it);
     else if (nm == "rsr_gram" && s->rsr.m > 0) {  // K' diag(omega_b) K of the last theta update (upper tiles; tests)
         v.resize((size_t)s->rsr.m * s->rsr.m);
-        HIP_TRY(hipMemcpy(v.data(), s->rsr.gram + (size_t)chain * v.size(), sizeof(double) * v.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, v.data(), s->rsr.gram + (size_t)chain * v.size(), sizeof(double) * v.size(), hipMemcpyDeviceToHost));
     }
     else if (nm == "theta" && s->rsr.m > 0) {
         v.resize((size_t)s->rsr.m);
-        HIP_TRY(hipMemcpy(v.data(), s->rsr.theta + (size_t)chain * s->rsr.m, sizeof(double) * v.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, v.data(), s->rsr.theta + (size_t)chain * s->rsr.m, sizeof(double) * v.size(), hipMemcpyDeviceToHost));
     }
     else return set_error(s, OCC_E_STATE, "unknown state name");
     if (rc) return rc;
@@ -1906,15 +1929,15 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
     auto need = [&](size_t want) { return (size_t)len == want; };
     if (nm == "eta") {
         if (!need(n)) return set_error(s, OCC_E_STATE, "wrong length");
-        HIP_TRY(hipMemcpy(c.eta + chain * n, in, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, c.eta + chain * n, in, sizeof(double) * n, hipMemcpyHostToDevice));
     } else if (nm == "omega_a") {
         if (!need(R)) return set_error(s, OCC_E_STATE, "wrong length");
-        HIP_TRY(hipMemcpy(c.omega_a + chain * R, in, sizeof(double) * R, hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, c.omega_a + chain * R, in, sizeof(double) * R, hipMemcpyHostToDevice));
     } else if (nm == "z") {
         if (!need(n)) return set_error(s, OCC_E_STATE, "wrong length");
         std::vector<uint8_t> z(n);
         for (size_t i = 0; i < n; ++i) z[i] = in[i] != 0.0;
-        HIP_TRY(hipMemcpy(c.z + chain * n, z.data(), n, hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, c.z + chain * n, z.data(), n, hipMemcpyHostToDevice));
     } else if (nm == "theta" && s->rsr.m > 0) {
         if (!need((size_t)s->rsr.m)) return set_error(s, OCC_E_STATE, "wrong length");
         int rc = set_theta(s, chain, in);
@@ -1923,7 +1946,7 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
         if (!need(2 * n)) return set_error(s, OCC_E_STATE, "wrong length");
         std::vector<double2> x(n);
         for (size_t i = 0; i < n; ++i) x[i] = make_double2(in[i], in[n + i]);
-        HIP_TRY(hipMemcpy(c.Xv + chain * n, x.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, c.Xv + chain * n, x.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
     } else {
         std::vector<ChainScalars> h;
         int rc = read_scalars(s, h);
@@ -1975,7 +1998,7 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->iter_kernel_mean_us = 0.0;
     if (s->ctx.iter_clock) {
         unsigned long long clk[4];
-        HIP_TRY(hipMemcpy(clk, s->ctx.iter_clock, sizeof(clk), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, clk, s->ctx.iter_clock, sizeof(clk), hipMemcpyDeviceToHost));
         int khz = 0;
         HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device));
         out->iter_kernel_launches = (int64_t)clk[3];
@@ -2139,7 +2162,7 @@ int cond_begin(occ_sampler *s, int chain, const Inject &inj, uint32_t *it_out)
         if ((rc = dev_alloc(s, &s->inj_dev, 1))) return rc;
         if ((rc = dev_alloc(s, &s->inj_u, (size_t)c.n))) return rc;
         c.inj = s->inj_dev;
-        HIP_TRY(hipMemcpy(s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     }
     std::vector<ChainScalars> h;
     if ((rc = read_scalars(s, h))) return rc;  // (synchronises both streams)
@@ -2153,7 +2176,7 @@ int cond_begin(occ_sampler *s, int chain, const Inject &inj, uint32_t *it_out)
     if ((rc = write_scalars(s, h))) return rc;
     Inject hinj = inj;
     hinj.z_u = s->inj_u;
-    HIP_TRY(hipMemcpy(s->inj_dev, &hinj, sizeof(Inject), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(s, s->inj_dev, &hinj, sizeof(Inject), hipMemcpyHostToDevice));
     s->need_prologue = true;  // whatever follows, omega_b of the coming iteration must be redrawn from the state
     return OCC_OK;
 }
@@ -2174,12 +2197,12 @@ int cond_end(occ_sampler *s, int chain, ChainScalars *out)
 int copy_in(occ_sampler *s, double *dst, const double *src, size_t count)
 {
     if (!src) return set_error(s, OCC_E_BADARG, "null input pointer");
-    HIP_TRY(hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDefault));
+    HIP_TRY(copy_on(s, dst, src, sizeof(double) * count, hipMemcpyDefault));
     return OCC_OK;
 }
 int copy_out(occ_sampler *s, double *dst, const double *src, size_t count)
 {
-    if (dst) HIP_TRY(hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost));
+    if (dst) HIP_TRY(copy_on(s, dst, src, sizeof(double) * count, hipMemcpyDeviceToHost));
     return OCC_OK;
 }
 
@@ -2239,7 +2262,7 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
     if ((rc = copy_out(s, eta_out, c.eta + co, n))) return rc;
     if (xz_out) {
         std::vector<double2> x(n);
-        HIP_TRY(hipMemcpy(x.data(), c.Xv + co, sizeof(double2) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, x.data(), c.Xv + co, sizeof(double2) * n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) { xz_out[i] = x[i].x; xz_out[n + i] = x[i].y; }
     }
     if (itn_out) *itn_out = sc.minres_itn_last;
@@ -2251,7 +2274,7 @@ int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const do
     if (!s || !eps) return OCC_E_BADARG;
     Inject inj{};
     inj.do_beta = 1;
-    HIP_TRY(hipMemcpy(inj.beta_eps, eps, sizeof(double) * s->ctx.p, hipMemcpyDefault));
+    HIP_TRY(copy_on(s, inj.beta_eps, eps, sizeof(double) * s->ctx.p, hipMemcpyDefault));
     uint32_t it;
     int rc = cond_begin(s, chain, inj, &it);
     if (rc) return rc;
@@ -2272,7 +2295,7 @@ int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const d
 {
     if (!s || !eps) return OCC_E_BADARG;
     Inject inj{};
-    HIP_TRY(hipMemcpy(inj.alpha_eps, eps, sizeof(double) * s->ctx.q, hipMemcpyDefault));
+    HIP_TRY(copy_on(s, inj.alpha_eps, eps, sizeof(double) * s->ctx.q, hipMemcpyDefault));
     uint32_t it;
     int rc = cond_begin(s, chain, inj, &it);
     if (rc) return rc;
@@ -2306,7 +2329,7 @@ int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out)
     if ((rc = cond_end(s, chain, nullptr))) return rc;
     if (z_out) {
         std::vector<uint8_t> z(n);
-        HIP_TRY(hipMemcpy(z.data(), c.z + (size_t)chain * n, n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(s, z.data(), c.z + (size_t)chain * n, n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) z_out[i] = (double)z[i];
     }
     return OCC_OK;

@@ -47,6 +47,7 @@ constexpr int ITER_WG_XL = 512;                 // ... one XCD per chain: two wa
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
 constexpr unsigned ITER_PROBE_SPIN_LIMIT = 1u << 14;  // ... in the residency probe at creation (flags bit 1 of k_iter)
 constexpr int BAR_STRIDE = 64;                  // unsigned words per chain in IterArgs::bar: the counter, or one flag per workgroup
+constexpr int XL_MAX_WG = 64;                   // workgroups per chain of an XCD-local launch (one flag / record per lane of the polling wave)
 constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch = XCDs the grid's x dimension walks over
 
 // Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
@@ -76,7 +77,8 @@ struct IterArgs {
     unsigned *bar;        // [C][BAR_STRIDE]
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
-    double *part;         // [C][2][nb_n][4] partial sums of the running solve, by step parity
+    double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
+    double *rec;          // [C][3][XL_MAX_WG][4] per-workgroup records of the XL step exchange
     int nbg;              // workgroups per chain
     int C, p, q;
 };
@@ -102,6 +104,27 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
 {
     return unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
+
+// XL step exchange: a workgroup's record of a step IS its arrival flag.  The four sums of a step are combined in a fixed
+// TREE over groups of eight 64-site slices -- ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), then the groups in the order of
+// wave_sum4 -- the order every path uses (sum8_tree below: k_minres at 64 threads per block, the any-placement form), so
+// all of them return the same bits.  A 512-thread workgroup owns one group, a 256-thread one half a group: its waves
+// leave their wave sums in LDS, and after the workgroup barrier that follows every wave's `s_waitcnt vmcnt(0)` (its g
+// is in the XCD's L2) the first wave adds them and stores ONE record {S0, S1 | S2, S3} of two 16-byte halves.  A half that
+// still holds the CANARY (a NaN no sum can produce) has not arrived.  Records rotate through three buffers: in step k
+// the first wave puts canaries into its record of step k + 1 before that wait, so whoever sees a workgroup's record of
+// step k also sees its g and its canaries of step k + 1 -- no ordering assumption between different cache lines.  The
+// buffer of step k + 1 was last read in step k - 2: a workgroup is in step k only after every workgroup has stored
+// its record of step k - 1, which each did after it had read all of step k - 2.  The poller (the first wave) reads
+// the records of all workgroups of the chain, one or two per lane, until none shows the canary: ONE round trip where
+// "poll the flags, then load 157 per-slice sums" took two.
+// 16-byte stores and loads are not torn (MI355X_MICROARCH.md, observed on gfx950); each half is checked on its own.
+__device__ __forceinline__ double2 rec_canary()
+{
+    const double c = __longlong_as_double(0x7ff8dead0ccbeef0LL);
+    return make_double2(c, c);
+}
+__device__ __forceinline__ bool rec_pending(double2 half) { return __double_as_longlong(half.x) == 0x7ff8dead0ccbeef0LL; }
 
 // Barrier among the workgroups of one chain, in two halves so that work which needs nothing from the other
 // workgroups can run between them.  ARRIVE: every storing wave drains its write-through stores, then one lane
@@ -250,6 +273,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     __shared__ int s_flag, s_noise_ok;
     __shared__ double s_bcast[12];  // W512: tau, then the coefficients of the coming step, from wave 0 to the workgroup
     __shared__ Slot s_slot;         // W512: the MINRES scalar state (wave 0)
+    __shared__ double s_wsum[8][4]; // XL: the wave sums of a step, combined by the first wave
     const KryArgs &a = ia.a;
     // grid = (nbg, C), the chain is blockIdx.y; XL: grid = (8, nbg), the chain is blockIdx.x (a scalar register
     // either way: the buffer descriptors below must be provably wave-uniform, or every buffer access becomes a
@@ -293,10 +317,21 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const __amdgpu_buffer_rsrc_t gbuf[2] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[0] + co), 0, n * 16, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[1] + co), 0, n * 16, 0x00020000)};
-    double *part_base = ia.part + (size_t)chain * 2 * a.nb_n * 4;
-    const __amdgpu_buffer_rsrc_t pbuf[2] = {
+    // per-slice records of the running solve {S0, S1 | S2, S3}: two buffers by step parity (any placement), three in
+    // rotation when the records double as arrival flags (XL, see "step exchange" below)
+    double *part_base = ia.part + (size_t)chain * 3 * a.nb_n * 4;
+    const __amdgpu_buffer_rsrc_t pbuf[3] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000)};
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 8), 0, a.nb_n * 32, 0x00020000)};
+    // XL: one record per WORKGROUP, three buffers in rotation, in the flag block's line-aligned tail (BAR_STRIDE words
+    // of flags, then 3 x XL_MAX_WG x 32 bytes)
+    double *rec_base = ia.rec + (size_t)chain * 3 * XL_MAX_WG * 4;
+    const __amdgpu_buffer_rsrc_t rbuf[3] = {
+        __builtin_amdgcn_make_buffer_rsrc((void *)rec_base, 0, ia.nbg * 32, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(rec_base + (size_t)XL_MAX_WG * 4), 0, ia.nbg * 32, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(rec_base + (size_t)XL_MAX_WG * 8), 0, ia.nbg * 32, 0x00020000)};
+    (void)rbuf;
     if (probe) {  // residency / placement probe: one barrier, nothing else
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -304,35 +339,21 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         return;
     }
 
-    // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
+    // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads).
+    // Order: the partial sums of eta'Q eta are requested first, then EVERY load of the phase that does not need tau
+    // (the site's data, its matrix row, the warm start at the site and at its neighbours), and only then the lead wave
+    // draws tau -- a gamma variate, some 4 000 cycles of dependent f64 arithmetic -- while those loads are in flight.
     PHASE_STAMP(0, 0)
-    double tau = 0.0;
-    if (lead) {
-        double q = 0.0;
+    double qv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lead) {  // (one round of four loads per lane covers 256 slices; more slices: the loop below the loads)
         const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
-        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
-            double v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bb = b0 + 64 * r;
-                const double t = pq[min(bb, a.nb_n - 1)];
-                v[r] = (bb < a.nb_n) ? t : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q += v[r];
+        for (int r = 0; r < 4; ++r) {
+            const int bb = lane + 64 * r;
+            const double t = pq[min(bb, a.nb_n - 1)];
+            qv[r] = (bb < a.nb_n) ? t : 0.0;
         }
-        q = wave_sum(q);
-        const double rate = 0.5 * q + ia.tau_rate;
-        Cursor gcur(sc.key, 0u, it, STREAM_TAU);
-        tau = (1.0 / rate) * std_gamma(gcur, ia.tau_shape);  // every lane draws the same tau (uniform control flow)
-        if (writer) sc.tau = tau;
-        if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
     }
-    if (SHARE) {
-        __syncthreads();
-        tau = s_bcast[0];
-    }
-    PHASE_STAMP(0, 1)
     // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
     // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
     // the site itself with coefficient 0; lanes past the last site read row n-1 and their buffer accesses fall
@@ -353,9 +374,59 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const double om = a.omega_b[it & 1][ci];
     const double zval = (double)ia.z[ci];
     const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
+    double2 x = X0[ic];
+    const double qd = a.qdiag[ic];
+    double vraw[NW];
+    int jraw[NW];
+#pragma unroll
+    for (int kk = 0; kk < NW; ++kk) {
+        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+        jraw[kk] = a.sell_col[slot];
+        vraw[kk] = a.sell_val[slot];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here: the scheduler must not sink them below the draw
+    if (synced) __syncthreads();  // thread 0's wait for the side stream's noise kernel is over: s_noise_ok is set
+    double tau = 0.0;
+    if (lead) {
+        double q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q += qv[r];
+        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
+        for (int b0 = lane + 256; b0 < a.nb_n; b0 += 256) {  // (more than 256 slices: same order as a plain loop)
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bb = b0 + 64 * r;
+                const double t = pq[min(bb, a.nb_n - 1)];
+                v[r] = (bb < a.nb_n) ? t : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += v[r];
+        }
+        q = wave_sum(q);
+        const double rate = 0.5 * q + ia.tau_rate;
+        // the standard gamma variate was drawn one iteration ahead by k_noise (side stream), like the rest of the noise
+        // (synced: the wait for that kernel was started at kernel entry and has been looked at before this point)
+        double gvar;
+        if (synced) {
+            if (threadIdx.x == 0 && !s_noise_ok) sc.err = -2;
+            gvar = load_agent(&sc.tau_gamma[it & 1]);
+        } else {
+            gvar = sc.tau_gamma[it & 1];
+        }
+        tau = (1.0 / rate) * gvar;
+        if (writer) sc.tau = tau;
+        if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
+    }
+    if (SHARE) {
+        __syncthreads();
+        tau = s_bcast[0];
+    }
+    PHASE_STAMP(0, 1)
+    // second round of loads, one latency: the noise (it comes from the side stream: the wait for it was started at
+    // kernel entry) and the warm start at the neighbours (their columns arrived during the draw)
     double en, up;
     if (synced) {
-        __syncthreads();
         if (!s_noise_ok && writer) sc.err = -2;
         en = load_agent(&ia.enorm[it & 1][ci]);
         up = load_agent(&ia.uprior[it & 1][ci]);
@@ -363,22 +434,18 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         en = ia.enorm[it & 1][ci];
         up = ia.uprior[it & 1][ci];
     }
-    const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
-    double2 x = X0[ic];
-    const double d = tau * a.qdiag[ic] + om;
     double2 xn[NW];
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) {
         const bool has = act && kk < width;
-        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-        const int jraw = a.sell_col[slot];
-        const double vraw = a.sell_val[slot];
-        const int j = has ? jraw : ic;
+        const int j = has ? jraw[kk] : ic;
         off[kk] = has ? j * 16 : myoff;
-        av[kk] = has ? tau * vraw : 0.0;
+        av[kk] = has ? tau * vraw[kk] : 0.0;
         xn[kk] = X0[j];
         nm1[kk] = zero2; nm2[kk] = zero2;
     }
+    const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
+    const double d = tau * qd + om;
     double ax = d * x.x, az = d * x.y;
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) {
@@ -388,6 +455,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const double2 p0 = make_double2(y - ax, 1.0 - az);
     if (act) ia.rhs[ci] = y;
     store_x<XL>(gbuf[0], myoff, p0);
+    if (XL && threadIdx.x < 2) store_x<1>(rbuf[1], wg * 32 + (int)threadIdx.x * 16, rec_canary());  // step 1 polls these records
     PHASE_STAMP(0, 2)
     ++nbar;
     OCC_CHAIN_BARRIER(s_flag);
@@ -473,59 +541,119 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             store_x<XL>(gbuf[k & 1], myoff, g);
         }
         if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
+        if (XL) {
+            // ---- records as arrival flags (see "XL step exchange" above)
+            constexpr int WPG = WGT / 64;  // waves (slices) per workgroup: 8, or 4 (two workgroups per group of eight slices)
+            const int rb = k % 3, rn = (k + 1) % 3, wave = (int)threadIdx.x >> 6;
+            if (threadIdx.x < 2) store_x<1>(rbuf[rn], wg * 32 + (int)threadIdx.x * 16, rec_canary());
+            wave_sum4(part);  // (a slice past the last site sums zeros)
+            if (lane == 0) { s_wsum[wave][0] = part[0]; s_wsum[wave][1] = part[1]; s_wsum[wave][2] = part[2]; s_wsum[wave][3] = part[3]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g (and the canaries) are in the XCD's L2
+            SOLVE_STAMP(2)
+            __syncthreads();
+            SOLVE_STAMP(3)
+            if (threadIdx.x < 2) {  // lane 0: {S0, S1}, lane 1: {S2, S3} of this workgroup's slices, in tree order
+                const int q0 = (int)threadIdx.x * 2;
+                double2 r;
+                if (WPG == 8) {
+                    r.x = ((s_wsum[0][q0] + s_wsum[1][q0]) + (s_wsum[2][q0] + s_wsum[3][q0])) + ((s_wsum[4][q0] + s_wsum[5][q0]) + (s_wsum[6][q0] + s_wsum[7][q0]));
+                    r.y = ((s_wsum[0][q0 + 1] + s_wsum[1][q0 + 1]) + (s_wsum[2][q0 + 1] + s_wsum[3][q0 + 1])) +
+                          ((s_wsum[4][q0 + 1] + s_wsum[5][q0 + 1]) + (s_wsum[6][q0 + 1] + s_wsum[7][q0 + 1]));
+                } else {
+                    r.x = (s_wsum[0][q0] + s_wsum[1][q0]) + (s_wsum[2][q0] + s_wsum[3][q0]);
+                    r.y = (s_wsum[0][q0 + 1] + s_wsum[1][q0 + 1]) + (s_wsum[2][q0 + 1] + s_wsum[3][q0 + 1]);
+                }
+                store_x<1>(rbuf[rb], wg * 32 + (int)threadIdx.x * 16, r);
+            }
+            SOLVE_STAMP(4)
+            if (lead) pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
+            SOLVE_STAMP(9)
+            SOLVE_STAMP(5)
+            if (threadIdx.x < 64) {  // the first wave polls the records of the chain's workgroups (at most 64)
+                constexpr int RPG = 8 / WPG;  // records per group of eight slices: lane l reads group l
+                int fail_ = 0;
+                unsigned spins_ = 0;
+                double2 lo[RPG], hi[RPG];
+                for (;;) {
+#pragma unroll
+                    for (int r = 0; r < RPG; ++r) {  // (records past the last workgroup fall outside the descriptor: zeros)
+                        lo[r] = load_sc1(rbuf[rb], (lane * RPG + r) * 32);
+                        hi[r] = load_sc1(rbuf[rb], (lane * RPG + r) * 32 + 16);
+                    }
+                    bool pend = false;
+#pragma unroll
+                    for (int r = 0; r < RPG; ++r) pend = pend || rec_pending(lo[r]) || rec_pending(hi[r]);
+                    if (!__any(pend)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins_ > spin_limit) { fail_ = 1; break; }
+                    if ((spins_ & 1023u) == 0u && chain_err(sc) != 0) { fail_ = 1; break; }
+                }
+                SOLVE_STAMP(6)
+                if (!fail_) {
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+                }
+                SOLVE_STAMP(7)
+                double acc[4];
+                if (RPG == 2) { acc[0] = 0.0 + (lo[0].x + lo[1].x); acc[1] = 0.0 + (lo[0].y + lo[1].y); acc[2] = 0.0 + (hi[0].x + hi[1].x); acc[3] = 0.0 + (hi[0].y + hi[1].y); }
+                else { acc[0] = 0.0 + lo[0].x; acc[1] = 0.0 + lo[0].y; acc[2] = 0.0 + hi[0].x; acc[3] = 0.0 + hi[0].y; }  // (0.0 + x: the other paths start their lane sums from +0)
+                wave_sum4(acc);
+                S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
+                if (threadIdx.x == 0) {
+                    s_flag = fail_;
+                    if (fail_) chain_fail(sc);
+                    if (!SHARE) { s_bcast[0] = S0; s_bcast[1] = S1; s_bcast[2] = S2; s_bcast[3] = xn2; }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the poll
+            if (s_flag) { failed = true; break; }
+            if (threadIdx.x >= 64) {
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+                if (!SHARE) { S0 = s_bcast[0]; S1 = s_bcast[1]; S2 = s_bcast[2]; xn2 = s_bcast[3]; }
+            }
+            SOLVE_STAMP(8)
+        } else {
         if (slice_act) {  // per-slice sums: the granularity (and order) of k_minres at 64 threads per block
             wave_sum4(part);
             if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(part[0], part[1]));
             if (lane == 1) store_x<XL>(pbuf[k & 1], slice * 32 + 16, make_double2(part[2], part[3]));
         }
         SOLVE_STAMP(2)
-#ifdef OCC_SOLVE_STAMPS
-        if (chain == 0 && k == 6 && threadIdx.x == 0 && wg < 40) g_solve_stamps[480 + wg] = __builtin_readcyclecounter();
-#endif
         ++nbar;
         OCC_CHAIN_ARRIVE();
         if (lead) pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
         SOLVE_STAMP(9)
         OCC_CHAIN_WAIT(s_flag);
         SOLVE_STAMP(6)
-#ifdef OCC_SOLVE_STAMPS
-        if (chain == 0 && k == 6 && threadIdx.x == 0 && wg < 40) g_solve_stamps[520 + wg] = __builtin_readcyclecounter();
-#endif
         if (s_flag) { failed = true; break; }
         // ---- everything below reads what other workgroups published in this step: sc1 loads only
         // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the
         // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
-        // W512: the lead wave's sums are the critical path (the coefficients of the next step hang on them), its
-        // gathers are not: sums' loads first there; the other forms keep the gathers in front (every wave sums)
-        if (!SHARE) {
 #pragma unroll
-            for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-        }
-        if (lead) {
+        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+        {  // lane l sums group l of eight slices in tree order (sum8_tree), then the groups as wave_sum4 does
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
-                double2 lo[4], hi[4];
+            const int ngroups = (a.nb_n + 7) >> 3;
+            for (int g0 = lane; g0 < ngroups; g0 += 64) {
+                double2 lo[8], hi[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    lo[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
-                    hi[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32 + 16);
+                for (int j = 0; j < 8; ++j) {  // (slices past the last one fall outside the descriptor: zeros)
+                    lo[j] = load_sc1(pbuf[k & 1], (g0 * 8 + j) * 32);
+                    hi[j] = load_sc1(pbuf[k & 1], (g0 * 8 + j) * 32 + 16);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { acc[0] += lo[r].x; acc[1] += lo[r].y; acc[2] += hi[r].x; acc[3] += hi[r].y; }
-            }
-            if (SHARE) {
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+                acc[0] += ((lo[0].x + lo[1].x) + (lo[2].x + lo[3].x)) + ((lo[4].x + lo[5].x) + (lo[6].x + lo[7].x));
+                acc[1] += ((lo[0].y + lo[1].y) + (lo[2].y + lo[3].y)) + ((lo[4].y + lo[5].y) + (lo[6].y + lo[7].y));
+                acc[2] += ((hi[0].x + hi[1].x) + (hi[2].x + hi[3].x)) + ((hi[4].x + hi[5].x) + (hi[6].x + hi[7].x));
+                acc[3] += ((hi[0].y + hi[1].y) + (hi[2].y + hi[3].y)) + ((hi[4].y + hi[5].y) + (hi[6].y + hi[7].y));
             }
             SOLVE_STAMP(7)
             wave_sum4(acc);
             S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
         }
-        if (SHARE && !lead) {
-#pragma unroll
-            for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-        }
         SOLVE_STAMP(8)
+        }
 #undef NEXT_STAMP
 #define NEXT_STAMP(pt) SOLVE_STAMP(pt)
         OCC_NEXT_STEP(k + 1);
@@ -544,7 +672,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     if (!failed) {
         if (slice_act) {
             const double t0 = wave_sum(act ? x.x : 0.0), t1 = wave_sum(act ? x.y : 0.0);
-            if (lane == 0) store_x<XL>(pbuf[k & 1], slice * 32, make_double2(t0, t1));
+            if (lane == 0) store_x<XL>(pbuf[XL ? k % 3 : (k & 1)], slice * 32, make_double2(t0, t1));
         }
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -556,7 +684,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
                 double2 v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[k & 1], (b0 + 64 * r) * 32);
+                for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[XL ? k % 3 : (k & 1)], (b0 + 64 * r) * 32);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sx += v[r].x; sz += v[r].y; }
             }

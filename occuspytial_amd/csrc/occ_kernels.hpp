@@ -98,6 +98,8 @@ struct Ctl {
 struct ChainScalars {
     double alpha[MAXC], beta[MAXC];
     double tau;
+    double tau_gamma[2];       // the standard gamma variate of tau's draw of iteration t in [t & 1] (logit.py:209): it depends on
+                               // nothing but (key, t), so k_noise draws it one iteration ahead, off the critical path
     uint64_t key;
     Ctl ctl[2], mid[2];
     uint32_t it_stop, it_base, burnin, keep;
@@ -654,9 +656,14 @@ __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on
     }
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    const uint32_t it_for = ctl.it + (uint32_t)ahead;
+    if (blk == 0 && threadIdx.x == 0) {  // tau's standard gamma variate of that iteration (the rate comes later)
+        Cursor g(sc.key, 0u, it_for, STREAM_TAU);
+        scs[chain].tau_gamma[it_for & 1] = std_gamma(g, c.tau_shape);
+    }
     const int i = blk * blockDim.x + threadIdx.x;
     if (i >= c.n) return;
-    noise_site(c, sc.key, chain, i, ctl.it + (uint32_t)ahead);
+    noise_site(c, sc.key, chain, i, it_for);
 }
 
 template <int INJ>
@@ -679,8 +686,7 @@ __global__ void __launch_bounds__(256) k_eta_init(OCC_KARGS)
     if (INJ) {  // the caller's gamma variate (rng.gamma(shape, 1 / rate) = standard_gamma(shape) * (1 / rate)), or the chain's tau as it is
         tau = c.inj->tau_from_gamma ? (1.0 / rate) * c.inj->gamma : sc.tau;
     } else {
-        Cursor g(sc.key, 0u, it, STREAM_TAU);
-        tau = (1.0 / rate) * std_gamma(g, c.tau_shape);
+        tau = (1.0 / rate) * sc.tau_gamma[it & 1];  // the variate k_noise drew for this iteration
     }
     if (blk == 0 && threadIdx.x == 0) {
         sc.tau = tau;
@@ -995,6 +1001,27 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     if (blockDim.x == 64 || threadIdx.x < 64) {
         const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nb_n);
         const int ln = threadIdx.x & 63;
+        if (blockDim.x == 64) {
+            // 64-site slices (the sizes the fused kernel also runs): the order of occ_iter.hpp's step exchange -- lane l
+            // sums group l of eight slices as ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), then the groups as wave_sum does --
+            // so that every path returns the same bits
+            const int ngroups = (a.nb_n + 7) >> 3;
+            for (int g0 = ln; g0 < ngroups; g0 += 64) {
+                double v[4][8];
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int b = g0 * 8 + j;
+                        const double t = part[qi * a.nb_n + min(b, a.nb_n - 1)];
+                        v[qi][j] = (b < a.nb_n) ? t : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi)
+                    S[qi] += ((v[qi][0] + v[qi][1]) + (v[qi][2] + v[qi][3])) + ((v[qi][4] + v[qi][5]) + (v[qi][6] + v[qi][7]));
+            }
+        } else
         // four rounds of loads in flight (a plain "load, add" loop waits for every round trip in turn: 15 of them at
         // 500x500); the sums are accumulated in the same order, rounds past the end add an exact 0
         for (int b0 = ln; b0 < a.nb_n; b0 += 256) {
@@ -1405,7 +1432,8 @@ __device__ __forceinline__ void record_draws(const Ctx &c, const ChainScalars &s
 
 template <int P>
 __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool synced, unsigned seq,
-                                          bool per_wave)
+                                          bool per_wave, int debug_skip = 0,  // debug_skip (timing experiments): 1 = no z update, 2 = no omega_b draw
+                                          bool beta_ready = false)            // beta was drawn by k_beta_draw, the previous kernel of the stream
 {
     __shared__ int s_wait_ok, s_beta_ok;
     __shared__ double s_beta[P];
@@ -1433,7 +1461,10 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     }
     if (skip) return;
     double beta[P];
-    {
+    if (beta_ready) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
+    } else {
         double sums[nacc(P)];
         reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);  // several waves: wave 0 + LDS
         const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
@@ -1458,8 +1489,13 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
             for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
         }
     }
-    if (blk >= nb) {  // role 1
-        omega_b_body<P>(c, sc, beta, chain, it + 1u, blk - nb, per_wave);
+    // the two roles take turns over the grid (odd blocks: role 1): the Polya-Gamma waves (arithmetic-bound) and the z
+    // waves (latency-bound on the visit rows) then share SIMDs from the start -- with the z blocks dealt first the
+    // omega_b blocks of a large problem only got onto the device once those had drained (500x500: 22 + 30 us in a row)
+    (void)nb;
+    if (blk & 1) {  // role 1
+        if (debug_skip & 2) return;
+        omega_b_body<P>(c, sc, beta, chain, it + 1u, blk >> 1, per_wave);
         return;
     }
     // role 0 needs alpha of THIS iteration, drawn on the side stream
@@ -1476,20 +1512,43 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
         for (int a = 0; a < MAXC; ++a) alpha[a] = (a < Q) ? sc.alpha[a] : 0.0;
     }
     if (writer) record_draws<P>(c, sc, chain, it, alpha, beta, sc.tau);
-    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int n = c.n, i = (blk >> 1) * blockDim.x + threadIdx.x;
+    if (i >= n || (debug_skip & 1)) return;
     z_update_site<P>(c, sc.key, chain, i, it, beta, alpha, c.eta[(size_t)chain * n + i]);
 }
 
+// beta ~ N(A^-1 r, A^-1) of every chain by ONE wave per chain, for problems with so many partial sums (blocks) that
+// re-reducing them in every block of k_z_ob is what that kernel spends its time on (500x500: 977 x 5 sums read by each
+// of 1 954 blocks, 23 of its 76 us); k_z_ob then takes beta from the chain's scalars (flags bit 2).  The same reduction
+// order and the same precision_mvnorm_reg as k_z_ob's own draw: the same bits.
 template <int P>
-__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave
+__global__ void __launch_bounds__(64) k_beta_draw(OCC_KARGS)
+{
+    const Ctx &c = *cp;
+    const int chain = chain_base + blockIdx.x;
+    ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.mid[e];
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    double sums[nacc(P)], beta[P];
+    reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);
+    const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
+    const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, beta);
+    if (threadIdx.x == 0) {
+        if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+#pragma unroll
+        for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave, bit 2: beta ready
 {
     __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
     const bool synced = (flags & 1) && c.sync != nullptr;
     // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
     const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
-    z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0);
+    z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0, (flags >> 3) & 3, (flags & 4) != 0);
 }
 
 

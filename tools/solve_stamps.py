@@ -31,7 +31,7 @@ buf = (C.c_ulonglong * (STEPS * PTS))()
 assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
 t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
 itn = int(eng.get('minres_itn', 0))
-names = ['top', 'compute+store', 'drain stores', 'sync+signal', 'minres_pre', 'poll', 'sync', 'loads+partial sums', 'wave sums', 'minres_post', 'hand-over', 'to next step']
+names = ['top', 'vectors+drain', 'wg barrier', 'record store', 'minres_pre', '-', 'poll', 'gathers issue', 'wave sums+sync', 'minres_post', 'hand-over', 'to next step']
 pts = [0, 1, 2, 3, 4, 9, 5, 6, 7, 8, 10, 11]
 print('last solve of chain 0: %d iterations; shader-clock ticks per segment' % itn)
 print('step ' + ' '.join('%13s' % n for n in names) + '   step total')
