@@ -87,20 +87,23 @@ def whole_iteration_bytes(prob, K, n_no_frac=0.4):
 
 
 def pmc_traffic(kernel, workload_key):
-    """HBM bytes per launch from the committed PMC pass (profiles/r02_pmc_hbm_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied).
-    Counters cannot be read from inside this process; the value is only reported for the workload the
-    pass was taken on, else null."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    if d.get('workload') != workload_key:
-        return None
-    # template instances carry their arguments in the name (occ::k_iter<8, 1>)
-    hits = [v for name, v in d['kernels'].items() if name == kernel or name.startswith(kernel + '<')]
-    return hits[0]['hbm_bytes_per_launch'] if hits else None
+    """HBM bytes per launch from the latest committed PMC pass for this workload (profiles/r*_pmc_hbm_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied;
+    tools/profile_round.sh).  Counters cannot be read from inside this process; the value is only reported for a
+    workload a pass was taken on, else null.  Returns (bytes per launch, file name)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*pmc_hbm_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get('workload') != workload_key:
+            continue
+        # template instances carry their arguments in the name (occ::k_iter<8, 1, 1>)
+        hits = [v for name, v in d['kernels'].items() if name == kernel or name.startswith(kernel + '<')]
+        if hits:
+            return hits[0]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def sell_entry_count(prob):
@@ -379,6 +382,7 @@ def main():
                       '(k_eta_init + k_minres launches 1..8, every launch cache-cold as in the real solve), '
                       'k_eta_init subtracted; = kernel duration + one dependent-launch boundary')
         achieved = bytes_launch / (ka['avg_us'] * 1e-6) / 1e9 if ka['avg_us'] > 0 else 0.0
+        traffic, traffic_file = pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else (None, None)
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
         # SURVEY 8(d)'s whole-iteration accounting beside the dominant kernel's: B_iter(measured K, R_e = R, n_no = 0.4 n)
         kmean = stats['krylov_mean']
@@ -415,8 +419,8 @@ def main():
                 'bound': 'hbm', 'kernel': kname,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else None,
-                'traffic_source': 'profiles/r02_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)',
+                'traffic': traffic,
+                'traffic_source': (traffic_file or 'none for this workload') + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)',
                 'bytes_per_launch': bytes_launch, 'avg_launch_us': round(ka['avg_us'], 3),
                 'launches_timed': ka['launches'],
                 'timing': timing,
