@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 3
+#define OCC_ABI_VERSION 4
 #define OCC_MAX_COVARIATES 8 /* p and q limit (register-resident p x p accumulators) */
 
 enum {
@@ -66,6 +66,14 @@ typedef struct occ_problem {
      * rsr_Q = K'QK (m x m), rsr_E its eigenfactor, E E' = K'QK (logit.py:321-323); all row-major; m <= 128. */
     int32_t rsr_dim;
     const double *rsr_K, *rsr_Q, *rsr_E;
+    /* Prior draw of the eta conditional, optional.  NULL (default): the engine draws the N(0, Q) prior term in EDGE form,
+     * u = B'eps with Q = B'B the weighted incidence factorisation -- O(nnz) work, no set-up -- which needs Q to be an ICAR
+     * precision D - W with W >= 0.  Non-NULL: the reference's own form (logit.py:64-67, 77): u = F eps with F an
+     * n x prior_factor_cols matrix, row-major, F F' = Q (the reference's eigenfactor E = U[:, 1:] sqrt(s[1:]) from the
+     * dense eigh of Q; any factor gives the same law) and eps standard normals of Philox stream 10 -- O(n^2) memory and
+     * bytes per iteration, but ANY symmetric positive semi-definite singular Q is accepted (positive off-diagonals too). */
+    const double *prior_factor;
+    int64_t prior_factor_cols;
 } occ_problem;
 
 typedef struct occ_sampler occ_sampler;

@@ -34,6 +34,10 @@ def problem_struct(prob):
     if rsr is not None:   # LogitRSRGibbs: eta = K theta
         pb.rsr_dim = int(rsr['dim'])
         pb.rsr_K, pb.rsr_Q, pb.rsr_E = _ptr(rsr['K']), _ptr(rsr['Q']), _ptr(rsr['E'])
+    elif getattr(prob, 'prior_factor', None) is not None:   # the reference's form of the prior draw: u = E eps
+        k['prior_factor'] = np.ascontiguousarray(prob.prior_factor, dtype=np.float64)
+        pb.prior_factor = _ptr(k['prior_factor'])
+        pb.prior_factor_cols = k['prior_factor'].shape[1]
     return pb, k
 
 

@@ -26,6 +26,7 @@ class OccProblem(C.Structure):
         ('a_mu', C.c_void_p), ('a_prec', C.c_void_p), ('b_mu', C.c_void_p), ('b_prec', C.c_void_p),
         ('tau_rate', C.c_double), ('tau_shape', C.c_double),
         ('rsr_dim', C.c_int32), ('rsr_K', C.c_void_p), ('rsr_Q', C.c_void_p), ('rsr_E', C.c_void_p),
+        ('prior_factor', C.c_void_p), ('prior_factor_cols', C.c_int64),
     ]
 
 
@@ -87,7 +88,7 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built, or no usable gfx950 device)."""
 
 
-ABI_VERSION = 3  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
+ABI_VERSION = 4  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
 
 
 def load():

@@ -12,6 +12,7 @@ from scipy import sparse
 from scipy.linalg import solve_triangular
 
 MAX_COVARIATES = 8  # compile-time limit of the register-resident p x p / q x q accumulators
+DENSE_PRIOR_MAX_SITES = 16384  # the reference-form prior draw keeps an n x (n - 1) factor: 2 GB at this size
 
 
 class FlatProblem:
@@ -22,7 +23,7 @@ class FlatProblem:
     ``not_surveyed``.
     """
 
-    def __init__(self, Q, W, X, y, hparams=None, check_singular=True):
+    def __init__(self, Q, W, X, y, hparams=None, check_singular=True, prior_draw='auto'):
         X = np.ascontiguousarray(X, dtype=np.float64)
         if X.ndim != 2:
             raise ValueError('X must be a 2-D array')
@@ -34,8 +35,25 @@ class FlatProblem:
         Qc.sort_indices()
         if Qc.shape != (self.n, self.n):
             raise ValueError('Q must be n x n with n = X.shape[0]')
-        if check_singular:
-            _verify_spatial_precision(Qc)
+        if prior_draw not in ('auto', 'edge', 'dense'):
+            raise ValueError("prior_draw must be 'auto', 'edge' or 'dense'")
+        # How the N(0, Q) prior term of the eta conditional is drawn.  'edge' (what 'auto' picks for an ICAR precision
+        # D - W, W >= 0): u = B'eps with Q = B'B, no set-up, O(nnz) work.  'dense': the reference's own form
+        # (gibbs/logit.py:64-67, 77): E = U[:, 1:] sqrt(s[1:]) from the dense eigh of Q, u = E eps -- O(n^3) set-up,
+        # O(n^2) bytes per iteration, but any symmetric positive semi-definite SINGULAR Q is accepted (the reference's
+        # own acceptance test, base.py:166-170, asks for nothing more); 'auto' falls back to it when Q is singular but
+        # not an ICAR precision.
+        self.prior_factor = None
+        if prior_draw != 'dense':
+            try:
+                if check_singular or prior_draw == 'edge':
+                    _verify_spatial_precision(Qc)
+            except ValueError as exc:
+                if prior_draw == 'edge' or 'must be singular' in str(exc) and not _is_singular_psd(Qc):
+                    raise
+                prior_draw = 'dense'
+        if prior_draw == 'dense':
+            self.prior_factor = dense_prior_factor(Qc)
         self.Q = Qc
 
         if list(W.keys()) != list(y.keys()):
@@ -124,6 +142,8 @@ class FlatProblem:
         d['scalars'] = np.array([self.tau_rate, self.tau_shape], dtype=np.float64)
         if self.rsr is not None:
             d['rsr_K'], d['rsr_Q'], d['rsr_E'] = self.rsr['K'], self.rsr['Q'], self.rsr['E']
+        if self.prior_factor is not None:
+            d['prior_factor'] = self.prior_factor
         return d
 
     @classmethod
@@ -147,6 +167,7 @@ class FlatProblem:
         self.not_surveyed = np.flatnonzero(~mask).tolist()
         self.hparams = dict(tau_rate=self.tau_rate, tau_shape=self.tau_shape, a_mu=self.a_mu,
                             a_prec=self.a_prec, b_mu=self.b_mu, b_prec=self.b_prec)
+        self.prior_factor = np.ascontiguousarray(d['prior_factor']) if 'prior_factor' in d else None
         self.rsr = None
         if 'rsr_K' in d:
             K = np.ascontiguousarray(d['rsr_K'])
@@ -201,6 +222,38 @@ def _verify_spatial_precision(Q):
     if off.nnz and off.max() > 0:
         raise ValueError('Spatial precision matrix Q must have non-positive off-diagonal entries '
                          '(Q = D - W with non-negative weights W).')
+
+
+def _is_singular_psd(Q):
+    """Symmetric, positive semi-definite and singular (dense eigenvalues; small problems only)."""
+    if Q.shape[0] > DENSE_PRIOR_MAX_SITES:
+        return False
+    A = Q.toarray()
+    if np.abs(A - A.T).max() > 1e-12 * max(np.abs(A).max(), 1e-300):
+        return False
+    s = np.linalg.eigvalsh(A)
+    return s[0] > -1e-8 * s[-1] and s[0] < 1e-8 * s[-1]
+
+
+def dense_prior_factor(Q):
+    """The reference's eigenfactor of the spatial precision (``_EtaICARPosterior.__init__``, gibbs/logit.py:64-67):
+    ``E = U[:, 1:] * sqrt(s[1:])`` from the dense ``eigh`` of Q, so that ``E E' = Q`` and ``E eps ~ N(0, Q)``.
+    Requires Q symmetric, positive semi-definite and singular (its smallest eigenvalue numerically zero -- the
+    condition the reference checks with shift-invert ``eigsh``, base.py:166-170 -- and none negative)."""
+    n = Q.shape[0]
+    if n > DENSE_PRIOR_MAX_SITES:
+        raise ValueError(f'the dense prior factor is n x (n - 1) doubles: at most {DENSE_PRIOR_MAX_SITES} sites '
+                         f'(an ICAR precision D - W needs no factor: the edge form is used)')
+    A = Q.toarray() if sparse.issparse(Q) else np.asarray(Q, dtype=np.float64)
+    scale = max(np.abs(A).max(), 1e-300)
+    if np.abs(A - A.T).max() > 1e-12 * scale:
+        raise ValueError('Spatial precision matrix Q must be symmetric.')
+    s, u = np.linalg.eigh(A)
+    if s[0] >= 1e-8 * s[-1] or not s[-1] > 0:
+        raise ValueError('Spatial precision matrix Q must be singular.')
+    if s[0] < -1e-8 * s[-1]:
+        raise ValueError('Spatial precision matrix Q must be positive semi-definite.')
+    return np.ascontiguousarray(u[:, 1:] * np.sqrt(np.clip(s[1:], 0.0, None)))
 
 
 def default_start(rng, prob):

@@ -263,7 +263,13 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
     switch (kind) {
         case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(c.p), gs, blk, 0, st, OCC_ARGS); break;
-        case K_NOISE: hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0); break;
+        case K_NOISE:
+            hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
+            if (c.dense_F != nullptr) {  // reference-form prior draw: uprior = F eps2, four chains per pass over F
+                const dim3 gd((unsigned)((c.n + 3) / 4));
+                for (int ch0 = 0; ch0 < c.C; ch0 += 4) hipLaunchKernelGGL(k_prior_dense<4>, gd, dim3(256), 0, st, s->ctx_dev, s->ctx.sc, ch0, e, extra);
+            }
+            break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
@@ -729,6 +735,8 @@ struct HostLayout {
     double tau_rate = 0.0, tau_shape = 0.0;
     std::vector<int> sell_ptr, sell_col, dia_off, row_site, site_sidx;
     std::vector<double> sell_val, qdiag, dia_val, Xt, Wt, hyp, Kh, Qh, Eh;
+    std::vector<double> prior_F;  // reference-form prior draw: n x prior_m, row-major (empty: edge form)
+    int prior_m = 0;
     std::vector<uint8_t> dia_mask, yrow, obs_site;
     std::vector<int32_t> site_id, site_ptr;
 };
@@ -787,10 +795,12 @@ static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
             rowsum += qdata[k];
             rowabs += std::fabs(qdata[k]);
             if (j == i) qdiag[i] = qdata[k];
-            else if (qdata[k] > 0.0) return set_error(s, OCC_E_BADARG, "Q must have non-positive off-diagonal entries");
+            else if (qdata[k] > 0.0 && !pb->prior_factor)
+                return set_error(s, OCC_E_BADARG, "Q must have non-positive off-diagonal entries (or come with a prior factor: occ_problem::prior_factor)");
         }
         scale = std::max(scale, rowabs);
-        if (std::fabs(rowsum) > 1e-10 * std::max(rowabs, 1e-300))
+        // (with a prior factor the caller has established the singularity: F F' = Q of rank < n)
+        if (!pb->prior_factor && std::fabs(rowsum) > 1e-10 * std::max(rowabs, 1e-300))
             return set_error(s, OCC_E_BADARG, "Spatial precision matrix Q must be singular.");
     }
     if (!(scale > 0.0)) return set_error(s, OCC_E_BADARG, "Spatial precision matrix Q must be singular.");
@@ -902,6 +912,12 @@ static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
             for (int b = 0; b < p; ++b) bpm[a] += b_prec[(size_t)a * p + b] * b_mu[b];  // base.py:162
     }
 
+    if (pb->prior_factor) {  // the reference's form of the prior draw: u = F eps
+        if (pb->prior_factor_cols < 1 || pb->prior_factor_cols > n) return set_error(s, OCC_E_BADARG, "prior_factor_cols must lie in [1, n]");
+        if (pb->rsr_dim > 0) return set_error(s, OCC_E_BADARG, "the reduced-rank model draws its prior term from rsr_E: no prior_factor");
+        L.prior_m = (int)pb->prior_factor_cols;
+        if ((rc = fetch(s, L.prior_F, pb->prior_factor, (size_t)n * L.prior_m))) return rc;
+    }
     if (pb->rsr_dim > 0) {  // reduced-rank model: the basis K (n x m), K'QK and its eigenfactor (m x m), row-major
         const int m = pb->rsr_dim;
         if ((rc = fetch(s, L.Kh, pb->rsr_K, (size_t)n * m))) return rc;
@@ -1070,6 +1086,14 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     }
     if ((rc = upload(s, &c.obs_site, s->obs_site))) return rc;
     if ((rc = upload(s, &c.hyp, hyp))) return rc;
+    c.dense_F = nullptr;
+    c.dense_m = 0;
+    if (L.prior_m > 0) {  // reference-form prior draw
+        if ((rc = upload(s, &c.dense_F, L.prior_F))) return rc;
+        c.dense_m = L.prior_m;
+        for (int b = 0; b < 2; ++b)
+            if ((rc = dev_alloc(s, &c.dense_eps[b], (size_t)C * L.prior_m))) return rc;
+    }
 
     const size_t Cn = (size_t)C * n;
     if ((rc = dev_alloc(s, &c.eta, Cn))) return rc;
@@ -1429,7 +1453,8 @@ int occ_create_distributed(const occ_problem *problem, occ_comm *cm, int32_t roo
     int rc = OCC_OK;
     if (cm->rank == root) {
         rc = build_layout(s, problem, L);
-        if (rc == OCC_OK && L.rsr_dim > 0) rc = set_error(s, OCC_E_BADARG, "occ_create_distributed covers the ICAR model");
+        if (rc == OCC_OK && (L.rsr_dim > 0 || L.prior_m > 0))
+            rc = set_error(s, OCC_E_BADARG, "occ_create_distributed covers the ICAR model with the edge-form prior draw");
         h.ok = rc == OCC_OK;
         if (h.ok) {
             h.n = L.n; h.S = L.S; h.R = L.R; h.p = L.p; h.q = L.q; h.ell_w = L.ell_w;

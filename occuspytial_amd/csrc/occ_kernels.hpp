@@ -168,6 +168,11 @@ struct Ctx {
     // never keep the producer it waits for off the device); null: not used.  See "Stream hand-overs" below.
     unsigned *sync;
     const Inject *inj;  // injected variates of the occ_cond_* entry points (INJ kernels only); null otherwise
+    // Reference-form prior draw (occ_problem::prior_factor): u = F eps2, F row-major n x dense_m; eps2 of iteration t in
+    // dense_eps[t & 1] ([C][dense_m]), written by k_noise, multiplied by k_prior_dense.  Null: the edge form.
+    const double *dense_F;
+    double *dense_eps[2];
+    int dense_m;
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -628,6 +633,7 @@ __device__ __forceinline__ void noise_site(const Ctx &c, uint64_t key, int chain
     const int n = c.n, lane = i & 63;
     int base, width;
     slice_of(c, i, base, width);
+    if (c.dense_F != nullptr) width = 0;  // reference-form prior draw: k_prior_dense writes uprior
     double u = 0.0;
     for (int k = 0; k < width; ++k) {
         const int j = c.sell_col[base + k * 64 + lane];
@@ -639,8 +645,54 @@ __device__ __forceinline__ void noise_site(const Ctx &c, uint64_t key, int chain
         }
     }
     const size_t ci = (size_t)chain * n + i;
-    c.uprior[it & 1][ci] = u;
+    if (c.dense_F == nullptr) c.uprior[it & 1][ci] = u;
+    else if (i < c.dense_m) c.dense_eps[it & 1][(size_t)chain * c.dense_m + i] = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_DENSE);
     c.enorm[it & 1][ci] = block_normal(key, (uint32_t)i, 0, it, STREAM_ETA_SITE);
+}
+
+// Reference-form prior term (logit.py:77): uprior = F eps2 for every chain in ONE pass over F (n x m, row-major: the
+// bytes that bound this kernel are read once for all chains).  One wave per row, lanes strided over the columns
+// (coalesced 512-byte requests), up to NCH chains accumulated side by side, fixed-order wave sums.  Launched right
+// behind k_noise (same control words, same `ahead`).
+template <int NCH>
+__global__ void __launch_bounds__(256) k_prior_dense(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, int chain0, int e, int ahead)
+{
+    const Ctx &c = *cp;
+    const int row = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= c.n) return;
+    const int m = c.dense_m;
+    uint32_t it[NCH];
+    bool on[NCH];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int ch = chain0 + q;
+        on[q] = false;
+        it[q] = 0;
+        if (ch < c.C) {
+            const ChainScalars &sc = scs[ch];
+            const Ctl ctl = sc.ctl[e];
+            on[q] = !(ctl.koff || ctl.it >= sc.it_stop || sc.err != 0);
+            it[q] = ctl.it + (uint32_t)ahead;
+        }
+        any = any || on[q];
+    }
+    if (!any) return;
+    const double *F = c.dense_F + (size_t)row * m;
+    double acc[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc[q] = 0.0;
+    for (int j = lane; j < m; j += 64) {
+        const double f = F[j];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+            if (on[q]) acc[q] = fma(f, c.dense_eps[it[q] & 1][(size_t)(chain0 + q) * m + j], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const double t = wave_sum(acc[q]);
+        if (on[q] && lane == 0) c.uprior[it[q] & 1][(size_t)(chain0 + q) * c.n + row] = t;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on)

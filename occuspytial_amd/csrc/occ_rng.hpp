@@ -25,7 +25,8 @@ enum : uint32_t {
     STREAM_BETA = 5,
     STREAM_OMEGA_A = 6,
     STREAM_ALPHA = 7,
-    STREAM_Z = 8
+    STREAM_Z = 8,
+    STREAM_ETA_DENSE = 10 // the standard normals of the reference-form prior draw: c0 = column of the factor
 };
 
 constexpr double kPi = 3.14159265358979323846;

@@ -46,8 +46,8 @@ class GibbsBase:
         raise NotImplementedError(f'{self.__class__.__name__} must implement a `step` method.')
 
     # ------------------------------------------------------------------ configuration (base.py:107-186)
-    def _configure(self, Q, hparams, verify_precision=True, **kwargs):
-        prob = FlatProblem(Q, self.W._data, self.X, self.y._data, hparams, check_singular=verify_precision)
+    def _configure(self, Q, hparams, verify_precision=True, prior_draw='auto', **kwargs):
+        prob = FlatProblem(Q, self.W._data, self.X, self.y._data, hparams, check_singular=verify_precision, prior_draw=prior_draw)
         self._problem = prob
 
         self.state = _GibbsState()

@@ -27,7 +27,10 @@ class LogitICARGibbs(GibbsBase):
       stream, so draws are equal to the reference's in distribution, not value for value;
     * the prior term of the :math:`\eta` conditional uses the edge factorisation
       :math:`Q = B^\top B` instead of a dense eigenfactor (``logit.py:66-67``): no O(n^2) memory, no
-      O(n^3) set-up; ``Q`` must be an ICAR precision (zero row sums, non-positive off-diagonals);
+      O(n^3) set-up, for any ICAR precision (zero row sums, non-positive off-diagonals).  ``prior_draw='dense'``
+      selects the reference's own form instead (dense ``eigh`` on the host, one dense matrix-vector product per
+      iteration on the device); ``'auto'`` takes it by itself for a singular positive semi-definite ``Q`` that is
+      not an ICAR precision, which the edge form cannot represent;
     * ``device`` selects the HIP device; all chains of one ``sample`` call run batched on it.  ``devices=[...]``
       instead fans the chains of ``sample(chains=N)`` out over several GPUs from this process, chain ``c`` on
       ``devices[c % len(devices)]`` -- the reference's one-process-per-chain fan-out (``gibbs/parallel.py:20-41``) with
@@ -36,14 +39,14 @@ class LogitICARGibbs(GibbsBase):
       depend on how many devices share the work.
     """
 
-    def __init__(self, Q, W, X, y, hparams=None, random_state=None, device=0, devices=None):
+    def __init__(self, Q, W, X, y, hparams=None, random_state=None, device=0, devices=None, prior_draw='auto'):
         super().__init__(Q, W, X, y, hparams, random_state)
         self.devices = [int(d) for d in devices] if devices is not None else None
         self.device = self.devices[0] if self.devices else device
-        self._configure(Q, hparams)
+        self._configure(Q, hparams, prior_draw=prior_draw)
 
-    def _configure(self, Q, hparams):
-        super()._configure(Q, hparams)
+    def _configure(self, Q, hparams, prior_draw='auto'):
+        super()._configure(Q, hparams, prior_draw=prior_draw)
 
     # ------------------------------------------------------------------ engine management
     def _get_engine(self, keys):
@@ -220,7 +223,7 @@ class LogitRSRGibbs(LogitICARGibbs):
     """
 
     def __init__(self, Q, W, X, y, hparams=None, random_state=None, r=0.5, q=None, device=0, devices=None):
-        super().__init__(Q, W, X, y, hparams, random_state, device=device, devices=devices)
+        super().__init__(Q, W, X, y, hparams, random_state, device=device, devices=devices, prior_draw='edge')
         self._configure_rsr(r, q, hparams)
 
     def _configure_rsr(self, r, q, hparams):

@@ -209,6 +209,8 @@ class OracleSampler:
         if self.rsr is not None:   # LogitRSRGibbs: eta = K theta
             if lib().orc_set_rsr(self._h, int(self.rsr['dim']), self.rsr['K'], self.rsr['Q'], self.rsr['E']):
                 raise ValueError('bad reduced-rank basis')
+        elif getattr(prob, 'prior_factor', None) is not None:   # the problem asks for the reference-form prior draw
+            self.set_dense_eigen(prob.prior_factor)
 
     def __del__(self):
         if getattr(self, '_h', None):

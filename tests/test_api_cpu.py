@@ -324,3 +324,33 @@ def test_reduced_rank_sampler_configuration_needs_no_device():
         LogitRSRGibbs(Q, W, X, y, r=1.1)
     hp = {'tau_rate': 1.0, 'tau_shape': 5.0}
     assert LogitRSRGibbs(Q, W, X, y, hparams=hp, q=10).fixed.tau_shape == 5.0
+
+
+def test_prior_draw_selection_on_the_host():
+    """How the N(0, Q) prior term is drawn (FlatProblem ``prior_draw``): the edge form for an ICAR precision; the
+    reference's dense eigenfactor (gibbs/logit.py:64-67) on request, and by itself for a singular positive semi-definite
+    Q with positive off-diagonals -- which the reference accepts (base.py:166-170) and the edge form cannot represent;
+    a non-singular Q is refused with the reference's message either way."""
+    from scipy import sparse
+    from occuspytial_amd._problem import FlatProblem, dense_prior_factor
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(6, 7, visits=3, p=2, q=2, random_state=6)
+    assert FlatProblem(Q, W, X, y).prior_factor is None
+    E = FlatProblem(Q, W, X, y, prior_draw='dense').prior_factor
+    assert E.shape == (42, 41) and np.abs(E @ E.T - Q.toarray()).max() < 1e-12
+    row = np.zeros(42)
+    row[[0, 20, 41]] = 1.0, 1.0, -2.0                              # sites 0 and 20 are not neighbours: +1 stays
+    M = sparse.csr_matrix(row[None, :])
+    Qg = (Q + M.T @ M).tocsr()                                     # still Q 1 = 0, PSD, but a positive off-diagonal
+    assert (Qg - sparse.diags(Qg.diagonal())).max() > 0
+    with pytest.raises(ValueError, match='non-positive off-diagonal'):
+        FlatProblem(Qg, W, X, y, prior_draw='edge')
+    Eg = FlatProblem(Qg, W, X, y).prior_factor
+    assert Eg is not None and np.abs(Eg @ Eg.T - Qg.toarray()).max() < 1e-10
+    for mode in ('auto', 'dense'):
+        with pytest.raises(ValueError, match='Spatial precision matrix Q must be singular.'):
+            FlatProblem(Q + 0.1 * sparse.identity(42), W, X, y, prior_draw=mode)
+    with pytest.raises(ValueError, match='symmetric'):
+        dense_prior_factor(sparse.csr_matrix(np.triu(Q.toarray())))
+    # the plain-array round trip (what a multi-process launch broadcasts) keeps the factor
+    assert np.array_equal(FlatProblem.from_arrays(FlatProblem(Qg, W, X, y).to_arrays()).prior_factor, Eg)

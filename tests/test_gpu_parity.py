@@ -620,3 +620,58 @@ def test_barrier_timeout_falls_back_to_launch_per_step_with_the_same_bits(monkey
     for su, sv in zip(ref[1], alt[1]):
         for u, v in zip(su, sv):
             assert np.array_equal(u, v)
+
+
+# ---- the reference's own form of the prior draw, and precisions the edge form cannot represent ---------------------
+def _general_singular_precision(n, seed):
+    """A symmetric positive semi-definite singular Q that is NOT an ICAR precision: Q = M'M with every row of M summing
+    to zero (so Q 1 = 0) but rows like (1, 1, -2), which put POSITIVE entries off the diagonal."""
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    r = 0
+    for i in range(n - 1):            # a path keeps the graph connected: rank n - 1
+        rows += [r, r]; cols += [i, i + 1]; vals += [1.0, -1.0]; r += 1
+    for _ in range(n):
+        i, j, k = rng.choice(n, size=3, replace=False)
+        rows += [r, r, r]; cols += [i, j, k]; vals += [1.0, 1.0, -2.0]; r += 1
+    M = sparse.csr_matrix((vals, (rows, cols)), shape=(r, n))
+    Q = (M.T @ M).tocsr()
+    Q.sum_duplicates()
+    return Q
+
+
+@pytest.mark.parametrize('which', ['icar_forced_dense', 'general_singular'])
+def test_reference_form_prior_draw_lockstep(oracle, which, solve_mode):
+    """prior_draw='dense': the N(0, Q) term of the eta conditional as the reference forms it (logit.py:64-67, 77) --
+    E from the dense eigh of Q on the host, u = E eps2 by one pass over E on the device for all chains -- in lock step
+    with the oracle's dense mode (same normals, Philox stream 10).  Once on an ICAR lattice (where the edge form is the
+    default), once on a singular Q with positive off-diagonals, which only this form can sample ('auto' selects it)."""
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(13, 17, visits=4, p=2, q=2, random_state=6)
+    if which == 'icar_forced_dense':
+        prob = FlatProblem(Q, W, X, y, prior_draw='dense')
+    else:
+        Qg = _general_singular_precision(Q.shape[0], 3)
+        assert (Qg - sparse.diags(Qg.diagonal())).max() > 0
+        with pytest.raises(ValueError, match='non-positive off-diagonal'):
+            FlatProblem(Qg, W, X, y, prior_draw='edge')
+        prob = FlatProblem(Qg, W, X, y)            # 'auto': falls back to the reference's form
+    E = prob.prior_factor
+    assert E is not None and E.shape == (prob.n, prob.n - 1) and np.abs(E @ E.T - prob.Q.toarray()).max() < 1e-9
+    starts = [_random_start(prob, 70 + c) for c in range(5)]     # five chains: two passes over E (four chains per pass)
+    worst, stats = _lockstep_chains(oracle, prob, starts, [KEY + 17 * c for c in range(5)], 4)
+    assert stats['n_chains'] == 5
+
+
+def test_reference_form_prior_draw_free_running_equals_edge_form_in_law(oracle):
+    """Same posterior whichever way the prior term is drawn (E E' = Q = B'B): 4 device chains with prior_draw='dense'
+    against the REFERENCE's chains (which use exactly this form)."""
+    from occuspytial_amd import LogitICARGibbs
+    from .test_reference_chains import compare_with_reference, problem_of
+    case = 'refchain_queen150_tauprior'
+    Q, W, X, y, hp, ch = problem_of(case)
+    s = LogitICARGibbs(Q, W, X, y, hparams=hp, random_state=77, prior_draw='dense')
+    assert s._problem.prior_factor is not None
+    post = s.sample(int(ch['size']), burnin=int(ch['burnin']), chains=4, progressbar=False)
+    compare_with_reference(case, post['alpha'], post['beta'], post['tau'])
