@@ -29,7 +29,9 @@ extern "C" {
 #endif
 
 #define OCC_ABI_VERSION 4
-#define OCC_MAX_COVARIATES 8 /* p and q limit (register-resident p x p accumulators) */
+#define OCC_MAX_COVARIATES 32 /* p and q limit.  Up to 8 of each: kernels with the p x p / q x q accumulators in registers and the
+                                fused iteration kernel; 9 to 32: generic kernels (run-time p and q, terms reduced one at a time,
+                                Cholesky factor in LDS) on the launch-per-step path */
 
 enum {
     OCC_OK = 0,

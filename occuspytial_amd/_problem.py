@@ -11,7 +11,7 @@ import numpy as np
 from scipy import sparse
 from scipy.linalg import solve_triangular
 
-MAX_COVARIATES = 8  # compile-time limit of the register-resident p x p / q x q accumulators
+MAX_COVARIATES = 32  # limit of the engine (up to 8: register-resident accumulators; beyond: its generic kernels)
 DENSE_PRIOR_MAX_SITES = 16384  # the reference-form prior draw keeps an n x (n - 1) factor: 2 GB at this size
 
 

@@ -57,6 +57,7 @@ struct occ_sampler {
     int nbg_any = 0;         // its workgroups per chain
     int tpb_plain = 256;     // threads per block of the launch-per-step path when no fused form applies
     int iter_flags_extra = 0;  // OR-ed into k_iter's flags (2: residency probe)
+    bool generic = false;      // more than 8 occupancy or detection covariates: the P = 0 / Q = 0 kernels (run-time p, q), launch-per-step path
     bool beta_split = false;   // beta drawn by k_beta_draw (one wave per chain) in front of k_z_ob: many blocks, launch-per-step path
     int zob_debug = 0;         // OCC_DEBUG_ZOB_SKIP (timing experiments with occ_profile only): 8 = no z update, 16 = no omega_b draw
     bool device_timeout = false;  // the last error was a device-side wait that gave up (not a HIP API failure)
@@ -202,6 +203,7 @@ using KernelEI = void (*)(const Ctx *, ChainScalars *, Slot *, int, int, int);
 KernelEI pick_beta_partial(int p)
 {
     switch (p) {
+        case 0: return k_beta_partial<0>;  // generic path (run-time p)
         case 1: return k_beta_partial<1>;
         case 2: return k_beta_partial<2>;
         case 3: return k_beta_partial<3>;
@@ -213,10 +215,13 @@ KernelEI pick_beta_partial(int p)
     }
 }
 #define OCC_PICK_P(NAME, p) \
-    ((p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
+    ((p) == 0 ? NAME<0> : (p) == 1 ? NAME<1> : (p) == 2 ? NAME<2> : (p) == 3 ? NAME<3> : (p) == 4 ? NAME<4> : (p) == 5 ? NAME<5> : (p) == 6 ? NAME<6> : (p) == 7 ? NAME<7> : NAME<8>)
 KernelE pick_omega_b(int p) { return OCC_PICK_P(k_omega_b, p); }
 using KernelRsrE = void (*)(const RsrArgs, const Ctx *, ChainScalars *, Slot *, int, int);
-KernelRsrE pick_rsr_eta_beta(int p) { return OCC_PICK_P(k_rsr_eta_beta, p); }
+KernelRsrE pick_rsr_eta_beta(int p)
+{
+    return p == 1 ? k_rsr_eta_beta<1> : p == 2 ? k_rsr_eta_beta<2> : p == 3 ? k_rsr_eta_beta<3> : p == 4 ? k_rsr_eta_beta<4> : p == 5 ? k_rsr_eta_beta<5> : p == 6 ? k_rsr_eta_beta<6> : p == 7 ? k_rsr_eta_beta<7> : k_rsr_eta_beta<8>;
+}
 using KernelRsr = void (*)(const RsrArgs, int);
 KernelRsr pick_rsr_solve(int m)
 {
@@ -235,6 +240,7 @@ KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
 KernelE pick_omega_a(int q)
 {
     switch (q) {
+        case 0: return k_omega_a<0>;  // generic path (run-time q)
         case 1: return k_omega_a<1>;
         case 2: return k_omega_a<2>;
         case 3: return k_omega_a<3>;
@@ -261,8 +267,10 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
 {
     const Ctx &c = s->ctx;
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, (unsigned)c.C), gr((unsigned)c.nb_r, (unsigned)c.C);
+    const int tp = s->generic ? 0 : c.p, tq = s->generic ? 0 : c.q;  // template arguments: 0 = the generic (run-time) instantiation
+    const size_t lds_p = s->generic ? generic_lds_bytes(nacc(c.p), s->tpb) : 0, lds_q = s->generic ? generic_lds_bytes(nacc(c.q), s->tpb) : 0;
     switch (kind) {
-        case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(c.p), gs, blk, 0, st, OCC_ARGS); break;
+        case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(tp), gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE:
             hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
             if (c.dense_F != nullptr) {  // reference-form prior draw: uprior = F eps2, four chains per pass over F
@@ -272,8 +280,8 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
-        case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, st, OCC_ARGS, extra); break;
-        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(c.q), gr, blk, 0, st, OCC_ARGS); break;
+        case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(tp), gs, blk, lds_p, st, OCC_ARGS, extra); break;
+        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), gr, blk, lds_q, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
@@ -292,10 +300,12 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         default:
             if (s->tpb == 64) {  // 64-site slices (fused paths): 256-thread blocks, beta once per block, partial sums still per slice
                 const unsigned nb4 = (unsigned)((c.n + 255) / 256);
-                hipLaunchKernelGGL(pick_z_ob(c.p), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2 | s->zob_debug);
+                if (s->generic) hipLaunchKernelGGL((k_beta_draw<0, 0>), dim3((unsigned)c.C), dim3(256), 0, st, OCC_ARGS);
+                hipLaunchKernelGGL(pick_z_ob(tp), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2 | s->zob_debug);
             } else {
-                if (s->beta_split) hipLaunchKernelGGL(OCC_PICK_P(k_beta_draw, c.p), dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS);
-                hipLaunchKernelGGL(pick_z_ob(c.p), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS,
+                if (s->generic) hipLaunchKernelGGL((k_beta_draw<0, 0>), dim3((unsigned)c.C), dim3(256), 0, st, OCC_ARGS);
+                else if (s->beta_split) hipLaunchKernelGGL(OCC_PICK_P(k_beta_draw, c.p), dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS);
+                hipLaunchKernelGGL(pick_z_ob(tp), dim3((unsigned)c.nb_n * 2, (unsigned)c.C), blk, 0, st, OCC_ARGS,
                                    (s->launch_sync ? 1 : 0) | s->zob_debug | (s->beta_split ? 4 : 0));
             }
             break;
@@ -747,7 +757,8 @@ static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
     if (pb->n < 1 || pb->n > 0x7fffffff || pb->n_rows > 0x7fffffff || pb->n_surveyed > pb->n)
         return set_error(s, OCC_E_BADARG, "problem sizes out of range");
     if (pb->p < 1 || pb->p > OCC_MAX_COVARIATES || pb->q < 1 || pb->q > OCC_MAX_COVARIATES)
-        return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 8]");
+        return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 32]");
+    if (pb->rsr_dim > 0 && (pb->p > MAXC || pb->q > MAXC)) return set_error(s, OCC_E_BADARG, "the reduced-rank model takes at most 8 covariates of each kind");
     if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_MAX_DIM || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
         return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 128 columns (rsr_K, rsr_Q, rsr_E)");
     if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
@@ -977,7 +988,8 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // against 251 us with one launch per MINRES step)
         s->iter_window = wmax <= 8 ? 8 : 16;
         const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
-        const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16;
+        s->generic = p > MAXC || q > MAXC;
+        const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16 && !s->generic;
         s->persistent = fused_ok && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         // one XCD per chain (k_iter<8, 1, *>); candidates -- the probe below decides.  Per XCD the main stream has 20 CUs
         // (24 for larger lattices, 28 when few chains leave the side stream little to do), whole shader engines'
@@ -2280,7 +2292,7 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
         if (slot.done) { k_last = k; break; }
         if ((long long)k > c.maxiter + 3) return set_error(s, OCC_E_MINRES, "MINRES solver did not converge!");
     }
-    hipLaunchKernelGGL(pick_beta_partial(c.p), gs, blk, 0, s->stream, OCC_CARGS, k_last);
+    hipLaunchKernelGGL(pick_beta_partial(s->generic ? 0 : c.p), gs, blk, s->generic ? generic_lds_bytes(nacc(c.p), s->tpb) : 0, s->stream, OCC_CARGS, k_last);
     ChainScalars sc;
     if ((rc = cond_end(s, chain, &sc))) return rc;
     if ((rc = copy_out(s, rhs_out, c.rhs + co, n))) return rc;
@@ -2308,8 +2320,13 @@ int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const do
     if ((rc = copy_in(s, c.omega_b[it & 1] + co, omega_b, n))) return rc;
     const int e = s->parity;
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
-    hipLaunchKernelGGL(OCC_PICK_P(k_beta_sums, c.p), gs, blk, 0, s->stream, OCC_CARGS);
-    hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    if (s->generic) {
+        hipLaunchKernelGGL(k_beta_sums<0>, gs, blk, generic_lds_bytes(nacc(c.p), s->tpb), s->stream, OCC_CARGS);
+        hipLaunchKernelGGL((k_beta_draw<0, 1>), dim3(1), dim3(256), 0, s->stream, OCC_CARGS);
+    } else {
+        hipLaunchKernelGGL(OCC_PICK_P(k_beta_sums, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+        hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    }
     ChainScalars sc;
     if ((rc = cond_end(s, chain, &sc))) return rc;
     if (beta_out) std::copy(sc.beta, sc.beta + c.p, beta_out);
@@ -2329,7 +2346,8 @@ int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const d
     const int e = s->parity;
     const dim3 blk((unsigned)s->tpb), gr((unsigned)c.nb_r, 1u);
 #define OCC_OMEGA_A_INJ(q) ((q) == 1 ? k_omega_a<1, 1> : (q) == 2 ? k_omega_a<2, 1> : (q) == 3 ? k_omega_a<3, 1> : (q) == 4 ? k_omega_a<4, 1> : (q) == 5 ? k_omega_a<5, 1> : (q) == 6 ? k_omega_a<6, 1> : (q) == 7 ? k_omega_a<7, 1> : k_omega_a<8, 1>)
-    hipLaunchKernelGGL(OCC_OMEGA_A_INJ(c.q), gr, blk, 0, s->stream, OCC_CARGS);
+    if (s->generic) hipLaunchKernelGGL((k_omega_a<0, 1>), gr, blk, generic_lds_bytes(nacc(c.q), s->tpb), s->stream, OCC_CARGS);
+    else hipLaunchKernelGGL(OCC_OMEGA_A_INJ(c.q), gr, blk, 0, s->stream, OCC_CARGS);
     hipLaunchKernelGGL(k_alpha_draw<1>, dim3(1), dim3(512), 0, s->stream, OCC_CARGS, 0);
     ChainScalars sc;
     if ((rc = cond_end(s, chain, &sc))) return rc;
@@ -2350,7 +2368,7 @@ int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out)
     if ((rc = copy_in(s, s->inj_u, u, n))) return rc;
     const int e = s->parity;
     const dim3 blk((unsigned)s->tpb), gs((unsigned)c.nb_n, 1u);
-    hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, c.p), gs, blk, 0, s->stream, OCC_CARGS);
+    hipLaunchKernelGGL(OCC_PICK_P(k_cond_beta_z, s->generic ? 0 : c.p), gs, blk, 0, s->stream, OCC_CARGS);
     if ((rc = cond_end(s, chain, nullptr))) return rc;
     if (z_out) {
         std::vector<uint8_t> z(n);

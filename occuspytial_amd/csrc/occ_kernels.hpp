@@ -42,8 +42,10 @@
 
 namespace occ {
 
-constexpr int MAXC = 8;                             // OCC_MAX_COVARIATES
+constexpr int MAXC = 8;                             // covariates of the register-resident fast path (templates on P, Q)
 constexpr int NACC_MAX = MAXC * (MAXC + 1) / 2 + MAXC;  // 44
+constexpr int MAXG = 32;                            // OCC_MAX_COVARIATES: the generic path (P = 0 instantiations, run-time p and q)
+constexpr int NACC_G = MAXG * (MAXG + 1) / 2 + MAXG;    // 560
 constexpr int NSLOT = 4;
 constexpr int MAX_WAVES = 4;  // threads per block <= 256
 
@@ -96,7 +98,7 @@ struct Ctl {
 // k_beta_partial publishes the carry decision of the slot in mid[s & 1].  No kernel reads a word that
 // another block of the same kernel writes.
 struct ChainScalars {
-    double alpha[MAXC], beta[MAXC];
+    double alpha[MAXG], beta[MAXG];
     double tau;
     double tau_gamma[2];       // the standard gamma variate of tau's draw of iteration t in [t & 1] (logit.py:209): it depends on
                                // nothing but (key, t), so k_noise draws it one iteration ahead, off the critical path
@@ -115,8 +117,8 @@ struct ChainScalars {
 // from the state buffers instead of drawing them).  Production launches never read it.
 struct Inject {
     double gamma;             // standard gamma variate of shape tau_shape                          logit.py:209
-    double beta_eps[MAXC];    // standard normals of precision_mvnorm                               distributions.pyx:95-96
-    double alpha_eps[MAXC];
+    double beta_eps[MAXG];    // standard normals of precision_mvnorm                               distributions.pyx:95-96
+    double alpha_eps[MAXG];
     const double *z_u;        // [n] uniform of site i (sites with a detection ignore theirs)        logit.py:247-251
     int tau_from_gamma;       // k_eta_init: 1 = tau = gamma / rate, 0 = keep the chain's tau
     int do_beta, do_z;        // k_z_ob: draw beta / update z
@@ -351,6 +353,36 @@ __device__ __forceinline__ void reduce_partials_lds(const double *part, int nq, 
     }
     __syncthreads();
 }
+
+// Generic path (more than MAXC covariates: the number of quantities is only known at run time): the terms of the
+// p x p / q x q systems are EMITTED one at a time -- wave sum at once, one LDS word per wave and quantity -- and
+// combined over the block's waves by finish() (one barrier), in the order of block_partials.
+struct PartialEmitter {
+    double *out;
+    int nb, blk, nq;
+    __device__ __forceinline__ void emit(int t, double v)
+    {
+        extern __shared__ double s_gpart[];  // [waves][nq] (dynamic LDS of the P = 0 kernels)
+        const double r = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) {
+            if (blockDim.x == 64) out[(size_t)t * nb + blk] = r;
+            else s_gpart[(threadIdx.x >> 6) * nq + t] = r;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        extern __shared__ double s_gpart[];
+        if (blockDim.x == 64) return;
+        __syncthreads();
+        const int nw = blockDim.x >> 6;
+        for (int t = threadIdx.x; t < nq; t += blockDim.x) {
+            double acc = 0.0;
+            for (int w = 0; w < nw; ++w) acc += s_gpart[w * nq + t];
+            out[(size_t)t * nb + blk] = acc;
+        }
+    }
+};
+__host__ __device__ constexpr size_t generic_lds_bytes(int nq, int threads) { return threads == 64 ? 0 : sizeof(double) * (size_t)(threads / 64) * nq; }
 
 // Off-diagonal slots of the 64-row slice that holds site i: first slot and number of slots per row.
 __device__ __forceinline__ void slice_of(const Ctx &c, int i, int &base, int &width)
@@ -594,6 +626,30 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
     block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
 }
 
+// ... with beta taken from the chain's scalars and a run-time number of covariates (generic path)
+__device__ __forceinline__ void omega_b_body_g(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int blk, bool per_wave = false)
+{
+    const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+    double quad[1] = {0.0};
+    if (i < n) {
+        const size_t ci = (size_t)chain * n + i;
+        const double *eta = c.eta + (size_t)chain * n;
+        double xb = 0.0;
+        for (int a = 0; a < c.p; ++a) xb += c.Xt[(size_t)a * n + i] * sc.beta[a];
+        const double eta_i = eta[i];
+        Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
+        c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
+        quad[0] = quad_site(c, eta, i, eta_i);
+    }
+    if (per_wave) {
+        const double t = wave_sum(quad[0]);
+        const int slice = blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && slice < c.nb_n) c.part_quad[(size_t)chain * c.nb_n + slice] = t;
+        return;
+    }
+    block_partials<1>(quad, c.part_quad + (size_t)chain * c.nb_n, c.nb_n, blk);
+}
+
 // Stand-alone omega_b of the CURRENT iteration: only needed when the start values or the state were
 // just set by the host (afterwards k_z_ob's second role has already produced it).
 template <int P>
@@ -605,10 +661,14 @@ __global__ void __launch_bounds__(256) k_omega_b(OCC_KARGS)
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    double beta[P];
+    if constexpr (P == 0) {
+        omega_b_body_g(c, sc, chain, ctl.it, blk);
+    } else {
+        double beta[P];
 #pragma unroll
-    for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
-    omega_b_body<P>(c, sc, beta, chain, ctl.it, blk);
+        for (int a = 0; a < P; ++a) beta[a] = sc.beta[a];
+        omega_b_body<P>(c, sc, beta, chain, ctl.it, blk);
+    }
 }
 
 // The partial sums of eta'Q eta alone, from the chain's current eta (occ_cond_tau: no Polya-Gamma draw).
@@ -1263,6 +1323,25 @@ __device__ __forceinline__ void beta_site_terms(const Ctx &c, int chain, int i, 
     for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
 }
 
+// ... generic path: the same terms in the same order (upper triangle row by row, then the right-hand side), emitted
+// one at a time
+__device__ __forceinline__ void beta_site_terms_g(const Ctx &c, int chain, int i, bool act, uint32_t it, double eta, int blk)
+{
+    const int n = c.n, p = c.p;
+    PartialEmitter em{c.part_beta + (size_t)chain * nacc(p) * c.nb_n, c.nb_n, blk, nacc(p)};
+    const int ic = act ? i : 0;
+    const size_t ci = (size_t)chain * n + ic;
+    const double om = c.omega_b[it & 1][ci];
+    const double tt = beta_rhs_term(om, eta, (double)c.z[ci]);
+    int t = 0;
+    for (int aa = 0; aa < p; ++aa) {
+        const double xo = c.Xt[(size_t)aa * n + ic] * om;
+        for (int bb = aa; bb < p; ++bb) em.emit(t++, act ? xo * c.Xt[(size_t)bb * n + ic] : 0.0);
+    }
+    for (int aa = 0; aa < p; ++aa) em.emit(t++, act ? c.Xt[(size_t)aa * n + ic] * tt : 0.0);
+    em.finish();
+}
+
 template <int P>
 __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_launch)
 {
@@ -1321,17 +1400,27 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     double sums[2];
     reduce_partials<2>(c.part_proj + (size_t)chain * 2 * c.nb_n, c.nb_n, sums);
     const double a = -sums[0] / sums[1];
-    double acc[nacc(P)];
+    if constexpr (P == 0) {
+        double eta = 0.0;
+        if (i < n) {
+            const size_t ci = (size_t)chain * n + i;
+            eta = eta_project(c.Xv[ci], a);
+            c.eta[ci] = eta;
+        }
+        beta_site_terms_g(c, chain, i, i < n, ctl.it, eta, blk);
+    } else {
+        double acc[nacc(P)];
 #pragma unroll
-    for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
-    if (i < n) {
-        const size_t ci = (size_t)chain * n + i;
-        const double2 xz = c.Xv[ci];
-        const double eta = eta_project(xz, a);
-        c.eta[ci] = eta;
-        beta_site_terms<P>(c, chain, i, ctl.it, eta, acc);
+        for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
+        if (i < n) {
+            const size_t ci = (size_t)chain * n + i;
+            const double2 xz = c.Xv[ci];
+            const double eta = eta_project(xz, a);
+            c.eta[ci] = eta;
+            beta_site_terms<P>(c, chain, i, ctl.it, eta, acc);
+        }
+        block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
     }
-    block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
 }
 
 // The partial sums of beta's system from the chain's current eta, omega_b and z (occ_cond_beta: no projection).
@@ -1343,11 +1432,15 @@ __global__ void __launch_bounds__(256) k_beta_sums(OCC_KARGS)
     const int chain = tile.chain, blk = tile.blk;
     const Ctl ctl = scs[chain].ctl[e];
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
-    double acc[nacc(P)];
+    if constexpr (P == 0) {
+        beta_site_terms_g(c, chain, i, i < n, ctl.it, i < n ? c.eta[(size_t)chain * n + i] : 0.0, blk);
+    } else {
+        double acc[nacc(P)];
 #pragma unroll
-    for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
-    if (i < n) beta_site_terms<P>(c, chain, i, ctl.it, c.eta[(size_t)chain * n + i], acc);
-    block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
+        for (int t = 0; t < nacc(P); ++t) acc[t] = 0.0;
+        if (i < n) beta_site_terms<P>(c, chain, i, ctl.it, c.eta[(size_t)chain * n + i], acc);
+        block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
+    }
 }
 
 // One visit row of the omega_a update: omega_a ~ PG(1, w'alpha) when the site exists (z = 1 or a detection
@@ -1391,6 +1484,41 @@ __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc
     }
 }
 
+// ... generic path (run-time q): the same row terms, emitted one at a time
+template <int INJ>
+__device__ __forceinline__ void omega_a_row_g(const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int r, int blk)
+{
+    const int R = c.R, q = c.q;
+    PartialEmitter em{c.part_alpha + (size_t)chain * nacc(q) * c.nb_r, c.nb_r, blk, nacc(q)};
+    bool exists = false;
+    double om = 0.0, tt = 0.0;
+    const int rc = (r < R) ? r : 0;
+    if (r < R) {
+        const int info = c.row_site[r];
+        const int site = info & 0x7fffffff;
+        exists = (info < 0) || (c.z[(size_t)chain * c.n + site] != 0);
+        if (exists) {
+            double wa = 0.0;
+            for (int a = 0; a < q; ++a) wa = fma(c.Wt[(size_t)a * R + r], sc.alpha[a], wa);
+            if (INJ) {
+                om = c.omega_a[(size_t)chain * R + r];
+            } else {
+                Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
+                om = pg1_draw(cur, wa);
+                c.omega_a[(size_t)chain * R + r] = om;
+            }
+            tt = (double)c.yrow[r] - 0.5;
+        }
+    }
+    int t = 0;
+    for (int a = 0; a < q; ++a) {
+        const double wo = c.Wt[(size_t)a * R + rc] * om;
+        for (int b = a; b < q; ++b) em.emit(t++, exists ? wo * c.Wt[(size_t)b * R + rc] : 0.0);
+    }
+    for (int a = 0; a < q; ++a) em.emit(t++, exists ? c.Wt[(size_t)a * R + rc] * tt : 0.0);
+    em.finish();
+}
+
 template <int Q, int INJ = 0>
 __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 {
@@ -1400,9 +1528,13 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    double acc[nacc(Q)];
-    omega_a_row<Q, INJ>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
-    block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
+    if constexpr (Q == 0) {
+        omega_a_row_g<INJ>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, blk);
+    } else {
+        double acc[nacc(Q)];
+        omega_a_row<Q, INJ>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, acc);
+        block_partials<nacc(Q)>(acc, c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, c.nb_r, blk);
+    }
 }
 
 // alpha ~ N(A^-1 r, A^-1) from the partial sums of k_omega_a (logit.py:224): one block per chain, one wave per
@@ -1410,7 +1542,7 @@ __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 template <int INJ>
 __global__ void __launch_bounds__(512) k_alpha_draw(OCC_KARGS, int sync_on)
 {
-    __shared__ double s_red[NACC_MAX], s_U[MAXC * MAXC], s_work[2 * MAXC];
+    __shared__ double s_red[NACC_G], s_U[MAXG * MAXG], s_work[2 * MAXG];
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
@@ -1569,26 +1701,106 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     z_update_site<P>(c, sc.key, chain, i, it, beta, alpha, c.eta[(size_t)chain * n + i]);
 }
 
+// The z update of one site with run-time numbers of covariates (generic path); alpha and beta come from the chain's
+// scalars.  Same operations as z_update_site.
+template <int INJ>
+__device__ __forceinline__ void z_update_site_g(const Ctx &c, const ChainScalars &sc, int chain, int i, uint32_t it, double eta_i)
+{
+    const int sidx = c.site_sidx[i];
+    const bool not_surveyed = sidx < 0;
+    if (!not_surveyed && c.obs_site[sidx]) return;
+    const int n = c.n, P = c.p, Q = c.q;
+    double xb = 0.0;
+    for (int a = 0; a < P; ++a) xb = fma(c.Xt[(size_t)a * n + i], sc.beta[a], xb);
+    const double num1 = expit(xb + eta_i);
+    double pr = num1;
+    if (!not_surveyed) {
+        double prod = 1.0;
+        const int r0 = c.site_ptr[sidx], r1 = c.site_ptr[sidx + 1];
+        for (int r = r0; r < r1; ++r) {
+            double wa = 0.0;
+            for (int a = 0; a < Q; ++a) wa = fma(c.Wt[(size_t)a * c.R + r], -sc.alpha[a], wa);
+            const double ex = expit(wa);
+            prod = (r == r0) ? ex : prod * ex;
+        }
+        const double num = num1 * prod;
+        pr = num / ((1.0 - num1) + num);
+    }
+    const double u = INJ ? c.inj->z_u[i] : block_uniform(sc.key, (uint32_t)i, 0, it, STREAM_Z);
+    c.z[(size_t)chain * n + i] = (u < pr) ? 1 : 0;
+}
+
+// k_z_ob of the generic path: beta has been drawn by k_beta_draw<0> (the previous kernel of the stream); this path never
+// runs with the device-counter hand-overs (it is not taken by the fused kernel nor by the reduced-rank model).
+__device__ __forceinline__ void z_ob_body_g(const Ctx &c, ChainScalars *__restrict__ scs, int chain_base, int e, bool per_wave, int debug_skip)
+{
+    const Tile tile = tile_of_block(chain_base);
+    const int chain = tile.chain, blk = tile.blk;
+    ChainScalars &sc = scs[chain];
+    const Ctl ctl = sc.mid[e];
+    const bool skip = ctl.koff || ctl.it >= sc.it_stop || sc.err != 0;
+    const uint32_t it = ctl.it;
+    const bool writer = (blk == 0 && threadIdx.x == 0);
+    if (writer) {
+        Ctl nx = ctl;
+        if (!skip) nx.it = it + 1;
+        sc.ctl[e ^ 1] = nx;
+    }
+    if (skip) return;
+    if (blk & 1) {  // role 1: omega_b of the next iteration
+        if (debug_skip & 2) return;
+        omega_b_body_g(c, sc, chain, it + 1u, blk >> 1, per_wave);
+        return;
+    }
+    if (writer) {  // record (base.py:238-239)
+        const uint32_t rel = it - sc.it_base;
+        if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
+            double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(c.q + c.p + 1);
+            for (int a = 0; a < c.q; ++a) row[a] = sc.alpha[a];
+            for (int a = 0; a < c.p; ++a) row[c.q + a] = sc.beta[a];
+            row[c.q + c.p] = sc.tau;
+        }
+    }
+    const int n = c.n, i = (blk >> 1) * blockDim.x + threadIdx.x;
+    if (i >= n || (debug_skip & 1)) return;
+    z_update_site_g<0>(c, sc, chain, i, it, c.eta[(size_t)chain * n + i]);
+}
+
 // beta ~ N(A^-1 r, A^-1) of every chain by ONE wave per chain, for problems with so many partial sums (blocks) that
 // re-reducing them in every block of k_z_ob is what that kernel spends its time on (500x500: 977 x 5 sums read by each
 // of 1 954 blocks, 23 of its 76 us); k_z_ob then takes beta from the chain's scalars (flags bit 2).  The same reduction
 // order and the same precision_mvnorm_reg as k_z_ob's own draw: the same bits.
-template <int P>
-__global__ void __launch_bounds__(64) k_beta_draw(OCC_KARGS)
+// P = 0 (generic path, launched with 256 threads): the waves share the quantities of the reduction, one thread factors in LDS
+// (precision_mvnorm_dev, the run-time-dimension form k_alpha_draw uses).  INJ: the normals of occ_cond_beta.
+template <int P, int INJ = 0>
+__global__ void __launch_bounds__(256) k_beta_draw(OCC_KARGS)
 {
     const Ctx &c = *cp;
     const int chain = chain_base + blockIdx.x;
     ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.mid[e];
+    const Ctl ctl = INJ ? sc.ctl[e] : sc.mid[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    if constexpr (P == 0) {
+        __shared__ double s_red[NACC_G], s_U[MAXG * MAXG], s_work[2 * MAXG];
+        const int p = c.p;
+        reduce_partials_lds(c.part_beta + (size_t)chain * nacc(p) * c.nb_n, nacc(p), c.nb_n, s_red);
+        if (threadIdx.x == 0) {
+            const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + p * p;
+            const bool ok = precision_mvnorm_dev(p, s_red, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, s_U, s_work, sc.beta,
+                                                 INJ ? c.inj->beta_eps : nullptr);
+            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+        }
+        return;
+    } else {
     double sums[nacc(P)], beta[P];
     reduce_partials<nacc(P)>(c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, sums);
     const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + P * P;
-    const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, beta);
+    const bool ok = precision_mvnorm_reg<P>(sums, b_prec, b_pbm, sc.key, ctl.it, STREAM_BETA, beta, INJ ? c.inj->beta_eps : nullptr);
     if (threadIdx.x == 0) {
         if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
 #pragma unroll
         for (int a = 0; a < P; ++a) sc.beta[a] = beta[a];
+    }
     }
 }
 
@@ -1597,10 +1809,14 @@ __global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: s
 {
     __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
-    const bool synced = (flags & 1) && c.sync != nullptr;
-    // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
-    const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
-    z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0, (flags >> 3) & 3, (flags & 4) != 0);
+    if constexpr (P == 0) {
+        z_ob_body_g(c, scs, chain_base, e, (flags & 2) != 0, (flags >> 3) & 3);
+    } else {
+        const bool synced = (flags & 1) && c.sync != nullptr;
+        // this sequence's number: k_iter, the previous kernel of the stream, left it in SYNC_MAIN
+        const unsigned seq = synced ? c.sync[SYNC_MAIN] : 0u;
+        z_ob_body<P>(c, scs, chain_base, e, synced, seq, (flags & 2) != 0, (flags >> 3) & 3, (flags & 4) != 0);
+    }
 }
 
 
@@ -1616,6 +1832,11 @@ __global__ void __launch_bounds__(256) k_cond_beta_z(OCC_KARGS)
     ChainScalars &sc = scs[chain];
     const Inject &inj = *c.inj;
     const Ctl ctl = sc.ctl[e];
+    if constexpr (P == 0) {  // generic path: the beta draw is k_beta_draw<0, 1>'s; here only the z update
+        const int n = c.n, i = blk * blockDim.x + threadIdx.x;
+        if (inj.do_z && i < n) z_update_site_g<1>(c, sc, chain, i, ctl.it, c.eta[(size_t)chain * n + i]);
+        return;
+    } else {
     double beta[P];
     if (inj.do_beta) {
         double sums[nacc(P)];
@@ -1637,6 +1858,7 @@ __global__ void __launch_bounds__(256) k_cond_beta_z(OCC_KARGS)
     for (int a = 0; a < MAXC; ++a) alpha[a] = (a < c.q) ? sc.alpha[a] : 0.0;
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (i < n) z_update_site<P, 1>(c, sc.key, chain, i, ctl.it, beta, alpha, c.eta[(size_t)chain * n + i]);
+    }
 }
 
 // Variates of the generators above, element i from the sub-stream (key, i, iteration, stream) exactly as the kernels of the

@@ -858,8 +858,8 @@ int orc_update_eta(orc_sampler *s)
 int orc_update_beta(orc_sampler *s)
 {
     int p = s->p;
-    double A[16 * 16], r[16], eps[16], out[16];
-    if (p > 16) return ORC_ERR_CHOLESKY;
+    double A[64 * 64], r[64], eps[64], out[64];
+    if (p > 64) return ORC_ERR_CHOLESKY;
     orc_beta_system(s->n, p, s->X, s->omega_b, s->k, s->eta, s->b_prec, s->b_prec_by_mu, A, r);
     for (int j = 0; j < p; ++j) eps[j] = orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_BETA);
     if (orc_precision_mvnorm(p, r, A, eps, out)) return ORC_ERR_CHOLESKY;
@@ -889,8 +889,8 @@ int orc_update_omega_a(orc_sampler *s)
 int orc_update_alpha(orc_sampler *s)
 {
     int q = s->q;
-    double A[16 * 16], r[16], eps[16], out[16];
-    if (q > 16) return ORC_ERR_CHOLESKY;
+    double A[64 * 64], r[64], eps[64], out[64];
+    if (q > 64) return ORC_ERR_CHOLESKY;
     orc_alpha_system(s->S, q, s->site_ptr, s->exists_site, s->W, s->yrow, s->omega_a, s->a_prec,
                      s->a_prec_by_mu, A, r);
     for (int j = 0; j < q; ++j) eps[j] = orc_block_normal(s->key, (uint32_t)j, 0, s->iter, ORC_STREAM_ALPHA);

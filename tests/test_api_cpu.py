@@ -267,9 +267,10 @@ def test_sampler_with_no_step_method(small):
 def test_too_many_covariates_is_an_error(small):
     from occuspytial_amd import LogitICARGibbs
     Q, W, X, y = small
-    Xbig = np.hstack([X, np.ones((X.shape[0], 7))])
-    with pytest.raises(ValueError, match='at most 8'):
+    Xbig = np.hstack([X, np.ones((X.shape[0], 31))])
+    with pytest.raises(ValueError, match='at most 32'):
         LogitICARGibbs(Q, W, Xbig, y)
+    LogitICARGibbs(Q, W, np.hstack([X, np.ones((X.shape[0], 7))]), y)      # 9-32: the engine's generic kernels
 
 
 def test_distribution_helpers_match_the_reference_functions():

@@ -675,3 +675,40 @@ def test_reference_form_prior_draw_free_running_equals_edge_form_in_law(oracle):
     assert s._problem.prior_factor is not None
     post = s.sample(int(ch['size']), burnin=int(ch['burnin']), chains=4, progressbar=False)
     compare_with_reference(case, post['alpha'], post['beta'], post['tau'])
+
+
+@pytest.mark.parametrize('p, q', [(12, 12), (20, 3), (2, 11), (32, 32)])
+def test_more_than_eight_covariates_take_the_generic_kernels(oracle, p, q):
+    """The reference's conditionals take any number of covariates (distributions.pyx:42-110 factors an n x n system for
+    any n).  Up to 8 of each kind the engine keeps the p x p / q x q accumulators in registers; beyond that (to 32) the
+    generic instantiations run -- run-time p and q, the terms of the systems reduced one at a time, the Cholesky factor
+    in LDS -- on the launch-per-step path.  Three lock-step iterations against the oracle, two chains; then the
+    per-conditional entry points on the same sizes."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(17, 19, visits=6, p=p, q=q, random_state=p + q)
+    prob = FlatProblem(Q, W, X, y)
+    rng = np.random.default_rng(p)
+    starts = [dict(alpha=0.3 * rng.standard_normal(q), beta=0.3 * rng.standard_normal(p), tau=1.1,
+                   eta=(lambda e: e - e.mean())(rng.standard_normal(prob.n))) for _ in range(2)]
+    worst, stats = _lockstep_chains(oracle, prob, starts, [KEY + 1, KEY + 2], 3)
+    assert stats['persistent_solve'] == 0
+    eng = Engine(prob, [KEY + 1, KEY + 2])
+    for c, st in enumerate(starts):
+        eng.set_start(c, **st)
+    rec = eng.run(12, 2)                                # graph replay through the generic kernels
+    assert rec[0].shape == (2, 10, q) and rec[1].shape == (2, 10, p) and np.all(np.isfinite(rec[1])) and np.all(rec[2] > 0)
+    # injected-variate entry points at these sizes: beta and alpha draws against numpy on the same sums
+    st = starts[0]
+    eng.set_start(0, **st)
+    om = rng.uniform(0.05, 0.3, prob.n)
+    eps = rng.standard_normal(p)
+    beta = eng.cond_beta(om, eps)
+    z = eng.get('z')
+    A = (prob.X.T * om) @ prob.X + prob.b_prec
+    r = prob.X.T @ ((z - 0.5) - om * st['eta']) + prob.b_prec @ prob.b_mu
+    U = np.linalg.cholesky(A).T
+    want = np.linalg.solve(A, r) + np.linalg.solve(U, eps)          # distributions.pyx:95-105
+    assert np.allclose(beta, want, rtol=1e-9, atol=1e-11)
+    eng.close()
