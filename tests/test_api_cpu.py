@@ -355,3 +355,30 @@ def test_prior_draw_selection_on_the_host():
         dense_prior_factor(sparse.csr_matrix(np.triu(Q.toarray())))
     # the plain-array round trip (what a multi-process launch broadcasts) keeps the factor
     assert np.array_equal(FlatProblem.from_arrays(FlatProblem(Qg, W, X, y).to_arrays()).prior_factor, Eg)
+
+
+def test_diagnostics_against_closed_forms():
+    """The numpy diagnostics that stand where the reference calls arviz (posterior.py:63-76), against what theory says
+    for processes with known answers (arviz is not installed, so closed forms stand in for it): a stationary AR(1)
+    with coefficient rho has ESS = N (1 - rho) / (1 + rho) and MCSE of the mean sd / sqrt(ESS); iid draws have ESS = N;
+    the 94 % HDI of a standard normal is +-1.881; R-hat of well-mixed chains is 1; a shift of one sd between chains
+    gives R-hat = sqrt(1 + 5/12) ~ 1.2 for the bulk statistic (variance of {0, 1, 0, 1} shifts)."""
+    from occuspytial_amd import diagnostics as dg
+    rng = np.random.default_rng(7)
+    N, C = 40000, 4
+    for rho in (0.0, 0.5, 0.8):
+        x = np.zeros((C, N))
+        x[:, 0] = rng.standard_normal(C) / np.sqrt(1 - rho * rho)
+        e = rng.standard_normal((C, N))
+        for t in range(1, N):
+            x[:, t] = rho * x[:, t - 1] + e[:, t]
+        want = C * N * (1 - rho) / (1 + rho)
+        assert abs(dg.ess(x) / want - 1) < 0.12, (rho, dg.ess(x), want)
+        sd = 1 / np.sqrt(1 - rho * rho)
+        assert abs(dg.mcse_mean(x) / (sd / np.sqrt(want)) - 1) < 0.10
+        assert 0.999 < dg.rhat(x) < 1.005
+    iid = rng.standard_normal((C, N))
+    lo, hi = dg.hdi(iid)
+    assert abs(lo + 1.881) < 0.03 and abs(hi - 1.881) < 0.03
+    shifted = iid + np.array([0.0, 1.0, 0.0, 1.0])[:, None]
+    assert 1.10 < dg.rhat(shifted) < 1.25
