@@ -269,7 +269,11 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const int sync_on = probe ? 0 : (flags & 1);
     const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
     constexpr int WGT = W512 ? ITER_WG_XL : ITER_WG;
-    constexpr bool SHARE = W512 != 0;  // two waves per SIMD in this workgroup: wave 0 does the uniform work for all
+    // Wave 0 does the uniform work for all in the 8-wide-window forms (round 1: only where two waves share a SIMD).  The step's sums
+    // reach the first wave with its poll anyway (one XCD per chain); redundant scalar work in every wave costs each of them
+    // the MINRES state in registers (72 spilled registers in the 256-thread one-XCD form: 60x60 x 8 chains 76.9 k -> 94.4 k
+    // chain-it/s with wave 0 alone) and, any placement, four readers of all per-slice sums per workgroup where one will do.
+    constexpr bool SHARE = NW == 8;  // (the 16-wide window has one workgroup per CU and registers to spare: every wave for itself, as in round 1)
     __shared__ int s_flag, s_noise_ok;
     __shared__ double s_bcast[12];  // W512: tau, then the coefficients of the coming step, from wave 0 to the workgroup
     __shared__ Slot s_slot;         // W512: the MINRES scalar state (wave 0)
@@ -339,21 +343,41 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         return;
     }
 
-    // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads).
-    // Order: the partial sums of eta'Q eta are requested first, then EVERY load of the phase that does not need tau
-    // (the site's data, its matrix row, the warm start at the site and at its neighbours), and only then the lead wave
-    // draws tau -- a gamma variate, some 4 000 cycles of dependent f64 arithmetic -- while those loads are in flight.
+    // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
     PHASE_STAMP(0, 0)
-    double qv[4] = {0.0, 0.0, 0.0, 0.0};
-    if (lead) {  // (one round of four loads per lane covers 256 slices; more slices: the loop below the loads)
-        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int bb = lane + 64 * r;
-            const double t = pq[min(bb, a.nb_n - 1)];
-            qv[r] = (bb < a.nb_n) ? t : 0.0;
-        }
+    if (synced) {  // thread 0's wait for the side stream's noise kernel (started at kernel entry) is over: s_noise_ok is set
+        __syncthreads();
+        if (!s_noise_ok && writer) sc.err = -2;
     }
+    double tau = 0.0;
+    if (lead) {
+        double q = 0.0;
+        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
+        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bb = b0 + 64 * r;
+                const double t = pq[min(bb, a.nb_n - 1)];
+                v[r] = (bb < a.nb_n) ? t : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += v[r];
+        }
+        q = wave_sum(q);
+        const double rate = 0.5 * q + ia.tau_rate;
+        // tau's standard gamma variate was drawn one iteration ahead by k_noise (side stream), like the rest of the noise:
+        // 4 000 cycles of dependent f64 arithmetic that used to sit here, in front of every load of the phase
+        const double gvar = synced ? load_agent(&sc.tau_gamma[it & 1]) : sc.tau_gamma[it & 1];
+        tau = (1.0 / rate) * gvar;
+        if (writer) sc.tau = tau;
+        if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
+    }
+    if (SHARE) {
+        __syncthreads();
+        tau = s_bcast[0];
+    }
+    PHASE_STAMP(0, 1)
     // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
     // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
     // the site itself with coefficient 0; lanes past the last site read row n-1 and their buffer accesses fall
@@ -374,78 +398,30 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const double om = a.omega_b[it & 1][ci];
     const double zval = (double)ia.z[ci];
     const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
-    double2 x = X0[ic];
-    const double qd = a.qdiag[ic];
-    double vraw[NW];
-    int jraw[NW];
-#pragma unroll
-    for (int kk = 0; kk < NW; ++kk) {
-        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-        jraw[kk] = a.sell_col[slot];
-        vraw[kk] = a.sell_val[slot];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here: the scheduler must not sink them below the draw
-    if (synced) __syncthreads();  // thread 0's wait for the side stream's noise kernel is over: s_noise_ok is set
-    double tau = 0.0;
-    if (lead) {
-        double q = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) q += qv[r];
-        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
-        for (int b0 = lane + 256; b0 < a.nb_n; b0 += 256) {  // (more than 256 slices: same order as a plain loop)
-            double v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bb = b0 + 64 * r;
-                const double t = pq[min(bb, a.nb_n - 1)];
-                v[r] = (bb < a.nb_n) ? t : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q += v[r];
-        }
-        q = wave_sum(q);
-        const double rate = 0.5 * q + ia.tau_rate;
-        // the standard gamma variate was drawn one iteration ahead by k_noise (side stream), like the rest of the noise
-        // (synced: the wait for that kernel was started at kernel entry and has been looked at before this point)
-        double gvar;
-        if (synced) {
-            if (threadIdx.x == 0 && !s_noise_ok) sc.err = -2;
-            gvar = load_agent(&sc.tau_gamma[it & 1]);
-        } else {
-            gvar = sc.tau_gamma[it & 1];
-        }
-        tau = (1.0 / rate) * gvar;
-        if (writer) sc.tau = tau;
-        if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
-    }
-    if (SHARE) {
-        __syncthreads();
-        tau = s_bcast[0];
-    }
-    PHASE_STAMP(0, 1)
-    // second round of loads, one latency: the noise (it comes from the side stream: the wait for it was started at
-    // kernel entry) and the warm start at the neighbours (their columns arrived during the draw)
     double en, up;
     if (synced) {
-        if (!s_noise_ok && writer) sc.err = -2;
         en = load_agent(&ia.enorm[it & 1][ci]);
         up = load_agent(&ia.uprior[it & 1][ci]);
     } else {
         en = ia.enorm[it & 1][ci];
         up = ia.uprior[it & 1][ci];
     }
+    const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
+    double2 x = X0[ic];
+    const double d = tau * a.qdiag[ic] + om;
     double2 xn[NW];
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) {
         const bool has = act && kk < width;
-        const int j = has ? jraw[kk] : ic;
+        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+        const int jraw = a.sell_col[slot];
+        const double vraw = a.sell_val[slot];
+        const int j = has ? jraw : ic;
         off[kk] = has ? j * 16 : myoff;
-        av[kk] = has ? tau * vraw[kk] : 0.0;
+        av[kk] = has ? tau * vraw : 0.0;
         xn[kk] = X0[j];
         nm1[kk] = zero2; nm2[kk] = zero2;
     }
-    const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
-    const double d = tau * qd + om;
     double ax = d * x.x, az = d * x.y;
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) {
@@ -595,8 +571,8 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 }
                 SOLVE_STAMP(7)
                 double acc[4];
-                if (RPG == 2) { acc[0] = 0.0 + (lo[0].x + lo[1].x); acc[1] = 0.0 + (lo[0].y + lo[1].y); acc[2] = 0.0 + (hi[0].x + hi[1].x); acc[3] = 0.0 + (hi[0].y + hi[1].y); }
-                else { acc[0] = 0.0 + lo[0].x; acc[1] = 0.0 + lo[0].y; acc[2] = 0.0 + hi[0].x; acc[3] = 0.0 + hi[0].y; }  // (0.0 + x: the other paths start their lane sums from +0)
+                if (RPG == 2) { acc[0] = lo[0].x + lo[1].x; acc[1] = lo[0].y + lo[1].y; acc[2] = hi[0].x + hi[1].x; acc[3] = hi[0].y + hi[1].y; }
+                else { acc[0] = lo[0].x; acc[1] = lo[0].y; acc[2] = hi[0].x; acc[3] = hi[0].y; }
                 wave_sum4(acc);
                 S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
                 if (threadIdx.x == 0) {
@@ -633,23 +609,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-        {  // lane l sums group l of eight slices in tree order (sum8_tree), then the groups as wave_sum4 does
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            const int ngroups = (a.nb_n + 7) >> 3;
-            for (int g0 = lane; g0 < ngroups; g0 += 64) {
-                double2 lo[8], hi[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {  // (slices past the last one fall outside the descriptor: zeros)
-                    lo[j] = load_sc1(pbuf[k & 1], (g0 * 8 + j) * 32);
-                    hi[j] = load_sc1(pbuf[k & 1], (g0 * 8 + j) * 32 + 16);
-                }
-                acc[0] += ((lo[0].x + lo[1].x) + (lo[2].x + lo[3].x)) + ((lo[4].x + lo[5].x) + (lo[6].x + lo[7].x));
-                acc[1] += ((lo[0].y + lo[1].y) + (lo[2].y + lo[3].y)) + ((lo[4].y + lo[5].y) + (lo[6].y + lo[7].y));
-                acc[2] += ((hi[0].x + hi[1].x) + (hi[2].x + hi[3].x)) + ((hi[4].x + hi[5].x) + (hi[6].x + hi[7].x));
-                acc[3] += ((hi[0].y + hi[1].y) + (hi[2].y + hi[3].y)) + ((hi[4].y + hi[5].y) + (hi[6].y + hi[7].y));
-            }
+        if (lead) {  // the canonical order from per-slice sums (sum_slices_canonical in occ_kernels.hpp says why it is the same)
+            double acc[4];
+            sum_slices_canonical(a.nb_n, lane, acc, [&](int slice, double (&v)[4]) {
+                const double2 lo = load_sc1(pbuf[k & 1], slice * 32), hi = load_sc1(pbuf[k & 1], slice * 32 + 16);  // past the end: zeros
+                v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+            });
             SOLVE_STAMP(7)
-            wave_sum4(acc);
             S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
         }
         SOLVE_STAMP(8)

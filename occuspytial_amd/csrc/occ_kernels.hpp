@@ -230,6 +230,63 @@ __device__ __forceinline__ void wave_sum4(double (&v)[4])
     }
 }
 
+// The canonical order of the four MINRES sums over the 64-site slices of a chain, from PER-SLICE sums with coalesced loads
+// (lane l of a wave takes slice 64 r + l of chunk r).  A plain wave_sum of a chunk is, level by level, (s0+s1), (+(s2+s3)),
+// then the half-mirror: the tree of eight consecutive slices ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) -- what a 512-thread
+// workgroup of the fused kernel's one-XCD form leaves in its record -- and its last three levels combine the chunk's eight
+// groups as ((G0+G1)+(G2+G3)) + ((G4+G5)+(G6+G7)) -- what the first three levels of that form's wave sum over its records
+// (lane = group) do.  The chunk sums C_r of up to eight chunks (512 slices) are then combined as ((C0+C1)+(C2+C3)) +
+// ((C4+C5)+(C6+C7)) -- that wave sum's last three levels.  (Beyond 512 slices: a cheaper order, see the code.)  Floating-point addition is commutative, so the mirrored operand orders inside wave_sum do
+// not matter; every path (k_iter one XCD per chain / any placement, k_minres at 64 threads per block) returns the same bits.
+// `load(slice, v)` fills the four sums of a slice (zeros past the last one).
+template <class F>
+__device__ __forceinline__ void sum_slices_canonical(int nslices, int lane, double (&tot)[4], F load)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[q] = 0.0;
+    if (nslices > 512) {
+        // more than 512 slices (32 768 sites): the one-XCD form never runs, so only k_minres and the any-placement form have
+        // to agree -- on the cheap order: every lane adds its slices l, l + 64, ... in turn, ONE wave sum at the end (a wave
+        // sum per 64-slice chunk cost the 250x250 solve 2 us per step)
+        for (int b0 = lane; b0 < nslices; b0 += 256) {
+            double v[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load(b0 + 64 * r, v[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tot[q] += v[r][q];
+            }
+        }
+        wave_sum4(tot);
+        return;
+    }
+    for (int base = 0; base < nslices; base += 512) {
+        double half[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) half[h][q] = 0.0;
+            if (base + 256 * h >= nslices) continue;  // (uniform)
+            double v[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load(base + 256 * h + 64 * r + lane, v[r]);  // four chunks of loads in flight
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (base + 256 * h + 64 * r < nslices) wave_sum4(v[r]);                // (uniform; an absent chunk holds zeros)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) half[h][q] = (v[0][q] + v[1][q]) + (v[2][q] + v[3][q]);
+        }
+        if (base == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tot[q] = half[0][q] + half[1][q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tot[q] += half[0][q] + half[1][q];
+        }
+    }
+}
+
 // XCD-aware workgroup -> (chain, tile) map.  MI355X deals workgroups round-robin over its 8 XCDs (each
 // with a private L2), so with the plain map consecutive tiles of one chain land on 8 different L2s and
 // every neighbour gather of the lattice re-fetches its lines into several of them (measured: fabric
@@ -1114,25 +1171,16 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         const double *part = a.part_kry + ((size_t)chain * 2 + (kl & 1)) * ((size_t)4 * a.nb_n);
         const int ln = threadIdx.x & 63;
         if (blockDim.x == 64) {
-            // 64-site slices (the sizes the fused kernel also runs): the order of occ_iter.hpp's step exchange -- lane l
-            // sums group l of eight slices as ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), then the groups as wave_sum does --
-            // so that every path returns the same bits
-            const int ngroups = (a.nb_n + 7) >> 3;
-            for (int g0 = ln; g0 < ngroups; g0 += 64) {
-                double v[4][8];
+            // 64-site slices (the sizes the fused kernel also runs): the canonical order (sum_slices_canonical); the totals are
+            // uniform already, S0..xn2 below take them as they are
+            sum_slices_canonical(a.nb_n, ln, S, [&](int slice, double (&v)[4]) {
+                const int bc = min(slice, a.nb_n - 1);
 #pragma unroll
                 for (int qi = 0; qi < 4; ++qi) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int b = g0 * 8 + j;
-                        const double t = part[qi * a.nb_n + min(b, a.nb_n - 1)];
-                        v[qi][j] = (b < a.nb_n) ? t : 0.0;
-                    }
+                    const double t = part[qi * a.nb_n + bc];
+                    v[qi] = (slice < a.nb_n) ? t : 0.0;
                 }
-#pragma unroll
-                for (int qi = 0; qi < 4; ++qi)
-                    S[qi] += ((v[qi][0] + v[qi][1]) + (v[qi][2] + v[qi][3])) + ((v[qi][4] + v[qi][5]) + (v[qi][6] + v[qi][7]));
-            }
+            });
         } else
         // four rounds of loads in flight (a plain "load, add" loop waits for every round trip in turn: 15 of them at
         // 500x500); the sums are accumulated in the same order, rounds past the end add an exact 0
@@ -1232,9 +1280,11 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
     {
         __shared__ double s_S[4];
-        if (blockDim.x == 64 || threadIdx.x < 64) {
+        if (blockDim.x == 64) {  // (already the totals, in the canonical order)
+            S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3];
+        } else if (threadIdx.x < 64) {
             S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]);
-            if (blockDim.x != 64 && threadIdx.x == 0) { s_S[0] = S0; s_S[1] = S1; s_S[2] = S2; s_S[3] = xn2; }
+            if (threadIdx.x == 0) { s_S[0] = S0; s_S[1] = S1; s_S[2] = S2; s_S[3] = xn2; }
         }
         if (blockDim.x != 64) {  // wave 0 reduced; the other waves take the totals from LDS
             __syncthreads();
