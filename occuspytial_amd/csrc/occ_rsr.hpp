@@ -394,8 +394,8 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
     if (tid == 0) {
         const double quad = ((rh[0] + rh[1]) + rh[2]) + rh[3];
         const double rate = 0.5 * quad + a.tau_rate;
-        Cursor g(sc.key, 0u, it, STREAM_TAU);
-        const double tau = (1.0 / rate) * std_gamma(g, a.tau_shape);
+        // the standard gamma variate of this iteration was drawn ahead by k_noise (like the ICAR path: occ_kernels.hpp)
+        const double tau = (1.0 / rate) * load_agent(&sc.tau_gamma[it & 1]);
         sc.tau = tau;
         s_scalar[0] = tau;
         s_scalar[1] = sqrt(tau);

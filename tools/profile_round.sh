@@ -34,7 +34,15 @@ python3 bench.py $C4 2> $out/c4_bench.err | tail -n 1 > profiles/${tag}_c4_bench
 run rocprofv3 --kernel-trace --stats --output-format csv -d $out/rsr_stats -- python3 tools/rsr_time.py 40 50 100 4 2000 > $out/rsr.log 2> $out/rsr_stats.log
 cp "$(ls -t $out/rsr_stats/*/*kernel_stats.csv | head -n 1)" profiles/${tag}_rsr_kernel_stats.csv
 tail -n 1 $out/rsr.log > profiles/${tag}_rsr_bench.txt
-# 5. the plain bench line (not profiled), cpu_baseline included
+# 5. other sizes and paths, one line each (chain-iterations/s; which path every case takes): BASELINE configs 1, 3 (its 8
+#    chains on one GPU), 4, 5, the any-placement form and the launch-per-step path on the headline workload
+{
+  python3 tools/sizes.py 20,20,1,2000 60,60,8,1500 100,100,1,1500 100,100,2,1500 100,100,4,2000 100,100,8,1500 100,100,16,600 250,250,1,400 500,500,1,300
+  python3 tools/c5.py 4
+  echo "OCC_NO_XCD_LOCAL=1 (any placement):"; OCC_NO_XCD_LOCAL=1 python3 tools/sizes.py 100,100,4,1000
+  echo "OCC_NO_PERSISTENT=1 (one launch per MINRES step):"; OCC_NO_PERSISTENT=1 python3 tools/sizes.py 100,100,4,1000
+} > profiles/${tag}_sizes.txt 2> $out/sizes.err
+# 6. the plain bench line (not profiled), cpu_baseline included
 python3 bench.py 2> $out/bench.err | tail -n 1 > profiles/${tag}_bench.json
 cp $out/commands.log profiles/${tag}_commands.log
 cat profiles/${tag}_bench.json
