@@ -1539,8 +1539,10 @@ int occ_create_group(const occ_problem *problem, int32_t n_devices, const int32_
             if (ss[g]->fixed_list[i].second != ss[0]->fixed_list[i].second) return fail(OCC_E_HIP, "internal: the samplers of a group disagree on their arrays");
     }
     std::string transport = "single device";
-    if (n_devices > 1) {
-        const char *force = std::getenv("OCC_GROUP_TRANSPORT");
+    const char *force = std::getenv("OCC_GROUP_TRANSPORT");
+    // (OCC_GROUP_TRANSPORT=rccl runs the RCCL broadcast for a group of ONE device too: an in-place broadcast among one
+    // rank, which is how a one-GPU box exercises ncclCommInitAll and the grouped ncclBroadcast calls)
+    if (n_devices > 1 || (force && std::string(force) == "rccl")) {
         bool done = false;
         std::string why;
         if (!(force && std::string(force) == "peer") && rccl().ok()) {

@@ -40,6 +40,23 @@ def test_group_of_one_device_equals_plain_engine():
     grp.close()
 
 
+def test_group_broadcast_through_rccl_with_one_device(monkeypatch):
+    """OCC_GROUP_TRANSPORT=rccl: the in-process group path through librccl for real -- dlopen, ncclCommInitAll, one grouped
+    ncclBroadcast per fixed array on the sampler's own (CU-masked) stream, ncclCommDestroy -- with the one device this box
+    has (an in-place broadcast among one rank); the arrays must come out untouched: same chains as a plain engine."""
+    from occuspytial_amd._engine import Engine, EngineGroup
+    monkeypatch.setenv('OCC_GROUP_TRANSPORT', 'rccl')
+    prob, _ = _problem_from_golden('ref_queen400_v3')
+    keys = [KEY + c for c in range(3)]
+    plain = Engine(prob, keys)
+    ref = _run(plain, prob, 3)
+    plain.close()
+    grp = EngineGroup(prob, keys, [0])
+    assert grp.transport.startswith('rccl broadcast (ncclCommInitAll), 1 devices'), grp.transport
+    _same(ref, _run(grp, prob, 3))
+    grp.close()
+
+
 @pytest.mark.parametrize('transport', ['peer', 'default'])
 def test_chains_sharded_over_two_samplers_equal_one_batch(monkeypatch, transport):
     """Two samplers of one group (both on device 0: the box has one GPU): the second receives the laid-out arrays
