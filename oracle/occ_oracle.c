@@ -273,6 +273,12 @@ double orc_std_gamma_draw(uint64_t key, uint32_t iter, uint32_t stream, double s
     cursor_t c = cursor_open(key, 0, iter, stream);
     return std_gamma(&c, shape);
 }
+/* ... from the sub-stream of `index` (the tau conditional uses index 0) */
+double orc_std_gamma_draw_at(uint64_t key, uint32_t index, uint32_t iter, uint32_t stream, double shape)
+{
+    cursor_t c = cursor_open(key, index, iter, stream);
+    return std_gamma(&c, shape);
+}
 
 /* ================================================================================================
  * Reference pieces
@@ -823,6 +829,8 @@ __attribute__((optimize("O3"))) static void dense_matvec(long n, long m, const d
  * with E the n x (n-1) eigenfactor of Q the caller computed (E E' = Q; numpy eigh on the host) and eps_2 the n-1 standard
  * normals of Philox stream ORC_STREAM_ETA_DENSE.  E is borrowed, not copied.  NULL switches back to the edge form. */
 void orc_set_dense_eigen(orc_sampler *s, const double *E) { s->dense_E = E; }
+/* a new Philox key for the chain's variate streams (the engine's occ_set_keys) */
+void orc_set_key(orc_sampler *s, uint64_t key) { s->key = key; }
 
 int orc_update_eta(orc_sampler *s)
 {

@@ -47,6 +47,7 @@ double orc_block_uniform(uint64_t key, uint32_t c0, uint32_t c1, uint32_t iter, 
 /* sequential draws from the (index, iter, stream) sub-stream */
 void orc_pg1_array(uint64_t key, uint32_t iter, uint32_t stream, long n, const double *z, double *out);
 double orc_std_gamma_draw(uint64_t key, uint32_t iter, uint32_t stream, double shape);
+double orc_std_gamma_draw_at(uint64_t key, uint32_t index, uint32_t iter, uint32_t stream, double shape);
 
 /* ---- reference pieces with injected variates --------------------------------------------------- */
 /* logit.py:208  rate = 0.5 * eta' Q eta + tau_rate */
@@ -121,5 +122,6 @@ int orc_set_rsr(orc_sampler *s, int r, const double *K, const double *Qr, const 
 /* reference-faithful prior draw of the eta conditional (logit.py:64-67, 77): dense eigenfactor E (n x (n-1), row-major,
  * E E' = Q, borrowed); the build's own form is the edge factorisation (orc_edge_prior_term).  Same law either way. */
 void orc_set_dense_eigen(orc_sampler *s, const double *E);
+void orc_set_key(orc_sampler *s, uint64_t key);
 
 #endif
