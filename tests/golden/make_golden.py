@@ -3,7 +3,9 @@
 
 Run in the build container only (needs ``/root/reference``; the GPU box never has it)::
 
-    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py                 # writes the per-conditional fixtures tests/golden/ref_*.npz
+    python tests/golden/make_golden.py --chains-only   # writes the whole-chain fixtures tests/golden/refchain_*.npz
+                                                       # (--with-chains: both)
 
 What runs, and what does not:
 
