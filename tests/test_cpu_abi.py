@@ -21,7 +21,8 @@ ABI_LIB = os.path.join(ROOT, 'oracle', 'liboccoracle_abi.so')
 def cpu_abi(monkeypatch, oracle):
     """Point occuspytial_amd._lib at the oracle's build of the C ABI for the duration of one test."""
     from occuspytial_amd import _lib
-    assert os.path.exists(ABI_LIB), 'make -C oracle'
+    if not os.path.exists(ABI_LIB) or os.path.getmtime(ABI_LIB) < os.path.getmtime(os.path.join(ROOT, 'oracle', 'occ_oracle_abi.c')):
+        oracle.build()                            # make -C oracle (idempotent)
     monkeypatch.setattr(_lib, 'LIB_PATH', ABI_LIB)
     monkeypatch.setattr(_lib, '_lib', None)
     lib = _lib.load()
