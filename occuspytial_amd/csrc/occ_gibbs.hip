@@ -292,8 +292,14 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
-            if (s->xcd_local && s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG_XL), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
-            else if (s->xcd_local) hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)s->iter.nbg), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+            if (s->xcd_local) {  // eight chains (one per XCD) per launch; more chains: the next eight right behind
+                for (int base = 0; base < c.C; base += XL_SLOTS) {
+                    IterArgs ia = s->iter;
+                    ia.chain_base = base;
+                    if (s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)ia.nbg), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)ia.nbg), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                }
+            }
             else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
             else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
             break;
@@ -1001,7 +1007,9 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         {
             const int ncu = prop.multiProcessorCount, nbg512 = (n + ITER_WG_XL - 1) / ITER_WG_XL;
             const int base = (ncu * 5 / 64) * 8;  // 160 of 256
-            const bool xl_ok = fused_ok && s->iter_window == 8 && C <= XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
+            // (more than eight chains: launches of eight, one behind the other -- 16 chains at 100x100 then run 2 x 60 us where
+            // the launch-per-step path took 374)
+            const bool xl_ok = fused_ok && s->iter_window == 8 && C <= 8 * XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
             auto part = [&](int per_xcd) { return std::max(32 * ((per_xcd + 3) / 4), base); };
             s->xl_candidate = false;
             if (xl_ok && nbg <= base / XL_SLOTS) {

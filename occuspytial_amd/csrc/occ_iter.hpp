@@ -80,6 +80,7 @@ struct IterArgs {
     double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
     double *rec;          // [C][3][XL_MAX_WG][4] per-workgroup records of the XL step exchange
     int nbg;              // workgroups per chain
+    int chain_base;       // one XCD per chain: first chain of this launch (more than eight chains run as several launches of eight)
     int C, p, q;
 };
 
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     // grid = (nbg, C), the chain is blockIdx.y; XL: grid = (8, nbg), the chain is blockIdx.x (a scalar register
     // either way: the buffer descriptors below must be provably wave-uniform, or every buffer access becomes a
     // serialising waterfall loop)
-    const int chain = XL ? (int)blockIdx.x : (int)blockIdx.y, wg = XL ? (int)blockIdx.y : (int)blockIdx.x;
+    const int chain = XL ? ia.chain_base + (int)blockIdx.x : (int)blockIdx.y, wg = XL ? (int)blockIdx.y : (int)blockIdx.x;
     if (XL && chain >= ia.C) return;  // the grid walks over all eight XCDs, the chains may be fewer
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said

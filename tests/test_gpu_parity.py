@@ -163,7 +163,7 @@ def test_batched_chains_equal_single_chain_runs():
     batch.close()
 
 
-@pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40), ((60, 60), 8, 30), ((30, 40), 10, 20)])
+@pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40), ((60, 60), 8, 30), ((30, 40), 10, 20), ((50, 50), 19, 20)])
 def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, iters):
     """k_iter exchanges g between the workgroups of a chain -- one XCD per chain: plain stores, L1-bypassing loads
     and one arrival flag per workgroup through that XCD's L2; any placement: write-through stores, L1-bypassing
@@ -185,8 +185,9 @@ def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, latti
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = Engine(prob, keys)
-        # 2: one XCD per chain (at most 8 chains, at most 64 workgroups per chain), 1: any placement, 0: launch per step
-        assert eng.stats()['persistent_solve'] == {'xcd_local': 2 if chains <= 8 else 1, 'any_placement': 1, 'launch_per_step': 0}[mode]
+        # 2: one XCD per chain (at most 64 workgroups per chain; more than 8 chains: launches of eight one behind the other),
+        # 1: any placement, 0: launch per step
+        assert eng.stats()['persistent_solve'] == {'xcd_local': 2, 'any_placement': 1, 'launch_per_step': 0}[mode]
         for c in range(chains):
             eng.set_start(c, **starts[c])
         rec = eng.run(iters, 0)
