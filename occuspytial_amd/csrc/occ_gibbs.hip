@@ -79,6 +79,9 @@ struct occ_sampler {
     bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
     int xl_nbg = 0;          // workgroups per chain of the XCD-local form
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
+    int xl_per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... per XCD, when the XCDs that host a chain get more than the others (first entry 0: evenly)
+    int main_hot_cus = 0;    // CUs the main stream's mask holds on XCD 0 (a chain's XCD)
+    int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
     // partition.  launch_sync = false makes launch_kind() launch kernels that neither wait nor publish
@@ -263,6 +266,14 @@ static const char *kind_name(int kind)
 
 // One kernel launch (all chains).  A launch the runtime rejects (bad grid, too much dynamic LDS, ...) is reported at
 // once -- also during stream capture -- instead of surfacing later as stale results or a barrier time-out.
+// Grid of a kernel that hands out its tiles in proportion to the CUs its stream owns on each XCD (tile_of_block_shared,
+// kernel `kid` of Ctx::tile_first): 8 x the largest share; the plain (per_chain, C) grid when the XCDs are treated alike.
+static dim3 shared_grid(const Ctx &c, int kid, int per_chain)
+{
+    if (!c.share_on) return dim3((unsigned)per_chain, (unsigned)c.C);
+    return dim3(8u * (unsigned)c.tile_most[kid]);
+}
+
 int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
 {
     const Ctx &c = s->ctx;
@@ -272,7 +283,7 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     switch (kind) {
         case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(tp), gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE:
-            hipLaunchKernelGGL(k_noise, gs, blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
+            hipLaunchKernelGGL(k_noise, shared_grid(c, 2, c.nb_n), blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
             if (c.dense_F != nullptr) {  // reference-form prior draw: uprior = F eps2, four chains per pass over F
                 const dim3 gd((unsigned)((c.n + 3) / 4));
                 for (int ch0 = 0; ch0 < c.C; ch0 += 4) hipLaunchKernelGGL(k_prior_dense<4>, gd, dim3(256), 0, st, s->ctx_dev, s->ctx.sc, ch0, e, extra);
@@ -281,7 +292,7 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(tp), gs, blk, lds_p, st, OCC_ARGS, extra); break;
-        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), gr, blk, lds_q, st, OCC_ARGS); break;
+        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), shared_grid(c, 1, c.nb_r), blk, lds_q, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
@@ -296,8 +307,8 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                 for (int base = 0; base < c.C; base += XL_SLOTS) {
                     IterArgs ia = s->iter;
                     ia.chain_base = base;
-                    if (s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS, (unsigned)ia.nbg), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
-                    else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS, (unsigned)ia.nbg), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    if (s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                 }
             }
             else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
@@ -307,7 +318,8 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             if (s->tpb == 64) {  // 64-site slices (fused paths): 256-thread blocks, beta once per block, partial sums still per slice
                 const unsigned nb4 = (unsigned)((c.n + 255) / 256);
                 if (s->generic) hipLaunchKernelGGL((k_beta_draw<0, 0>), dim3((unsigned)c.C), dim3(256), 0, st, OCC_ARGS);
-                hipLaunchKernelGGL(pick_z_ob(tp), dim3(nb4 * 2, (unsigned)c.C), dim3(256), 0, st, OCC_ARGS, (s->launch_sync ? 1 : 0) | 2 | s->zob_debug);
+                hipLaunchKernelGGL(pick_z_ob(tp), s->generic ? dim3(nb4 * 2, (unsigned)c.C) : shared_grid(c, 0, (int)nb4 * 2), dim3(256), 0, st, OCC_ARGS,
+                                   (s->launch_sync ? 1 : 0) | 2 | s->zob_debug);
             } else {
                 if (s->generic) hipLaunchKernelGGL((k_beta_draw<0, 0>), dim3((unsigned)c.C), dim3(256), 0, st, OCC_ARGS);
                 else if (s->beta_split) hipLaunchKernelGGL(OCC_PICK_P(k_beta_draw, c.p), dim3((unsigned)c.C), dim3(64), 0, st, OCC_ARGS);
@@ -643,6 +655,9 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
         sc.keep = (uint32_t)keep;
         ctl.koff = 0;
     }
+    // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
+    // error may have left them anywhere)
+    if (s->ctx.claim) HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
     return write_scalars(s, h);
 }
 
@@ -657,6 +672,7 @@ int create_plain_streams(occ_sampler *s)
     HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
     s->main_cus = 0;
     s->flag_sync = false;
+    s->ctx.share_on = 0;
     return OCC_OK;
 }
 
@@ -684,6 +700,7 @@ int residency_probe(occ_sampler *s, bool *ok)
     int rc;
     for (int rep = 0; rep < 3 && *ok; ++rep) {
         s->iter_flags_extra = 2;
+        HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
         LAUNCH(s, s->stream, K_ITER, 0);
         s->iter_flags_extra = 0;
         if ((rc = take_launch_rc(s))) return rc;
@@ -693,6 +710,7 @@ int residency_probe(occ_sampler *s, bool *ok)
     }
     // the barrier state starts from scratch whatever the probes left behind
     HIP_TRY(fill_on(s, s->ctx.bar, 0, sizeof(unsigned) * (size_t)s->ctx.C * BAR_STRIDE));
+    HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
     if ((rc = read_scalars(s, h))) return rc;
     for (auto &sc : h) { sc.bar_base = 0; sc.err = 0; }
     return write_scalars(s, h);
@@ -1002,20 +1020,35 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // worth: an XCD deals a chain's workgroups round-robin over its four shader engines, so its CUs in the mask
         // must be a multiple of four (26 workgroups on 26 CUs per XCD dead-locked, on 28 they run).
         //   A  256-thread workgroups, one per CU            nbg <= 20
-        //   B  512-thread workgroups, one per CU            ceil(n / 512) <= 24, or <= 28 with at most two chains
+        //   B  512-thread workgroups (scalar wave + 448 sites), one per CU: ceil(n / 448) <= 28 CUs of the chain's XCD
         //   C  256-thread workgroups, two per CU            nbg <= 64 (partition of at most 24 CUs per XCD, else none)
+        // Form B with fewer than eight chains: only the XCDs that host a chain need that many CUs -- the others give the
+        // main stream fewer, so that the side stream keeps its share of the device (4 chains at 100x100: 24 CUs on four
+        // XCDs, 16 on the other four: 160 + 96 as before).
         {
-            const int ncu = prop.multiProcessorCount, nbg512 = (n + ITER_WG_XL - 1) / ITER_WG_XL;
+            const int ncu = prop.multiProcessorCount, nbg512 = (n + ITER_SITES_SW - 1) / ITER_SITES_SW;  // (one wave of the 512 threads owns no sites)
             const int base = (ncu * 5 / 64) * 8;  // 160 of 256
             // (more than eight chains: launches of eight, one behind the other -- 16 chains at 100x100 then run 2 x 60 us where
             // the launch-per-step path took 374)
             const bool xl_ok = fused_ok && s->iter_window == 8 && C <= 8 * XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
             auto part = [&](int per_xcd) { return std::max(32 * ((per_xcd + 3) / 4), base); };
             s->xl_candidate = false;
+            for (int x = 0; x < XL_SLOTS; ++x) s->xl_per_xcd[x] = 0;
+            const int need = 4 * ((nbg512 + 3) / 4), hot = std::min(C, XL_SLOTS), per_xcd = ncu / XL_SLOTS;
+            int wide_main = 0, wide_xcd[XL_SLOTS];
+            if (need <= per_xcd - 4) {  // the hot XCDs leave the side stream one CU per shader engine at least
+                int rest = need;
+                if (hot < XL_SLOTS) {
+                    rest = 4 * (int)std::lround((double)(base - hot * need) / (4.0 * (XL_SLOTS - hot)));
+                    rest = std::max(8, std::min(rest, need));
+                }
+                for (int x = 0; x < XL_SLOTS; ++x) { wide_xcd[x] = x < hot ? need : rest; wide_main += wide_xcd[x]; }
+            }
             if (xl_ok && nbg <= base / XL_SLOTS) {
                 s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 1; s->xl_main = base;
-            } else if (xl_ok && nbg512 <= 64 && (part(nbg512) <= ncu - 64 || (part(nbg512) <= ncu - 32 && C <= 2))) {
-                s->xl_candidate = true; s->xl_wide = true; s->xl_nbg = nbg512; s->xl_per_cu = 1; s->xl_main = part(nbg512);
+            } else if (xl_ok && nbg512 <= 64 && wide_main > 0 && wide_main <= ncu - 64) {
+                s->xl_candidate = true; s->xl_wide = true; s->xl_nbg = nbg512; s->xl_per_cu = 1; s->xl_main = wide_main;
+                for (int x = 0; x < XL_SLOTS; ++x) s->xl_per_xcd[x] = wide_xcd[x];
             } else if (xl_ok && nbg <= 64 && nbg <= 2 * (ncu / XL_SLOTS)) {
                 s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 2;
                 s->xl_main = part((nbg + 1) / 2) <= ncu - 64 ? part((nbg + 1) / 2) : 0;  // 0: no CU partition
@@ -1052,8 +1085,22 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 return set_error(s, OCC_E_BADARG, "OCC_CU_SPLIT must be 0 (no partition) or a multiple of 32 that leaves the side stream at least 32 CUs");
         }
         if ((s->persistent || pb->rsr_dim > 0) && s->side_enabled && nmain >= 8 && nmain <= ncu - 32) {
+            // bit i of a mask is CU i / 8 of XCD i % 8: the main stream takes the first per[x] CUs of XCD x
             std::vector<uint32_t> m_main((ncu + 31) / 32, 0u), m_side((ncu + 31) / 32, 0u);
-            for (int i = 0; i < ncu; ++i) (i < nmain ? m_main : m_side)[i / 32] |= 1u << (i % 32);
+            int per[XL_SLOTS];
+            for (int x = 0; x < XL_SLOTS; ++x) per[x] = (s->xl_candidate && s->xl_per_xcd[0] > 0 && !std::getenv("OCC_CU_SPLIT")) ? s->xl_per_xcd[x] : nmain / XL_SLOTS;
+            for (int i = 0; i < ncu; ++i) (i / XL_SLOTS < per[i % XL_SLOTS] ? m_main : m_side)[i / 32] |= 1u << (i % 32);
+            s->main_hot_cus = per[0];
+            // the XCDs' shares of each stream's CUs (tile_of_block_shared), when they differ; the tile tables follow
+            // once the block sizes are known
+            c.share_on = 0;
+            s->share_cum[0][0] = s->share_cum[1][0] = 0;
+            for (int x = 0; x < XL_SLOTS; ++x) {
+                s->share_cum[0][x + 1] = s->share_cum[0][x] + per[x];
+                s->share_cum[1][x + 1] = s->share_cum[1][x] + (ncu / XL_SLOTS - per[x]);
+                if (per[x] != per[0]) c.share_on = 1;
+            }
+            if (std::getenv("OCC_NO_XCD_SHARES")) c.share_on = 0;
             // a runtime that cannot mask CUs (an error here is not sticky) gets the unpartitioned streams below
             if (hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()) == hipSuccess) {
                 if (hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()) == hipSuccess) {
@@ -1077,7 +1124,8 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         s->any_fits = s->fused_fallback && (long long)s->iter.nbg * C <= (long long)(s->iter_window == 8 ? 2 : 1) * cus;
         s->nbg_any = s->iter.nbg;
         const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
-        if (!trust && s->xl_candidate && s->xl_nbg > s->xl_per_cu * (cus / XL_SLOTS)) s->xl_candidate = false;
+        const int hot_cus = s->main_cus > 0 ? s->main_hot_cus : prop.multiProcessorCount / XL_SLOTS;  // CUs of a chain's XCD
+        if (!trust && s->xl_candidate && s->xl_nbg > s->xl_per_cu * hot_cus) s->xl_candidate = false;
         s->persistent = s->xl_candidate || s->any_fits;
         if (!s->persistent) {
             tpb = s->tpb_plain;
@@ -1088,6 +1136,21 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     c.nb_n = (n + tpb - 1) / tpb;
     s->beta_split = tpb != 64 && c.nb_n >= 128 && !std::getenv("OCC_NO_BETA_SPLIT");
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
+    if (c.share_on) {  // tiles of the device-filling kernels per XCD, in proportion to the CUs of their stream
+        const int per_chain[3] = {tpb == 64 ? 2 * ((n + 255) / 256) : 2 * c.nb_n, c.nb_r, c.nb_n}, which[3] = {0, 1, 1};
+        c.surplus_last = 0;
+        if (const char *sl = std::getenv("OCC_DEBUG_SURPLUS_LAST")) c.surplus_last = std::atoi(sl);
+        if (const char *cw = std::getenv("OCC_DEBUG_MAIN_SHARE")) {  // developer knob: weight of an XCD without a chain in k_z_ob's shares
+            const int w = std::atoi(cw), hot = std::min(C, XL_SLOTS);
+            for (int x = hot; x < XL_SLOTS; ++x) s->share_cum[0][x + 1] = s->share_cum[0][x] + w;
+        }
+        for (int k = 0; k < 3; ++k) {
+            const long long T = (long long)per_chain[k] * C, W = s->share_cum[which[k]][8];
+            c.tile_most[k] = 0;
+            for (int x = 0; x <= XL_SLOTS; ++x) c.tile_first[k][x] = (int)(T * s->share_cum[which[k]][x] / W);
+            for (int x = 0; x < XL_SLOTS; ++x) c.tile_most[k] = std::max(c.tile_most[k], c.tile_first[k][x + 1] - c.tile_first[k][x]);
+        }
+    }
 
     // ---- device memory ------------------------------------------------------------------------------
     if ((rc = upload(s, &c.sell_ptr, sell_ptr))) return rc;
@@ -1141,6 +1204,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     if ((rc = dev_alloc(s, &c.sc, (size_t)C))) return rc;
     c.rec = nullptr;
     c.bar = nullptr;
+    c.claim = nullptr;
     c.iter_clock = nullptr;
     c.sync = nullptr;
     if (s->flag_sync) {
@@ -1151,8 +1215,9 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
         s->iter.clock = c.iter_clock;
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
+        if ((rc = dev_alloc(s, &c.claim, (size_t)C * 16))) return rc;
+        s->iter.claim = c.claim;
         if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 3 * c.nb_n * 4))) return rc;
-        if ((rc = dev_alloc(s, &s->iter.rec, (size_t)C * 3 * XL_MAX_WG * 4))) return rc;
         s->iter.bar = c.bar;
     }
 
@@ -1198,6 +1263,9 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
             s->iter.nbg = s->xl_nbg;
             ok = trust;
             if (!trust && (rc = residency_probe(s, &ok))) return rc;
+            if (std::getenv("OCC_VERBOSE"))
+                std::fprintf(stderr, "[occ] one XCD per chain: %d workgroups of %d threads per chain, main stream %d CUs (%d on a chain's XCD): %s\n",
+                             s->xl_nbg, s->xl_wide ? ITER_WG_XL : ITER_WG, s->main_cus, s->main_hot_cus, ok ? "resident" : "NOT resident");
             if (!ok) s->xcd_local = false;
         }
         if (!ok && s->any_fits) {

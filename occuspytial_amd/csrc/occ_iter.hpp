@@ -44,10 +44,11 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int ITER_WG = 256;                    // threads per workgroup of k_iter, any placement
 constexpr int ITER_WG_XL = 512;                 // ... one XCD per chain: two waves per SIMD IN one workgroup (see k_iter)
+constexpr int ITER_SITES_SW = 448;              // ... of which the first wave owns no sites (the scalar wave): seven site waves
 constexpr unsigned ITER_SPIN_LIMIT = 1u << 21;  // polls (about a microsecond each) before a barrier gives up
 constexpr unsigned ITER_PROBE_SPIN_LIMIT = 1u << 14;  // ... in the residency probe at creation (flags bit 1 of k_iter)
 constexpr int BAR_STRIDE = 64;                  // unsigned words per chain in IterArgs::bar: the counter, or one flag per workgroup
-constexpr int XL_MAX_WG = 64;                   // workgroups per chain of an XCD-local launch (one flag / record per lane of the polling wave)
+constexpr int XL_MAX_WG = 64;                   // workgroups per chain of an XCD-local launch (one flag per lane of the polling wave)
 constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch = XCDs the grid's x dimension walks over
 
 // Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
@@ -59,8 +60,11 @@ __device__ unsigned long long g_solve_stamps[STAMP_STEPS * STAMP_POINTS];
     if (chain == 0 && wg == 0 && threadIdx.x == 0 && k < STAMP_STEPS) g_solve_stamps[k * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
 #define PHASE_STAMP(row, pt)                                                                             \
     if (chain == 0 && wg == 0 && threadIdx.x == 0) g_solve_stamps[(row) * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
+#define SITE_STAMP(pt)                                                                                   \
+    if (chain == 0 && wg == 0 && threadIdx.x == 64 && k < STAMP_STEPS) g_solve_stamps[k * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
 #else
 #define SOLVE_STAMP(pt)
+#define SITE_STAMP(pt)
 #define PHASE_STAMP(row, pt)
 #endif
 
@@ -75,10 +79,10 @@ struct IterArgs {
     double *part_beta;
     double tau_rate, tau_shape;
     unsigned *bar;        // [C][BAR_STRIDE]
+    unsigned *claim;      // [C][16] one XCD per chain: the next free workgroup slot of the chain
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
     double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
-    double *rec;          // [C][3][XL_MAX_WG][4] per-workgroup records of the XL step exchange
     int nbg;              // workgroups per chain
     int chain_base;       // one XCD per chain: first chain of this launch (more than eight chains run as several launches of eight)
     int C, p, q;
@@ -106,19 +110,17 @@ __device__ __forceinline__ double2 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_o
     return unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
 
-// XL step exchange: a workgroup's record of a step IS its arrival flag.  The four sums of a step are combined in a fixed
-// TREE over groups of eight 64-site slices -- ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), then the groups in the order of
-// wave_sum4 -- the order every path uses (sum8_tree below: k_minres at 64 threads per block, the any-placement form), so
-// all of them return the same bits.  A 512-thread workgroup owns one group, a 256-thread one half a group: its waves
-// leave their wave sums in LDS, and after the workgroup barrier that follows every wave's `s_waitcnt vmcnt(0)` (its g
-// is in the XCD's L2) the first wave adds them and stores ONE record {S0, S1 | S2, S3} of two 16-byte halves.  A half that
-// still holds the CANARY (a NaN no sum can produce) has not arrived.  Records rotate through three buffers: in step k
-// the first wave puts canaries into its record of step k + 1 before that wait, so whoever sees a workgroup's record of
-// step k also sees its g and its canaries of step k + 1 -- no ordering assumption between different cache lines.  The
-// buffer of step k + 1 was last read in step k - 2: a workgroup is in step k only after every workgroup has stored
-// its record of step k - 1, which each did after it had read all of step k - 2.  The poller (the first wave) reads
-// the records of all workgroups of the chain, one or two per lane, until none shows the canary: ONE round trip where
-// "poll the flags, then load 157 per-slice sums" took two.
+// XL step exchange: a slice's record of a step IS its arrival flag.  Every site wave (one 64-site slice) adds up its four
+// sums of the step and, after its `s_waitcnt vmcnt(0)` (its g is in the XCD's L2), stores ONE record {S0, S1 | S2, S3} of
+// two 16-byte halves.  A half that still holds the CANARY (a NaN no sum can produce) has not arrived.  Records rotate
+// through three buffers: in step k a wave puts canaries into its record of step k + 1 before that wait, so whoever sees
+// a slice's record of step k also sees its g and its canaries of step k + 1 -- no ordering assumption between different
+// cache lines.  The buffer of step k + 1 was last read in step k - 2: a workgroup is in step k only after every slice
+// has stored its record of step k - 1, which each did after its workgroup had read all of step k - 2.  The poller (one
+// wave per workgroup) reads the records of all slices of the chain, lane l those of slices l, l + 64, ..., until none
+// shows the canary, adding them up as it goes (poll_slice_records): ONE round trip where "poll the flags, then load the
+// per-slice sums" took two, and no reduction inside the workgroup on the way (round 2 had one record per workgroup:
+// wave sums through LDS, a workgroup barrier and a tree that tied the summation order to 512-site workgroups).
 // 16-byte stores and loads are not torn (MI355X_MICROARCH.md, observed on gfx950); each half is checked on its own.
 __device__ __forceinline__ double2 rec_canary()
 {
@@ -249,15 +251,52 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
         default: { constexpr int D = 8; CALL; } break;                                                     \
     }
 
+// The poll of the one-XCD forms' step exchange: lane l reads the records of slices l, l + 64, ... of the chain (two
+// 16-byte halves each, L1 bypassed) until none shows the canary, and adds them up in the canonical order
+// (sum_slices_canonical: the same rounds, the same additions, one wave sum at the end).  Returns false when it gave up.
+__device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, int nslices, int lane, unsigned spin_limit, const ChainScalars &sc,
+                                                   double (&tot)[4])
+{
+    unsigned spins = 0;
+    for (;;) {
+        bool pend = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tot[q] = 0.0;
+        for (int base = 0; base < nslices; base += 256) {
+            double2 lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // (records past the last slice fall outside the descriptor: zeros)
+                lo[r] = load_sc1(buf, (base + 64 * r + lane) * 32);
+                hi[r] = load_sc1(buf, (base + 64 * r + lane) * 32 + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pend = pend || rec_pending(lo[r]) || rec_pending(hi[r]);
+                tot[0] += lo[r].x; tot[1] += lo[r].y; tot[2] += hi[r].x; tot[3] += hi[r].y;
+            }
+        }
+        if (!__any(pend)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit) return false;
+        if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;  // another workgroup gave up
+    }
+    wave_sum4(tot);
+    return true;
+}
+
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
 //
 // W512 (with XL, where a chain's waves outnumber the SIMDs its XCD gives the main stream) runs 512 threads per
-// workgroup: two waves share a SIMD, and
-// the f64 dependency chains of the scalar recurrence do not interleave -- two 256-thread workgroups per CU each ran
-// the whole recurrence and the second arrived a microsecond late at every barrier.  With both waves of a SIMD in
-// ONE workgroup the uniform work (tau, the re-reduction of the partial sums, minres_pre / minres_post) is done by
-// wave 0 alone, the others sleep at the workgroup barrier, and the step's coefficients travel through LDS.
+// workgroup, two waves per SIMD, as ONE SCALAR WAVE AND SEVEN SITE WAVES (448 sites).  A MINRES step is a chain of
+// dependent events -- sums of step k - 1 -> scalar recurrence (~100 dependent f64 instructions) -> coefficients ->
+// vectors -> sums -- and with the recurrence on a wave that also owns sites (round 2: wave 0 of eight site waves) every
+// wave of the chain waits for it: 45 % of a step.  Here the scalar wave owns no sites.  It polls the records, forms
+// `stop` and the three coefficients of p_{k-1} (minres_post_ab: the short half) and hands them over in LDS; while the
+// site waves form p and g = A p with them it runs the rotation of iteration k - 2 and the slot's update (minres_post_c),
+// hands over the rotation's coefficients for the w / x update that ends the site waves' step, prepares the next step
+// (minres_pre) and is polling again before the first record of the step arrives.  Per step: three workgroup barriers
+// (coefficients, rotation, poll done), no reduction through LDS (every site wave publishes its own record).
 //
 // flags: bit 0 = hand over to / from the side stream through the device counters; bit 1 = RESIDENCY PROBE: the launch
 // does nothing but one barrier among the workgroups of every chain, with a short time limit -- the same kernel, grid,
@@ -270,21 +309,39 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const int sync_on = probe ? 0 : (flags & 1);
     const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
     constexpr int WGT = W512 ? ITER_WG_XL : ITER_WG;
-    // Wave 0 does the uniform work for all in the 8-wide-window forms (round 1: only where two waves share a SIMD).  The step's sums
-    // reach the first wave with its poll anyway (one XCD per chain); redundant scalar work in every wave costs each of them
+    constexpr bool SW = W512 != 0;                       // scalar wave + seven site waves
+    constexpr int SITES_WG = SW ? ITER_SITES_SW : WGT;   // sites per workgroup
+    // Wave 0 does the uniform work for all in the 8-wide-window forms.  Redundant scalar work in every wave costs each of them
     // the MINRES state in registers (72 spilled registers in the 256-thread one-XCD form: 60x60 x 8 chains 76.9 k -> 94.4 k
     // chain-it/s with wave 0 alone) and, any placement, four readers of all per-slice sums per workgroup where one will do.
     constexpr bool SHARE = NW == 8;  // (the 16-wide window has one workgroup per CU and registers to spare: every wave for itself, as in round 1)
     __shared__ int s_flag, s_noise_ok;
-    __shared__ double s_bcast[12];  // W512: tau, then the coefficients of the coming step, from wave 0 to the workgroup
-    __shared__ Slot s_slot;         // W512: the MINRES scalar state (wave 0)
-    __shared__ double s_wsum[8][4]; // XL: the wave sums of a step, combined by the first wave
+    __shared__ double s_bcast[12];  // SHARE: tau, then the coefficients of the coming step, from wave 0 to the workgroup
+    __shared__ double s_rot[8];     // SW: the rotation's coefficients (second hand-over of a step)
+    __shared__ Slot s_slot;         // SHARE without a scalar wave: the MINRES scalar state (wave 0)
     const KryArgs &a = ia.a;
-    // grid = (nbg, C), the chain is blockIdx.y; XL: grid = (8, nbg), the chain is blockIdx.x (a scalar register
-    // either way: the buffer descriptors below must be provably wave-uniform, or every buffer access becomes a
-    // serialising waterfall loop)
-    const int chain = XL ? ia.chain_base + (int)blockIdx.x : (int)blockIdx.y, wg = XL ? (int)blockIdx.y : (int)blockIdx.x;
-    if (XL && chain >= ia.C) return;  // the grid walks over all eight XCDs, the chains may be fewer
+    // grid = (nbg, C), the chain is blockIdx.y (a scalar register: the buffer descriptors below must be provably
+    // wave-uniform, or every buffer access becomes a serialising waterfall loop).
+    // XL: the chain is THE XCD THE WORKGROUP RUNS ON (HW_REG_XCC_ID, also a scalar register) and its place among the chain's
+    // workgroups is claimed from a counter -- nothing is assumed about how the dispatcher deals a grid to the XCDs (round 2
+    // took chain = blockIdx.x of an (8, nbg) grid: true while every XCD can take its share of the grid at once, false
+    // as soon as the stream's CU mask gives the XCDs different numbers of CUs -- the form with a scalar wave wants 24 CUs
+    // on the XCDs that host a chain and leaves the others to the side stream).  The grid is 8 x (nbg + 1) workgroups:
+    // those on an XCD without a chain and those that find the chain complete return at once.
+    __shared__ int s_claim;
+    int chain, wg;
+    const unsigned my_xcc = XL ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) : 0u;  // HW_REG_XCC_ID
+    if (XL) {
+        if ((int)my_xcc >= min(ia.C - ia.chain_base, XL_SLOTS)) return;
+        chain = ia.chain_base + (int)my_xcc;
+        if (threadIdx.x == 0) s_claim = (int)__hip_atomic_fetch_add(ia.claim + (size_t)chain * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        wg = __builtin_amdgcn_readfirstlane(s_claim);
+        if (wg >= ia.nbg) return;
+    } else {
+        chain = (int)blockIdx.y;
+        wg = (int)blockIdx.x;
+    }
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
     // before anything can return or wait.
@@ -306,16 +363,18 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         s_noise_ok = sync_wait(ia.sync + SYNC_NOISE, j) ? 1 : 0;
     }
     const uint32_t it = ctl.it;
-    const int n = a.n, i = wg * WGT + (int)threadIdx.x;
+    // the scalar wave (SW): a wave-uniform fact the compiler can see (a scalar register), so that the two roles of the
+    // solve below are two loops, each with its own registers, not one loop under an execution mask
+    const bool scalar_wave = SW && __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+    const int n = a.n, i = scalar_wave ? n : wg * SITES_WG + (int)threadIdx.x - (SW ? 64 : 0);
     const bool lead = !SHARE || threadIdx.x < 64;  // the wave that does the uniform work
     const bool act = i < n;
-    const int lane = threadIdx.x & 63, slice = i >> 6;
+    const int lane = threadIdx.x & 63, slice = scalar_wave ? a.nb_n : (i >> 6);
     const bool slice_act = slice < a.nb_n;  // a slice with at least one site owns a partial sum
     const size_t co = (size_t)chain * n;
     const double2 zero2 = make_double2(0.0, 0.0);
     unsigned *cnt = ia.bar + (size_t)chain * BAR_STRIDE;
     const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)cnt, 0, ia.nbg * 4, 0x00020000);  // XL: the chain's flags
-    const unsigned my_xcc = XL ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) : 0u;  // HW_REG_XCC_ID
     (void)fbuf; (void)my_xcc;
     const unsigned bar_base = sc.bar_base;
     unsigned nbar = 0;  // barriers passed in this launch
@@ -323,20 +382,12 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[0] + co), 0, n * 16, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[1] + co), 0, n * 16, 0x00020000)};
     // per-slice records of the running solve {S0, S1 | S2, S3}: two buffers by step parity (any placement), three in
-    // rotation when the records double as arrival flags (XL, see "step exchange" below)
+    // rotation when the records double as arrival flags (XL, see "step exchange" above)
     double *part_base = ia.part + (size_t)chain * 3 * a.nb_n * 4;
     const __amdgpu_buffer_rsrc_t pbuf[3] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 8), 0, a.nb_n * 32, 0x00020000)};
-    // XL: one record per WORKGROUP, three buffers in rotation, in the flag block's line-aligned tail (BAR_STRIDE words
-    // of flags, then 3 x XL_MAX_WG x 32 bytes)
-    double *rec_base = ia.rec + (size_t)chain * 3 * XL_MAX_WG * 4;
-    const __amdgpu_buffer_rsrc_t rbuf[3] = {
-        __builtin_amdgcn_make_buffer_rsrc((void *)rec_base, 0, ia.nbg * 32, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(rec_base + (size_t)XL_MAX_WG * 4), 0, ia.nbg * 32, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(rec_base + (size_t)XL_MAX_WG * 8), 0, ia.nbg * 32, 0x00020000)};
-    (void)rbuf;
     if (probe) {  // residency / placement probe: one barrier, nothing else
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -346,9 +397,56 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 
     // ---- phase A: tau, right-hand side, p_0 = b - A x0 (all inputs come from earlier launches: plain loads)
     PHASE_STAMP(0, 0)
+    // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
+    // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
+    // the site itself with coefficient 0; lanes past the last site (and the scalar wave) read row n-1 and their buffer
+    // accesses fall outside the descriptors' range (loads return 0, stores are dropped).
+    // What does not depend on tau or on the noise is loaded FIRST: the site waves have it in flight while the lead wave
+    // draws tau.
+    int off[NW];      // byte offset of neighbour kk in a [n] double2 array
+    double av[NW];    // Q_ij, then tau * Q_ij
+    unsigned hasmask = 0u;
+    double2 nm1[NW], nm2[NW], ng[NW];
+    const int ic = act ? i : n - 1;             // clamped row for plain loads
+    const int myoff = act ? i * 16 : n * 16;    // byte offset of this site in the exchange buffers
+    int width, base;
+    {
+        const int sl = ic >> 6;
+        if (a.ell_w > 0) { width = a.ell_w; base = sl * a.ell_w * 64; }
+        else { base = a.sell_ptr[sl]; width = (a.sell_ptr[sl + 1] - base) >> 6; }
+    }
+    const size_t ci = co + ic;
+    const double2 *X0 = a.Xv + co;
+    const double om = a.omega_b[it & 1][ci];
+    const double zval = (double)ia.z[ci];
+    const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
+    double2 x = X0[ic];
+    const double qd = a.qdiag[ic];
+    double2 xn[NW];
+#pragma unroll
+    for (int kk = 0; kk < NW; ++kk) {
+        const bool has = act && kk < width;
+        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+        const int jraw = a.sell_col[slot];
+        const double vraw = a.sell_val[slot];
+        const int j = has ? jraw : ic;
+        off[kk] = has ? j * 16 : myoff;
+        av[kk] = vraw;
+        hasmask |= has ? (1u << kk) : 0u;
+        xn[kk] = X0[j];
+        nm1[kk] = zero2; nm2[kk] = zero2;
+    }
     if (synced) {  // thread 0's wait for the side stream's noise kernel (started at kernel entry) is over: s_noise_ok is set
         __syncthreads();
         if (!s_noise_ok && writer) sc.err = -2;
+    }
+    double en, up;
+    if (synced) {
+        en = load_agent(&ia.enorm[it & 1][ci]);
+        up = load_agent(&ia.uprior[it & 1][ci]);
+    } else {
+        en = ia.enorm[it & 1][ci];
+        up = ia.uprior[it & 1][ci];
     }
     double tau = 0.0;
     if (lead) {
@@ -379,50 +477,10 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         tau = s_bcast[0];
     }
     PHASE_STAMP(0, 1)
-    // Every memory operation of the solve role is issued unconditionally (no per-slot branch: a branch per
-    // gather makes the compiler wait for each load before it issues the next).  Unused neighbour slots point at
-    // the site itself with coefficient 0; lanes past the last site read row n-1 and their buffer accesses fall
-    // outside the descriptors' range (loads return 0, stores are dropped).
-    int off[NW];      // byte offset of neighbour kk in a [n] double2 array
-    double av[NW];    // tau * Q_ij
-    double2 nm1[NW], nm2[NW], ng[NW];
-    const int ic = act ? i : n - 1;             // clamped row for plain loads
-    const int myoff = act ? i * 16 : n * 16;    // byte offset of this site in the exchange buffers
-    int width, base;
-    {
-        const int sl = ic >> 6;
-        if (a.ell_w > 0) { width = a.ell_w; base = sl * a.ell_w * 64; }
-        else { base = a.sell_ptr[sl]; width = (a.sell_ptr[sl + 1] - base) >> 6; }
-    }
-    const size_t ci = co + ic;
-    const double2 *X0 = a.Xv + co;
-    const double om = a.omega_b[it & 1][ci];
-    const double zval = (double)ia.z[ci];
-    const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
-    double en, up;
-    if (synced) {
-        en = load_agent(&ia.enorm[it & 1][ci]);
-        up = load_agent(&ia.uprior[it & 1][ci]);
-    } else {
-        en = ia.enorm[it & 1][ci];
-        up = ia.uprior[it & 1][ci];
-    }
     const double y = eta_rhs_site(om, xb, zval, en, up, sqrt(tau));
-    double2 x = X0[ic];
-    const double d = tau * a.qdiag[ic] + om;
-    double2 xn[NW];
+    const double d = tau * qd + om;
 #pragma unroll
-    for (int kk = 0; kk < NW; ++kk) {
-        const bool has = act && kk < width;
-        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-        const int jraw = a.sell_col[slot];
-        const double vraw = a.sell_val[slot];
-        const int j = has ? jraw : ic;
-        off[kk] = has ? j * 16 : myoff;
-        av[kk] = has ? tau * vraw : 0.0;
-        xn[kk] = X0[j];
-        nm1[kk] = zero2; nm2[kk] = zero2;
-    }
+    for (int kk = 0; kk < NW; ++kk) av[kk] = ((hasmask >> kk) & 1u) ? tau * av[kk] : 0.0;
     double ax = d * x.x, az = d * x.y;
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) {
@@ -432,7 +490,8 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const double2 p0 = make_double2(y - ax, 1.0 - az);
     if (act) ia.rhs[ci] = y;
     store_x<XL>(gbuf[0], myoff, p0);
-    if (XL && threadIdx.x < 2) store_x<1>(rbuf[1], wg * 32 + (int)threadIdx.x * 16, rec_canary());  // step 1 polls these records
+    // XL: every site wave puts the canary into its slice's record of step 1 (the records step 1 polls)
+    if (XL && !scalar_wave && lane < 2) store_x<1>(pbuf[1], slice * 32 + lane * 16, rec_canary());
     PHASE_STAMP(0, 2)
     ++nbar;
     OCC_CHAIN_BARRIER(s_flag);
@@ -441,19 +500,125 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
 
-    // ---- phase B: MINRES.  The coefficients of step k come from the sums of step k - 1 (minres_post); the lead wave
-    // (W512: wave 0, else every wave for itself) forms them at the bottom of step k - 1 and, XL, hands them over in LDS.
-    // W512: the scalar state lives in LDS (only wave 0 touches it; in registers it would cost every wave 30 VGPRs)
+    // ---- phase B: MINRES.  The coefficients of step k come from the sums of step k - 1 (minres_post).
     Slot s_reg = {};
+    int k = 1;
+    double2 g = p0, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
+    if constexpr (SW) {
+        // ======== scalar wave + seven site waves.  Workgroup barriers of step k, in order:
+        //   B1  stop / coefficients of p_{k-1} are in s_bcast            (scalar wave: after minres_post_ab)
+        //   B2  the rotation's coefficients are in s_rot                 (scalar wave: after minres_post_c; site waves: after g)
+        //   B0  every record of step k has arrived (or the poll gave up: s_flag)
+        // Both roles leave the loop at the same place: after B1 (stop) or after B0 (failure).
+        // At step 1 the coefficients are ca = 1, cb = cc = 0: kry_form_p then returns its first argument -- p_0 at the
+        // site (g starts as p_0) and at its neighbours (ng holds p_0) -- exactly: the histories are zeros.
+        if (scalar_wave) {
+            Slot &s = s_reg;
+            KryMid mid;
+            KryPre pre = minres_pre(s);
+            KryStep st = minres_post_ab(s, pre, 1, 0.0, 0.0, 0.0, 0.0, a.maxiter, mid);
+            if (threadIdx.x == 0) { s_bcast[0] = 1.0; s_bcast[1] = 0.0; s_bcast[2] = 0.0; s_bcast[3] = 0.0; }
+            __syncthreads();  // B1 of step 1
+            for (; !failed; ++k) {
+                SOLVE_STAMP(0)
+                if (st.stop) break;
+                minres_post_c(s, pre, k, st, mid);
+                if (threadIdx.x == 0) {
+                    s_rot[0] = st.sj; s_rot[1] = st.oldeps; s_rot[2] = st.delta; s_rot[3] = st.denom; s_rot[4] = st.phi;
+                    s_rot[5] = st.rotate ? 1.0 : 0.0;
+                }
+                SOLVE_STAMP(1)
+                __syncthreads();  // B2
+                SOLVE_STAMP(2)
+                pre = minres_pre(s);  // the slot-only half of step k + 1, while the site waves finish step k
+                double acc[4];
+                const bool ok = poll_slice_records(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
+                SOLVE_STAMP(3)
+                if (threadIdx.x == 0) {
+                    s_flag = ok ? 0 : 1;
+                    if (!ok) chain_fail(sc);
+                }
+                __syncthreads();  // B0
+                SOLVE_STAMP(4)
+                if (!ok) { failed = true; break; }
+                st = minres_post_ab(s, pre, k + 1, acc[0], acc[1], acc[2], acc[3], a.maxiter, mid);
+                SOLVE_STAMP(5)
+                if (threadIdx.x == 0) { s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.stop ? 1.0 : 0.0; }
+                __syncthreads();  // B1 of step k + 1
+            }
+            if (writer) {
+                if (failed) { s.done = 1; s.istop = 6; s.itn = k; }
+                slot_store(&a.slots[(size_t)chain * NSLOT], s);
+                sc.minres_itn_last = s.itn;
+                sc.krylov_total += (unsigned long long)s.itn;
+                sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
+                sc.solves += 1ull;
+                if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
+            }
+        } else {
+            KryStep st = {};
+            __syncthreads();  // B1 of step 1
+            for (; !failed; ++k) {
+                SITE_STAMP(6)
+                st.ca = s_bcast[0]; st.cb = s_bcast[1]; st.cc = s_bcast[2];
+                if (s_bcast[3] != 0.0) break;
+                double part[4] = {0.0, 0.0, 0.0, 0.0};
+                {
+                    const double2 p = kry_form_p(st, g, pm2, pm1);  // p_{k-1}
+                    double gx = d * p.x, gy = d * p.y;
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const double2 pj = kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
+                        gx = fma(av[kk], pj.x, gx);
+                        gy = fma(av[kk], pj.y, gy);
+                        nm2[kk] = nm1[kk];
+                        nm1[kk] = pj;
+                    }
+                    g = make_double2(gx, gy);
+                    store_x<1>(gbuf[k & 1], myoff, g);
+                    if (lane < 2) store_x<1>(pbuf[(k + 1) % 3], slice * 32 + lane * 16, rec_canary());  // this slice's record of step k + 1
+                    part[0] = dot2(p, p);
+                    part[1] = fma(p.y, gy, p.x * gx);
+                    if (k >= 2) part[2] = dot2(p, pm1);
+                    SITE_STAMP(7)
+                    __syncthreads();  // B2 (p_{k-3} = pm2 is the rotation's operand: the history shifts after it)
+                    SITE_STAMP(8)
+                    if (s_rot[5] != 0.0) {  // w_{k-2}, x_{k-2}
+                        st.sj = s_rot[0]; st.oldeps = s_rot[1]; st.delta = s_rot[2]; st.denom = s_rot[3]; st.phi = s_rot[4];
+                        const double2 w = kry_form_w(st, pm2, wm2, wm1);
+                        x.x = fma(st.phi, w.x, x.x);
+                        x.y = fma(st.phi, w.y, x.y);
+                        wm2 = wm1;
+                        wm1 = w;
+                        part[3] = dot2(x, x);
+                    }
+                    pm2 = pm1;
+                    pm1 = p;
+                }
+                if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
+                wave_sum4(part);  // (a slice past the last site sums zeros)
+                SITE_STAMP(9)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g and its canaries of step k + 1 are in the XCD's L2
+                if (lane < 2) store_x<1>(pbuf[k % 3], slice * 32 + lane * 16, lane == 0 ? make_double2(part[0], part[1]) : make_double2(part[2], part[3]));
+                SITE_STAMP(10)
+                __syncthreads();  // B0
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the poll
+                if (s_flag) { failed = true; break; }
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
+                SITE_STAMP(11)
+                __syncthreads();  // B1 of step k + 1
+            }
+        }
+    } else {
+    // W512: the scalar state lives in LDS (only wave 0 touches it; in registers it would cost every wave 30 VGPRs)
     Slot &s = SHARE ? s_slot : s_reg;
     if (SHARE && threadIdx.x == 0) {
 #define X(f) s_slot.f = 0;
         OCC_SLOT_FIELDS(X)
 #undef X
     }
-    double2 g = zero2, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
-    int k = 1;
     KryPre pre = {};
     KryStep st = {};
 #define NEXT_STAMP(pt)
@@ -483,6 +648,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     } while (0)
     if (lead) pre = minres_pre(s);
     OCC_NEXT_STEP(1);
+    st.ca = 1.0;  // step 1: kry_form_p returns its first argument (p_0 at the site and at its neighbours) exactly
 #undef BAR_STAMP
 #define BAR_STAMP(pt) SOLVE_STAMP(pt)
     for (; !failed; ++k) {
@@ -499,11 +665,11 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             part[3] = dot2(x, x);
         }
         {
-            const double2 p = (k == 1) ? p0 : kry_form_p(st, g, pm2, pm1);  // p_{k-1}
+            const double2 p = kry_form_p(st, g, pm2, pm1);  // p_{k-1}
             double gx = d * p.x, gy = d * p.y;
 #pragma unroll
             for (int kk = 0; kk < NW; ++kk) {
-                const double2 pj = (k == 1) ? ng[kk] : kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
+                const double2 pj = kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
                 gx = fma(av[kk], pj.x, gx);
                 gy = fma(av[kk], pj.y, gy);
                 nm2[kk] = nm1[kk];
@@ -519,66 +685,27 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         }
         if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
         if (XL) {
-            // ---- records as arrival flags (see "XL step exchange" above)
-            constexpr int WPG = WGT / 64;  // waves (slices) per workgroup: 8, or 4 (two workgroups per group of eight slices)
-            const int rb = k % 3, rn = (k + 1) % 3, wave = (int)threadIdx.x >> 6;
-            if (threadIdx.x < 2) store_x<1>(rbuf[rn], wg * 32 + (int)threadIdx.x * 16, rec_canary());
+            // ---- records as arrival flags (see "XL step exchange" above): every wave publishes its slice's record
+            if (lane < 2) store_x<1>(pbuf[(k + 1) % 3], slice * 32 + lane * 16, rec_canary());
             wave_sum4(part);  // (a slice past the last site sums zeros)
-            if (lane == 0) { s_wsum[wave][0] = part[0]; s_wsum[wave][1] = part[1]; s_wsum[wave][2] = part[2]; s_wsum[wave][3] = part[3]; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g (and the canaries) are in the XCD's L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g and its canaries of step k + 1 are in the XCD's L2
+            if (lane < 2) store_x<1>(pbuf[k % 3], slice * 32 + lane * 16, lane == 0 ? make_double2(part[0], part[1]) : make_double2(part[2], part[3]));
             SOLVE_STAMP(2)
-            __syncthreads();
-            SOLVE_STAMP(3)
-            if (threadIdx.x < 2) {  // lane 0: {S0, S1}, lane 1: {S2, S3} of this workgroup's slices, in tree order
-                const int q0 = (int)threadIdx.x * 2;
-                double2 r;
-                if (WPG == 8) {
-                    r.x = ((s_wsum[0][q0] + s_wsum[1][q0]) + (s_wsum[2][q0] + s_wsum[3][q0])) + ((s_wsum[4][q0] + s_wsum[5][q0]) + (s_wsum[6][q0] + s_wsum[7][q0]));
-                    r.y = ((s_wsum[0][q0 + 1] + s_wsum[1][q0 + 1]) + (s_wsum[2][q0 + 1] + s_wsum[3][q0 + 1])) +
-                          ((s_wsum[4][q0 + 1] + s_wsum[5][q0 + 1]) + (s_wsum[6][q0 + 1] + s_wsum[7][q0 + 1]));
-                } else {
-                    r.x = (s_wsum[0][q0] + s_wsum[1][q0]) + (s_wsum[2][q0] + s_wsum[3][q0]);
-                    r.y = (s_wsum[0][q0 + 1] + s_wsum[1][q0 + 1]) + (s_wsum[2][q0 + 1] + s_wsum[3][q0 + 1]);
-                }
-                store_x<1>(rbuf[rb], wg * 32 + (int)threadIdx.x * 16, r);
-            }
-            SOLVE_STAMP(4)
-            if (lead) pre = minres_pre(s);  // the slot-only half of step k + 1, while the other workgroups arrive
+            if (lead) pre = minres_pre(s);  // the slot-only half of step k + 1, while the other slices arrive
             SOLVE_STAMP(9)
-            SOLVE_STAMP(5)
-            if (threadIdx.x < 64) {  // the first wave polls the records of the chain's workgroups (at most 64)
-                constexpr int RPG = 8 / WPG;  // records per group of eight slices: lane l reads group l
-                int fail_ = 0;
-                unsigned spins_ = 0;
-                double2 lo[RPG], hi[RPG];
-                for (;;) {
-#pragma unroll
-                    for (int r = 0; r < RPG; ++r) {  // (records past the last workgroup fall outside the descriptor: zeros)
-                        lo[r] = load_sc1(rbuf[rb], (lane * RPG + r) * 32);
-                        hi[r] = load_sc1(rbuf[rb], (lane * RPG + r) * 32 + 16);
-                    }
-                    bool pend = false;
-#pragma unroll
-                    for (int r = 0; r < RPG; ++r) pend = pend || rec_pending(lo[r]) || rec_pending(hi[r]);
-                    if (!__any(pend)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins_ > spin_limit) { fail_ = 1; break; }
-                    if ((spins_ & 1023u) == 0u && chain_err(sc) != 0) { fail_ = 1; break; }
-                }
+            if (threadIdx.x < 64) {  // the first wave polls the records of the chain's slices
+                double acc[4];
+                const bool ok = poll_slice_records(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
                 SOLVE_STAMP(6)
-                if (!fail_) {
+                if (ok) {
 #pragma unroll
                     for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
                 }
                 SOLVE_STAMP(7)
-                double acc[4];
-                if (RPG == 2) { acc[0] = lo[0].x + lo[1].x; acc[1] = lo[0].y + lo[1].y; acc[2] = hi[0].x + hi[1].x; acc[3] = hi[0].y + hi[1].y; }
-                else { acc[0] = lo[0].x; acc[1] = lo[0].y; acc[2] = hi[0].x; acc[3] = hi[0].y; }
-                wave_sum4(acc);
                 S0 = acc[0]; S1 = acc[1]; S2 = acc[2]; xn2 = acc[3];
                 if (threadIdx.x == 0) {
-                    s_flag = fail_;
-                    if (fail_) chain_fail(sc);
+                    s_flag = ok ? 0 : 1;
+                    if (!ok) chain_fail(sc);
                     if (!SHARE) { s_bcast[0] = S0; s_bcast[1] = S1; s_bcast[2] = S2; s_bcast[3] = xn2; }
                 }
             }
@@ -606,11 +733,9 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         SOLVE_STAMP(6)
         if (s_flag) { failed = true; break; }
         // ---- everything below reads what other workgroups published in this step: sc1 loads only
-        // (partial sums: four rounds of loads in flight at a time; rounds past the last slice fall outside the
-        // descriptor and read 0, which leaves the sums -- accumulated in slice order, as k_minres does -- unchanged)
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-        if (lead) {  // the canonical order from per-slice sums (sum_slices_canonical in occ_kernels.hpp says why it is the same)
+        if (lead) {  // the canonical order from per-slice sums
             double acc[4];
             sum_slices_canonical(a.nb_n, lane, acc, [&](int slice, double (&v)[4]) {
                 const double2 lo = load_sc1(pbuf[k & 1], slice * 32), hi = load_sc1(pbuf[k & 1], slice * 32 + 16);  // past the end: zeros
@@ -631,6 +756,16 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 #undef OCC_NEXT_STEP
 #undef BAR_STAMP
 #define BAR_STAMP(pt)
+    if (writer) {
+        if (failed) { s.done = 1; s.istop = 6; s.itn = k; }
+        slot_store(&a.slots[(size_t)chain * NSLOT], s);
+        sc.minres_itn_last = s.itn;
+        sc.krylov_total += (unsigned long long)s.itn;
+        sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
+        sc.solves += 1ull;
+        if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
+    }
+    }
 
     // ---- phase C: sum-to-zero projection, eta, partial sums of beta's system.  The solve stopped at the top
     // of step k, uniformly over the chain: buffers of parity k are free (everybody has passed barrier k-1).
@@ -667,7 +802,6 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         PHASE_STAMP(STAMP_STEPS - 1, 1)
     } else if (writer) {
         chain_fail(sc);  // OCC_E_HIP: the host falls back to one launch per MINRES step
-        s.done = 1; s.istop = 6; s.itn = k;
     }
     double eta = 0.0;
     if (act && !failed) {  // a failed solve leaves the warm start and eta as they were: the host re-runs the iteration
@@ -677,16 +811,10 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     }
     OCC_SWITCH_DIM(ia.p, beta_partials_slice<D>(ia, chain, i, act, slice, slice_act, om, eta, zval));
     if (writer) {
-        slot_store(&a.slots[(size_t)chain * NSLOT], s);
         Ctl m = ctl;
         m.koff = 0u;
         sc.mid[e] = m;
         sc.bar_base = bar_base + nbar * (XL ? 1u : (unsigned)ia.nbg);
-        sc.minres_itn_last = s.itn;
-        sc.krylov_total += (unsigned long long)s.itn;
-        sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
-        sc.solves += 1ull;
-        if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
         atomicMin(ia.clock, clk0);
         atomicMax(ia.clock + 1, (unsigned long long)wall_clock64());
     }

@@ -161,6 +161,7 @@ struct Ctx {
     ChainScalars *sc;   // [C]
     double *rec;        // [C][keep][q + p + 1]
     unsigned *bar;      // [C][32] barrier / ticket counters of k_iter (occ_iter.hpp); null: not used
+    unsigned *claim;    // [C][16] one XCD per chain: the next workgroup slot of the chain (k_iter claims, k_z_ob resets); null: not used
     // k_iter's own clock (constant-rate wall clock): {earliest start, latest end} of the running launch over
     // its chains, and {sum of launch durations, launches} since the last occ_run began.  k_iter's chain
     // writers fill the first pair, k_z_ob (the next kernel) folds it into the second.
@@ -175,6 +176,14 @@ struct Ctx {
     const double *dense_F;
     double *dense_eps[2];
     int dense_m;
+    // The streams' CU masks may give the XCDs different numbers of CUs (k_iter's scalar-wave form with fewer than eight
+    // chains: occ_gibbs.hip).  A grid is dealt to the XCDs in equal shares whatever they can take, so the kernels that fill
+    // the device (k_z_ob on the main stream; k_omega_a, k_noise on the side stream) then hand out their tiles in
+    // proportion to the CUs their stream owns there: tile_first[k][x] = first tile of XCD x for kernel k (0: k_z_ob, main
+    // stream; 1: k_omega_a, 2: k_noise, side stream), tile_most[k] = the largest share; share_on = 0: the plain map.
+    int share_on;
+    int tile_first[3][9], tile_most[3];
+    int surplus_last;  // bit k: kernel k's surplus workgroups come last (see tile_of_block_shared)
 };
 
 // ---- reductions ----------------------------------------------------------------------------------
@@ -230,61 +239,30 @@ __device__ __forceinline__ void wave_sum4(double (&v)[4])
     }
 }
 
-// The canonical order of the four MINRES sums over the 64-site slices of a chain, from PER-SLICE sums with coalesced loads
-// (lane l of a wave takes slice 64 r + l of chunk r).  A plain wave_sum of a chunk is, level by level, (s0+s1), (+(s2+s3)),
-// then the half-mirror: the tree of eight consecutive slices ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) -- what a 512-thread
-// workgroup of the fused kernel's one-XCD form leaves in its record -- and its last three levels combine the chunk's eight
-// groups as ((G0+G1)+(G2+G3)) + ((G4+G5)+(G6+G7)) -- what the first three levels of that form's wave sum over its records
-// (lane = group) do.  The chunk sums C_r of up to eight chunks (512 slices) are then combined as ((C0+C1)+(C2+C3)) +
-// ((C4+C5)+(C6+C7)) -- that wave sum's last three levels.  (Beyond 512 slices: a cheaper order, see the code.)  Floating-point addition is commutative, so the mirrored operand orders inside wave_sum do
-// not matter; every path (k_iter one XCD per chain / any placement, k_minres at 64 threads per block) returns the same bits.
+// The canonical order of the four MINRES sums over the 64-site slices of a chain, from PER-SLICE sums with coalesced loads:
+// lane l adds its slices l, l + 64, l + 128, ... in turn (four rounds of loads in flight), then ONE wave sum.  Every path
+// that has to return the same bits takes its totals here or in the same order (k_minres at 64 threads per block, k_iter
+// any placement; the one-XCD forms of k_iter while they poll the slices' records: poll_slice_records in occ_iter.hpp).  The
+// order does not depend on how slices are grouped into workgroups, so a form of the fused kernel may change its workgroup
+// size (448 sites beside a scalar wave, 256, 512) without changing a bit of the result.  (Round 2 had a tree over groups
+// of eight slices, which a 512-site workgroup could pre-reduce into one record; it tied the order to that workgroup size.)
 // `load(slice, v)` fills the four sums of a slice (zeros past the last one).
 template <class F>
 __device__ __forceinline__ void sum_slices_canonical(int nslices, int lane, double (&tot)[4], F load)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) tot[q] = 0.0;
-    if (nslices > 512) {
-        // more than 512 slices (32 768 sites): the one-XCD form never runs, so only k_minres and the any-placement form have
-        // to agree -- on the cheap order: every lane adds its slices l, l + 64, ... in turn, ONE wave sum at the end (a wave
-        // sum per 64-slice chunk cost the 250x250 solve 2 us per step)
-        for (int b0 = lane; b0 < nslices; b0 += 256) {
-            double v[4][4];
+    for (int base = 0; base < nslices; base += 256) {  // (uniform trip count: rounds past the end add exact zeros)
+        double v[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) load(b0 + 64 * r, v[r]);
+        for (int r = 0; r < 4; ++r) load(base + 64 * r + lane, v[r]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tot[q] += v[r][q];
-            }
-        }
-        wave_sum4(tot);
-        return;
-    }
-    for (int base = 0; base < nslices; base += 512) {
-        double half[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) half[h][q] = 0.0;
-            if (base + 256 * h >= nslices) continue;  // (uniform)
-            double v[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) load(base + 256 * h + 64 * r + lane, v[r]);  // four chunks of loads in flight
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (base + 256 * h + 64 * r < nslices) wave_sum4(v[r]);                // (uniform; an absent chunk holds zeros)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) half[h][q] = (v[0][q] + v[1][q]) + (v[2][q] + v[3][q]);
-        }
-        if (base == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tot[q] = half[0][q] + half[1][q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tot[q] += half[0][q] + half[1][q];
+            for (int q = 0; q < 4; ++q) tot[q] += v[r][q];
         }
     }
+    wave_sum4(tot);
 }
 
 // XCD-aware workgroup -> (chain, tile) map.  MI355X deals workgroups round-robin over its 8 XCDs (each
@@ -306,6 +284,29 @@ __device__ __forceinline__ Tile tile_of_block(int chain_base)
     Tile t;
     t.chain = chain_base + (int)(id / gx);
     t.blk = (int)(id % gx);
+    return t;
+}
+
+// ... with the tiles handed out in proportion to the CUs the stream owns on each XCD (Ctx::tile_first of kernel `kid`): a 1-D
+// grid of 8 x (largest share) workgroups, workgroup `lin` being the (lin / 8)-th of XCD lin % 8 -- that is how a grid is
+// dealt, strictly round-robin whatever the XCDs can take (tools/xcc_probe6); only speed depends on it, the map is a
+// bijection between workgroups and tiles either way.  An XCD with a smaller share returns its surplus workgroups
+// (chain = -1) FIRST: the dealing stalls on a workgroup whose XCD is full, so a surplus workgroup dealt late to a full XCD
+// held up the workgroups behind it that other XCDs still had room for (k_z_ob: a second round, 15 -> 22 us).
+__device__ __forceinline__ Tile tile_of_block_shared(const Ctx &c, int kid, int per_chain, int chain_base)
+{
+    if (!c.share_on) return tile_of_block(chain_base);
+    const int lin = (int)blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    const int first = c.tile_first[kid][xcd], surplus = c.tile_most[kid] - (c.tile_first[kid][xcd + 1] - first);
+    Tile t;
+    t.chain = -1;
+    t.blk = 0;
+    const bool last = (c.surplus_last >> kid) & 1;
+    if (last ? idx < c.tile_most[kid] - surplus : idx >= surplus) {
+        const int id = first + idx - (last ? 0 : surplus);
+        t.chain = chain_base + id / per_chain;
+        t.blk = id % per_chain;
+    }
     return t;
 }
 
@@ -815,14 +816,15 @@ __global__ void __launch_bounds__(256) k_prior_dense(const Ctx *__restrict__ cp,
 __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on)
 {
     const Ctx &c = *cp;
-    const Tile tile = tile_of_block(chain_base);
+    const Tile tile = tile_of_block_shared(c, 2, c.nb_n, chain_base);
     const int chain = tile.chain, blk = tile.blk;
-    const ChainScalars &sc = scs[chain];
     if (sync_on && c.sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const unsigned j = c.sync[SYNC_SIDE_SEQ];
         sync_set(c.sync + SYNC_ALPHA, j + 1u);  // k_alpha_draw of this sequence, the previous kernel of the stream, is complete
         c.sync[SYNC_SIDE_SEQ] = j + 1u;         // read next by k_gate, the next kernel of the stream
     }
+    if (chain < 0) return;
+    const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const uint32_t it_for = ctl.it + (uint32_t)ahead;
@@ -1002,15 +1004,27 @@ __device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, d
     }
     return false;
 }
-// (b) + (c): beta_{k-1}, alfa_{k-1}, the rotation of iteration k - 2 and the coefficients of step k
-__device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int k, double S0, double S1, double S2)
+// (a) + (b): the stopping test, beta_{k-1}, alfa_{k-1} -- `stop` and the coefficients of p_{k-1}, all that the vectors'
+// first half of step k (p_{k-1} at the site and its neighbours, g_k = A p_{k-1}) needs.  (c), the rotation of iteration
+// k - 2 and the slot's update, follows in minres_post_c: k_iter's scalar wave runs it while the site waves are busy with
+// that first half (occ_iter.hpp).  Called one after the other (minres_post) they are the unsplit step: the same
+// operations on the same operands.
+struct KryMid {
+    double beta_km1, beta_km2, alfa_km1;
+};
+__device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter,
+                                                  KryMid &mid)
 {
     KryStep st;
     st.ca = st.cb = st.cc = 0.0;
     st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
     st.rotate = false;
     st.stop = false;
-    const double eps = DBL_EPSILON;
+    mid.beta_km1 = mid.beta_km2 = mid.alfa_km1 = 0.0;
+    if (minres_post_a(s, q, k, xn2, maxiter)) {
+        st.stop = true;
+        return st;
+    }
     if (k >= 2) {  // (b)
         if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
             s.done = 1; s.istop = 0; s.itn = 0;
@@ -1020,17 +1034,30 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
         // beta_{k-1} = sqrt(S0) and its reciprocal from ONE reciprocal square root (the step is issue-bound on one SIMD:
         // sqrt + two divisions were 40 dependent instructions, this is 12)
         const double ibeta = rsqrt_nr(S0);
-        const double beta_km1 = S0 * ibeta;    // beta_{k-1}
-        const double beta_km2 = s.beta;        // beta_{k-2} (k >= 3)
+        mid.beta_km1 = S0 * ibeta;         // beta_{k-1}
+        mid.beta_km2 = s.beta;             // beta_{k-2} (k >= 3)
         double alfa_km1 = (S1 * ibeta) * ibeta;  // (p.g)/beta^2
         if (k >= 3) alfa_km1 = alfa_km1 - S2 * q.sj;
+        mid.alfa_km1 = alfa_km1;
+        st.ca = ibeta;
+        st.cc = alfa_km1 * st.ca;
+        if (k >= 3) st.cb = mid.beta_km1 * q.sj;
+    }
+    return st;
+}
+// (c): the rotation of iteration k - 2 (k >= 3) and the slot after step k
+__device__ __forceinline__ void minres_post_c(Slot &s, const KryPre &q, int k, KryStep &st, const KryMid &mid)
+{
+    const double eps = DBL_EPSILON;
+    if (k >= 2) {
+        const double beta_km1 = mid.beta_km1;
         if (k == 2) {
             s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
             s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
             s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
-        } else {  // (c) rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
+        } else {  // rotation of iteration j = k-2 with alfa_j (slot), beta_j (slot), beta_{j+1} (new)
             const int j = k - 2;
-            const double beta_j = beta_km2, beta_n = beta_km1;
+            const double beta_j = mid.beta_km2, beta_n = beta_km1;
             s.oldb = beta_j;
             s.tnorm2 += fma(beta_n, beta_n, q.t_ab);
             if (j == 1 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
@@ -1055,28 +1082,19 @@ __device__ __forceinline__ KryStep minres_post_bc(Slot &s, const KryPre &q, int 
             s.rhs2 = -s.epsln * zz;
             st.sj = q.sj;
             st.rotate = true;
-            st.cb = beta_km1 * q.sj;
         }
-        st.ca = ibeta;
-        st.cc = alfa_km1 * st.ca;
         s.beta = beta_km1;
         s.ibeta = st.ca;
-        s.alfa = alfa_km1;
+        s.alfa = mid.alfa_km1;
     }
     s.itn = k;
-    return st;
 }
 __device__ __forceinline__ KryStep minres_post(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter)
 {
-    if (minres_post_a(s, q, k, xn2, maxiter)) {
-        KryStep st;
-        st.ca = st.cb = st.cc = 0.0;
-        st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
-        st.rotate = false;
-        st.stop = true;
-        return st;
-    }
-    return minres_post_bc(s, q, k, S0, S1, S2);
+    KryMid mid;
+    KryStep st = minres_post_ab(s, q, k, S0, S1, S2, xn2, maxiter, mid);
+    if (!st.stop) minres_post_c(s, q, k, st, mid);
+    return st;
 }
 __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
 {
@@ -1573,8 +1591,9 @@ template <int Q, int INJ = 0>
 __global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
 {
     const Ctx &c = *cp;
-    const Tile tile = tile_of_block(chain_base);
+    const Tile tile = tile_of_block_shared(c, 1, c.nb_r, chain_base);
     const int chain = tile.chain, blk = tile.blk;
+    if (chain < 0) return;
     const ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
@@ -1671,8 +1690,9 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
 {
     __shared__ int s_wait_ok, s_beta_ok;
     __shared__ double s_beta[P];
-    const Tile tile = tile_of_block(chain_base);
+    const Tile tile = tile_of_block_shared(c, 0, 2 * (per_wave ? (c.n + (int)blockDim.x - 1) / (int)blockDim.x : c.nb_n), chain_base);
     const int chain = tile.chain, blk = tile.blk;
+    if (chain < 0) return;
     ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.mid[e];
     const bool skip = ctl.koff || ctl.it >= sc.it_stop || sc.err != 0;
@@ -1692,6 +1712,7 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
         }
         // the next sequence has the other parity: its kernels read the word this sequence's kernels do not
         if (chain == chain_base && synced) c.sync[SYNC_MAIN_SEQ + (e ^ 1)] = seq + 1u;
+        if (c.claim != nullptr) c.claim[(size_t)chain * 16] = 0u;  // k_iter of this sequence is complete: the next one claims its slots from 0
     }
     if (skip) return;
     double beta[P];
@@ -1855,7 +1876,7 @@ __global__ void __launch_bounds__(256) k_beta_draw(OCC_KARGS)
 }
 
 template <int P>
-__global__ void __launch_bounds__(256) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave, bit 2: beta ready
+__global__ void __launch_bounds__(256, 3) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave, bit 2: beta ready
 {
     __builtin_amdgcn_s_setprio(3);  // critical path (see k_minres)
     const Ctx &c = *cp;
