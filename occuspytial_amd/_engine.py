@@ -265,16 +265,17 @@ class Engine:
                 for i, k in enumerate(_lib.KERNEL_KINDS)}
 
 
-DRAW_KINDS = {'pg1': 0, 'std_gamma': 1, 'normal': 2, 'uniform': 3}
+DRAW_KINDS = {'pg1': 0, 'std_gamma': 1, 'normal': 2, 'uniform': 3, 'wave_sum_check': 4}
 
 
 def device_draw(kind, param=None, n=None, key=1, it=0, stream=1, device=0):
     """Variates of the engine's own generators drawn on the device (``occ_draw``): element ``i`` comes from the
     sub-stream ``(key, i, it, stream)`` exactly as the kernels draw it.  ``kind``: ``'pg1'`` (``param`` = z),
-    ``'std_gamma'`` (``param`` = shape), ``'normal'``, ``'uniform'`` (``n`` draws)."""
+    ``'std_gamma'`` (``param`` = shape), ``'normal'``, ``'uniform'`` (``n`` draws); ``'wave_sum_check'``: a device self-test
+    (tests/test_gpu_rng.py), NaN where the forms of the engine's wave sum disagree."""
     lib = _lib.load()
     par = None
-    if kind in ('pg1', 'std_gamma'):
+    if kind in ('pg1', 'std_gamma', 'wave_sum_check'):
         par = np.ascontiguousarray(param, dtype=np.float64).ravel()
         n = par.size
     out = np.empty(int(n))

@@ -2459,7 +2459,7 @@ int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out)
 // Device draws of the engine's own variate generators (see the header).
 int occ_draw(int32_t device, int32_t kind, uint64_t key, uint32_t iteration, uint32_t stream, int64_t n, const double *param, double *out)
 {
-    if (n < 0 || n > 0x7fffffffLL || !out || kind < 0 || kind > 3 || ((kind == 0 || kind == 1) && !param && n > 0)) {
+    if (n < 0 || n > 0x7fffffffLL || !out || kind < 0 || kind > 4 || ((kind == 0 || kind == 1 || kind == 4) && !param && n > 0) || (kind == 4 && n % 64 != 0)) {
         g_create_error = "occ_draw: bad arguments";
         return OCC_E_BADARG;
     }

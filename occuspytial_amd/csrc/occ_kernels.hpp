@@ -215,8 +215,9 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // Four wave sums at once, each in wave_sum's order (bit-identical to four calls): written level by level so that the four
 // independent dependency chains sit next to each other -- a DPP move has to wait for the add that feeds it, and four
-// calls in a row expose that wait 24 times.
-__device__ __forceinline__ void wave_sum4(double (&v)[4])
+// calls in a row expose that wait 24 times.  (Kept as the statement of the order; wave_sum4 below returns the same bits
+// with half the instructions.)
+__device__ __forceinline__ void wave_sum4_plain(double (&v)[4])
 {
 #define OCC_LEVEL(CTRL, MASK)                                                      \
     {                                                                               \
@@ -235,6 +236,59 @@ __device__ __forceinline__ void wave_sum4(double (&v)[4])
     for (int q = 0; q < 4; ++q) {
         const long long b = __double_as_longlong(v[q]);
         const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+        v[q] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
+    }
+}
+
+// The same four sums, the same additions -- (l0+l1), +(l2+l3) within a quad, quads by pairs within a row of 16, rows
+// (R0+R1), (R2+R3), then their sum -- with the four quantities TRANSPOSED over the lanes of a quad on the way: after the
+// first level a lane carries two of them (even lanes 0 and 1, odd lanes 2 and 3), after the second one, and the remaining
+// four levels move one value instead of four: 36 instructions where the plain form takes 80.  Those 80 were 40 % of what a
+// site wave of k_iter issues per MINRES step (two such waves share a SIMD) and sit once more on the polling wave's
+// path.  The last two levels exchange whole rows with v_permlane16_swap / v_permlane32_swap (gfx950).  Floating-point
+// addition is commutative: which lane holds a partial sum does not change its bits (tests/test_gpu_rng.py compares the
+// two forms on the device).
+typedef unsigned occ_v2u __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void wave_sum4(double (&v)[4])
+{
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool p1 = lane & 1u, p2 = lane & 2u;
+    // level 1 (lane ^ 1): even lanes keep quantities 0, 1 and take the neighbour's, odd lanes 2, 3
+    double a = p1 ? v[2] : v[0], b = p1 ? v[3] : v[1];
+    const double sa = p1 ? v[0] : v[2], sb = p1 ? v[1] : v[3];
+    a += dpp_move<0xB1>(sa);  // quad_perm [1,0,3,2]
+    b += dpp_move<0xB1>(sb);
+    // level 2 (lane ^ 2): lanes 0, 1 of a quad keep a (quantities 0, 2), lanes 2, 3 keep b (quantities 1, 3)
+    double c = p2 ? b : a;
+    const double sc = p2 ? a : b;
+    c += dpp_move<0x4E>(sc);  // quad_perm [2,3,0,1]: lane 4 j + t holds the sum of quad j of quantity {0, 2, 1, 3}[t]
+    c += dpp_move<0x114>(c);  // row_shr:4: quads 1 and 3 of a row hold Q0 + Q1, Q2 + Q3
+    c += dpp_move<0x118>(c);  // row_shr:8: quad 3 holds the row sum
+    {  // rows 1 and 3 take rows 0 and 2, then row 3 takes row 1
+        const long long bits = __double_as_longlong(c);
+        const occ_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)bits, (unsigned)bits, false, false);
+        const occ_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
+        c += __longlong_as_double(((long long)hi.x << 32) | lo.x);
+    }
+    {
+        const long long bits = __double_as_longlong(c);
+        const occ_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)bits, (unsigned)bits, false, false);
+        const occ_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
+        c += __longlong_as_double(((long long)hi.x << 32) | lo.x);
+    }
+    const long long bits = __double_as_longlong(c);
+    constexpr int src[4] = {60, 62, 61, 63};  // lanes 60 .. 63 hold quantities 0, 2, 1, 3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int lo = __builtin_amdgcn_readlane((int)bits, src[q]), hi = __builtin_amdgcn_readlane((int)(bits >> 32), src[q]);
         v[q] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // uniform
     }
 }
@@ -1012,8 +1066,10 @@ __device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, d
 struct KryMid {
     double beta_km1, beta_km2, alfa_km1;
 };
-__device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter,
-                                                  KryMid &mid)
+// (b) alone: it reads the slot (beta_{k-2}) and writes nothing to it unless the solve ends here (k == 2, beta1 == 0), so it
+// may run before (a) -- k_iter's scalar wave hands the coefficients over first and evaluates the stopping test while the
+// site waves already use them (a step too many when the test says stop: its results are dropped).
+__device__ __forceinline__ KryStep minres_post_b(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, KryMid &mid)
 {
     KryStep st;
     st.ca = st.cb = st.cc = 0.0;
@@ -1021,11 +1077,7 @@ __device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int 
     st.rotate = false;
     st.stop = false;
     mid.beta_km1 = mid.beta_km2 = mid.alfa_km1 = 0.0;
-    if (minres_post_a(s, q, k, xn2, maxiter)) {
-        st.stop = true;
-        return st;
-    }
-    if (k >= 2) {  // (b)
+    if (k >= 2) {
         if (k == 2 && S0 == 0.0) {  // beta1 == 0: x0 already solves the system (minres.py)
             s.done = 1; s.istop = 0; s.itn = 0;
             st.stop = true;
@@ -1044,6 +1096,20 @@ __device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int 
         if (k >= 3) st.cb = mid.beta_km1 * q.sj;
     }
     return st;
+}
+__device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int k, double S0, double S1, double S2, double xn2, long long maxiter,
+                                                  KryMid &mid)
+{
+    if (minres_post_a(s, q, k, xn2, maxiter)) {
+        KryStep st;
+        st.ca = st.cb = st.cc = 0.0;
+        st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
+        st.rotate = false;
+        st.stop = true;
+        mid.beta_km1 = mid.beta_km2 = mid.alfa_km1 = 0.0;
+        return st;
+    }
+    return minres_post_b(s, q, k, S0, S1, S2, mid);
 }
 // (c): the rotation of iteration k - 2 (k >= 3) and the slot after step k
 __device__ __forceinline__ void minres_post_c(Slot &s, const KryPre &q, int k, KryStep &st, const KryMid &mid)
@@ -1934,11 +2000,28 @@ __global__ void __launch_bounds__(256) k_cond_beta_z(OCC_KARGS)
 
 // Variates of the generators above, element i from the sub-stream (key, i, iteration, stream) exactly as the kernels of the
 // iteration draw them (occ_draw in the C ABI: known-answer and distributional tests on DEVICE draws).
-enum : int { DRAW_PG1 = 0, DRAW_STD_GAMMA = 1, DRAW_NORMAL = 2, DRAW_UNIFORM = 3 };
+enum : int { DRAW_PG1 = 0, DRAW_STD_GAMMA = 1, DRAW_NORMAL = 2, DRAW_UNIFORM = 3, DRAW_WAVE_SUM_CHECK = 4 };
 __global__ void __launch_bounds__(256) k_draw(int kind, uint64_t key, uint32_t it, uint32_t stream, long long n, const double *__restrict__ param,
                                               double *__restrict__ out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == DRAW_WAVE_SUM_CHECK) {  // (whole waves: n is a multiple of 64) the three forms of the wave sum agree bit for bit
+        double x[4], y[4], z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x[q] = (i < n) ? param[i] * (1.0 + 0.37 * q) + (q == 3 ? param[i] * param[i] : 0.0) : 0.0;
+            y[q] = x[q];
+            z[q] = wave_sum(x[q]);
+        }
+        wave_sum4(x);
+        wave_sum4_plain(y);
+        bool same = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            same = same && __double_as_longlong(x[q]) == __double_as_longlong(y[q]) && __double_as_longlong(x[q]) == __double_as_longlong(z[q]);
+        if (i < n) out[i] = same ? x[(int)(i & 3)] : __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
     if (i >= n) return;
     Cursor cur(key, (uint32_t)i, it, stream);
     double v;

@@ -109,3 +109,22 @@ def test_the_samplers_omega_b_kernel_draws_what_occ_draw_draws():
         x = om[j::5]
         assert abs(x.mean() - _pg_mean(z)) < 5 * np.sqrt(_pg_var(z) / x.size)
     eng.close()
+
+
+def test_wave_sum_forms_agree_bit_for_bit():
+    """The engine adds four quantities over a wave in one fixed order (wave_sum: DPP levels); the form k_iter and the
+    per-slice readers use transposes the quantities over the lanes of a quad and moves one value instead of four.
+    It must return the bits of the plain form and of four separate wave sums, whatever the data (magnitudes spread
+    over 60 binary orders, mixed signs, zeros)."""
+    from occuspytial_amd._engine import device_draw
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(64 * 512) * np.exp2(rng.integers(-30, 30, 64 * 512))
+    x[rng.random(x.size) < 0.05] = 0.0
+    out = device_draw('wave_sum_check', x)
+    assert not np.isnan(out).any()
+    # and the value is the sum it claims to be (quantity q of wave w: lanes with i % 4 == q report it)
+    w = x.reshape(-1, 64)
+    for q in range(4):
+        ref = (w * (1.0 + 0.37 * q) + (w * w if q == 3 else 0.0)).sum(axis=1)
+        got = out.reshape(-1, 64)[:, q]
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(w).max())
