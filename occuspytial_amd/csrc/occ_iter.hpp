@@ -497,8 +497,10 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     OCC_CHAIN_BARRIER(s_flag);
     PHASE_STAMP(0, 3)
     bool failed = s_flag != 0;
+    if (!SW) {
 #pragma unroll
-    for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
+        for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[0], off[kk]);  // p_0 at the neighbours: plays p_{k-1} at step 1
+    }
 
     // ---- phase B: MINRES.  The coefficients of step k come from the sums of step k - 1 (minres_post).
     Slot s_reg = {};
@@ -557,44 +559,50 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             }
         } else {
             KryStep st = {};
-            __syncthreads();  // B1 of step 1
-            for (; !failed; ++k) {
+            // One step.  The histories are passed in the roles they play in THIS step -- (h1, h2) = p_{k-2}, p_{k-3} at the
+            // neighbours, (q1, q2) the same at the site, (u1, u2) = w_{k-3}, w_{k-4} -- and the step leaves the new vector in
+            // the older one's registers; the loop below calls it with the roles swapped every other step.  (With one set of
+            // names and "older = newer; newer = new" at the end of the body the compiler moved 76 registers per step, a
+            // third of what a site wave issued.)  Returns false when the solve is over (stop or failure).
+            auto site_step = [&](double2 (&h1)[NW], double2 (&h2)[NW], double2 &q1, double2 &q2, double2 &u1, double2 &u2) -> bool {
+                // g_{k-1} at the neighbours (step 1: p_0), complete since the poll of step k - 1 (the chain barrier of phase A):
+                // the only place that loads it, so the loads land in the registers the step reads them from
+                double2 ng[NW];
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[(k - 1) & 1], off[kk]);
+                SITE_STAMP(11)
+                __syncthreads();  // B1
                 SITE_STAMP(6)
                 st.ca = s_bcast[0]; st.cb = s_bcast[1]; st.cc = s_bcast[2];
-                if (s_bcast[3] != 0.0) break;
+                if (s_bcast[3] != 0.0) return false;
                 double part[4] = {0.0, 0.0, 0.0, 0.0};
-                {
-                    const double2 p = kry_form_p(st, g, pm2, pm1);  // p_{k-1}
-                    double gx = d * p.x, gy = d * p.y;
+                const double2 p = kry_form_p(st, g, q2, q1);  // p_{k-1}
+                double gx = d * p.x, gy = d * p.y;
 #pragma unroll
-                    for (int kk = 0; kk < NW; ++kk) {
-                        const double2 pj = kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
-                        gx = fma(av[kk], pj.x, gx);
-                        gy = fma(av[kk], pj.y, gy);
-                        nm2[kk] = nm1[kk];
-                        nm1[kk] = pj;
-                    }
-                    g = make_double2(gx, gy);
-                    store_x<1>(gbuf[k & 1], myoff, g);
-                    if (lane < 2) store_x<1>(pbuf[(k + 1) % 3], slice * 32 + lane * 16, rec_canary());  // this slice's record of step k + 1
-                    part[0] = dot2(p, p);
-                    part[1] = fma(p.y, gy, p.x * gx);
-                    if (k >= 2) part[2] = dot2(p, pm1);
-                    SITE_STAMP(7)
-                    __syncthreads();  // B2 (p_{k-3} = pm2 is the rotation's operand: the history shifts after it)
-                    SITE_STAMP(8)
-                    if (s_rot[5] != 0.0) {  // w_{k-2}, x_{k-2}
-                        st.sj = s_rot[0]; st.oldeps = s_rot[1]; st.delta = s_rot[2]; st.denom = s_rot[3]; st.phi = s_rot[4];
-                        const double2 w = kry_form_w(st, pm2, wm2, wm1);
-                        x.x = fma(st.phi, w.x, x.x);
-                        x.y = fma(st.phi, w.y, x.y);
-                        wm2 = wm1;
-                        wm1 = w;
-                        part[3] = dot2(x, x);
-                    }
-                    pm2 = pm1;
-                    pm1 = p;
+                for (int kk = 0; kk < NW; ++kk) {
+                    const double2 pj = kry_form_p(st, ng[kk], h2[kk], h1[kk]);
+                    gx = fma(av[kk], pj.x, gx);
+                    gy = fma(av[kk], pj.y, gy);
+                    h2[kk] = pj;
                 }
+                g = make_double2(gx, gy);
+                store_x<1>(gbuf[k & 1], myoff, g);
+                if (lane < 2) store_x<1>(pbuf[(k + 1) % 3], slice * 32 + lane * 16, rec_canary());  // this slice's record of step k + 1
+                part[0] = dot2(p, p);
+                part[1] = fma(p.y, gy, p.x * gx);
+                if (k >= 2) part[2] = dot2(p, q1);
+                SITE_STAMP(7)
+                __syncthreads();  // B2 (p_{k-3} = q2 is the rotation's operand: p takes its place after it)
+                SITE_STAMP(8)
+                if (s_rot[5] != 0.0) {  // w_{k-2}, x_{k-2}  (before the first rotation both w's are zeros: the roles may swap)
+                    st.sj = s_rot[0]; st.oldeps = s_rot[1]; st.delta = s_rot[2]; st.denom = s_rot[3]; st.phi = s_rot[4];
+                    const double2 w = kry_form_w(st, q2, u2, u1);
+                    x.x = fma(st.phi, w.x, x.x);
+                    x.y = fma(st.phi, w.y, x.y);
+                    u2 = w;
+                    part[3] = dot2(x, x);
+                }
+                q2 = p;
                 if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
                 wave_sum4(part);  // (a slice past the last site sums zeros)
                 SITE_STAMP(9)
@@ -603,11 +611,14 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 SITE_STAMP(10)
                 __syncthreads();  // B0
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the poll
-                if (s_flag) { failed = true; break; }
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) ng[kk] = load_sc1(gbuf[k & 1], off[kk]);
-                SITE_STAMP(11)
-                __syncthreads();  // B1 of step k + 1
+                if (s_flag) { failed = true; return false; }
+                ++k;
+                return true;
+            };
+            if (failed) __syncthreads();  // (phase A gave up: the scalar wave's B1 of step 1 still stands)
+            while (!failed) {
+                if (!site_step(nm1, nm2, pm1, pm2, wm1, wm2)) break;
+                if (!site_step(nm2, nm1, pm2, pm1, wm2, wm1)) break;
             }
         }
     } else {
