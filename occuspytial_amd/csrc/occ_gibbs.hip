@@ -76,7 +76,8 @@ struct occ_sampler {
     double *inj_u = nullptr;    // [n] uniforms of occ_cond_z
     int snap_parity = 0;
     int64_t fused_fallbacks = 0;  // occ_run calls that were re-run on the launch-per-step path after a device-side time-out
-    bool xl_wide = false;    // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs)
+    int xl_wide = 0;         // ... with 512-thread workgroups (a chain needs more waves than its XCD's main-stream SIMDs): 1 = a scalar
+                             // wave beside seven site waves, 2 = eight site waves, the first one leads
     int xl_nbg = 0;          // workgroups per chain of the XCD-local form
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
     int xl_per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... per XCD, when the XCDs that host a chain get more than the others (first entry 0: evenly)
@@ -307,7 +308,8 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                 for (int base = 0; base < c.C; base += XL_SLOTS) {
                     IterArgs ia = s->iter;
                     ia.chain_base = base;
-                    if (s->xl_wide) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    if (s->xl_wide == 1) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    else if (s->xl_wide == 2) hipLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                 }
             }
@@ -1027,6 +1029,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // XCDs, 16 on the other four: 160 + 96 as before).
         {
             const int ncu = prop.multiProcessorCount, nbg512 = (n + ITER_SITES_SW - 1) / ITER_SITES_SW;  // (one wave of the 512 threads owns no sites)
+            const int nbg512p = (n + ITER_WG_XL - 1) / ITER_WG_XL;                                        // (eight site waves)
             const int base = (ncu * 5 / 64) * 8;  // 160 of 256
             // (more than eight chains: launches of eight, one behind the other -- 16 chains at 100x100 then run 2 x 60 us where
             // the launch-per-step path took 374)
@@ -1045,12 +1048,17 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 for (int x = 0; x < XL_SLOTS; ++x) { wide_xcd[x] = x < hot ? need : rest; wide_main += wide_xcd[x]; }
             }
             if (xl_ok && nbg <= base / XL_SLOTS) {
-                s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 1; s->xl_main = base;
-            } else if (xl_ok && nbg512 <= 64 && wide_main > 0 && wide_main <= ncu - 64) {
-                s->xl_candidate = true; s->xl_wide = true; s->xl_nbg = nbg512; s->xl_per_cu = 1; s->xl_main = wide_main;
+                s->xl_candidate = true; s->xl_wide = 0; s->xl_nbg = nbg; s->xl_per_cu = 1; s->xl_main = base;
+            } else if (xl_ok && nbg512 <= 64 && wide_main > 0 && wide_main <= ncu - 96 && hot <= 5 && !std::getenv("OCC_NO_SCALAR_WAVE")) {
+                // (the scalar wave's seventh of the sites costs CUs: taken while the side stream keeps its 96 and most of them on
+                // XCDs without a chain -- 100x100: 4 chains 70.0 us per iteration against 80.0 with eight site waves, 5 chains
+                // 80.3 / 81.8, 6 chains 99.3 / 82.3; 8 chains on 192 + 64 CUs 121.7 / 92.5, side-stream bound)
+                s->xl_candidate = true; s->xl_wide = 1; s->xl_nbg = nbg512; s->xl_per_cu = 1; s->xl_main = wide_main;
                 for (int x = 0; x < XL_SLOTS; ++x) s->xl_per_xcd[x] = wide_xcd[x];
+            } else if (xl_ok && nbg512p <= 64 && (part(nbg512p) <= ncu - 64 || (part(nbg512p) <= ncu - 32 && C <= 2))) {
+                s->xl_candidate = true; s->xl_wide = 2; s->xl_nbg = nbg512p; s->xl_per_cu = 1; s->xl_main = part(nbg512p);
             } else if (xl_ok && nbg <= 64 && nbg <= 2 * (ncu / XL_SLOTS)) {
-                s->xl_candidate = true; s->xl_wide = false; s->xl_nbg = nbg; s->xl_per_cu = 2;
+                s->xl_candidate = true; s->xl_wide = 0; s->xl_nbg = nbg; s->xl_per_cu = 2;
                 s->xl_main = part((nbg + 1) / 2) <= ncu - 64 ? part((nbg + 1) / 2) : 0;  // 0: no CU partition
             }
         }
@@ -1269,7 +1277,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
             if (!ok) s->xcd_local = false;
         }
         if (!ok && s->any_fits) {
-            s->xl_wide = false;
+            s->xl_wide = 0;
             s->iter.nbg = s->nbg_any;
             ok = trust;
             if (!trust && (rc = residency_probe(s, &ok))) return rc;

@@ -254,10 +254,49 @@ __device__ __forceinline__ void beta_partials_slice(const IterArgs &ia, int chai
 // The poll of the one-XCD forms' step exchange: lane l reads the records of slices l, l + 64, ... of the chain (two
 // 16-byte halves each, L1 bypassed) until none shows the canary, and adds them up in the canonical order
 // (sum_slices_canonical: the same rounds, the same additions, one wave sum at the end).  Returns false when it gave up.
+struct RecordSet {
+    double2 lo[4], hi[4];
+};
+template <bool PIPELINED>  // (64 more registers: for a wave that has them -- the scalar wave)
 __device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, int nslices, int lane, unsigned spin_limit, const ChainScalars &sc,
                                                    double (&tot)[4])
 {
     unsigned spins = 0;
+    if (PIPELINED && nslices <= 256) {
+        // at most four records per lane: TWO rounds of loads in flight, a new one issued while the previous one returns --
+        // the last record is noticed about half an L2 round trip earlier than with "load, wait, look, load again"
+        auto issue = [&](RecordSet &s) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // (records past the last slice fall outside the descriptor: zeros)
+                s.lo[r] = load_sc1(buf, (64 * r + lane) * 32);
+                s.hi[r] = load_sc1(buf, (64 * r + lane) * 32 + 16);
+            }
+        };
+        auto complete = [&](const RecordSet &s) {
+            bool pend = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend = pend || rec_pending(s.lo[r]) || rec_pending(s.hi[r]);
+            return !__any(pend);
+        };
+        auto add_up = [&](const RecordSet &s) {  // the canonical order (sum_slices_canonical)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tot[q] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tot[0] += s.lo[r].x; tot[1] += s.lo[r].y; tot[2] += s.hi[r].x; tot[3] += s.hi[r].y; }
+        };
+        RecordSet A, B;
+        issue(A);
+        for (;;) {
+            issue(B);
+            if (complete(A)) { add_up(A); break; }
+            issue(A);
+            if (complete(B)) { add_up(B); break; }
+            if (++spins > spin_limit) return false;
+            if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;  // another workgroup gave up
+        }
+        wave_sum4(tot);
+        return true;
+    }
     for (;;) {
         bool pend = false;
 #pragma unroll
@@ -309,7 +348,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const int sync_on = probe ? 0 : (flags & 1);
     const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
     constexpr int WGT = W512 ? ITER_WG_XL : ITER_WG;
-    constexpr bool SW = W512 != 0;                       // scalar wave + seven site waves
+    constexpr bool SW = W512 == 1;                       // scalar wave + seven site waves (W512 = 2: eight site waves, the first one leads)
     constexpr int SITES_WG = SW ? ITER_SITES_SW : WGT;   // sites per workgroup
     // Wave 0 does the uniform work for all in the 8-wide-window forms.  Redundant scalar work in every wave costs each of them
     // the MINRES state in registers (72 spilled registers in the 256-thread one-XCD form: 60x60 x 8 chains 76.9 k -> 94.4 k
@@ -534,7 +573,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 SOLVE_STAMP(2)
                 pre = minres_pre(s);  // the slot-only half of step k + 1, while the site waves finish step k
                 double acc[4];
-                const bool ok = poll_slice_records(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
+                const bool ok = poll_slice_records<true>(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
                 SOLVE_STAMP(3)
                 if (threadIdx.x == 0) {
                     s_flag = ok ? 0 : 1;
@@ -706,7 +745,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             SOLVE_STAMP(9)
             if (threadIdx.x < 64) {  // the first wave polls the records of the chain's slices
                 double acc[4];
-                const bool ok = poll_slice_records(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
+                const bool ok = poll_slice_records<false>(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
                 SOLVE_STAMP(6)
                 if (ok) {
 #pragma unroll
