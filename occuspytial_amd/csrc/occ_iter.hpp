@@ -456,31 +456,37 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     }
     const size_t ci = co + ic;
     const double2 *X0 = a.Xv + co;
-    const double om = a.omega_b[it & 1][ci];
-    const double zval = (double)ia.z[ci];
-    const double xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
-    double2 x = X0[ic];
-    const double qd = a.qdiag[ic];
+    double om = 0.0, zval = 0.0, xb = 0.0, qd = 0.0;
+    double2 x = zero2;
     double2 xn[NW];
 #pragma unroll
-    for (int kk = 0; kk < NW; ++kk) {
-        const bool has = act && kk < width;
-        const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-        const int jraw = a.sell_col[slot];
-        const double vraw = a.sell_val[slot];
-        const int j = has ? jraw : ic;
-        off[kk] = has ? j * 16 : myoff;
-        av[kk] = vraw;
-        hasmask |= has ? (1u << kk) : 0u;
-        xn[kk] = X0[j];
-        nm1[kk] = zero2; nm2[kk] = zero2;
+    for (int kk = 0; kk < NW; ++kk) { off[kk] = myoff; av[kk] = 0.0; xn[kk] = zero2; nm1[kk] = zero2; nm2[kk] = zero2; }
+    if (!scalar_wave) {  // (the scalar wave owns no site: nothing stands between it and tau -- its loads sat in front of tau's)
+        om = a.omega_b[it & 1][ci];
+        zval = (double)ia.z[ci];
+        xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
+        x = X0[ic];
+        qd = a.qdiag[ic];
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) {
+            const bool has = act && kk < width;
+            const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+            const int jraw = a.sell_col[slot];
+            const double vraw = a.sell_val[slot];
+            const int j = has ? jraw : ic;
+            off[kk] = has ? j * 16 : myoff;
+            av[kk] = vraw;
+            hasmask |= has ? (1u << kk) : 0u;
+            xn[kk] = X0[j];
+        }
     }
     if (synced) {  // thread 0's wait for the side stream's noise kernel (started at kernel entry) is over: s_noise_ok is set
         __syncthreads();
         if (!s_noise_ok && writer) sc.err = -2;
     }
-    double en, up;
-    if (synced) {
+    double en = 0.0, up = 0.0;
+    if (scalar_wave) {
+    } else if (synced) {
         en = load_agent(&ia.enorm[it & 1][ci]);
         up = load_agent(&ia.uprior[it & 1][ci]);
     } else {

@@ -985,7 +985,8 @@ struct KryStep {
 // the square roots and half of the divisions) off the critical path -- k_iter runs it while it waits for the
 // other workgroups' sums.  Contractions are explicit: the split does not change a bit of the result.
 struct KryPre {
-    double Anorm, test2, Acond;            // (a)
+    double Anorm, rn2, b1sq;               // (a): Anorm^2, rnorm^2, beta1^2 and the tests that do not need ||x||
+    bool root_tiny, root_small, ill_cond, no_norm;
     double t_ab, delta, gbar, gbar2, sj;   // (c): t_ab = alfa_j^2 + beta_j^2
 };
 // 1 / sqrt(x) for x > 0 away from the ends of the exponent range: v_rsq_f64 (2^-24 relative, measured on gfx950) and two
@@ -1006,9 +1007,20 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 // The two halves of minres_pre: what the stopping test (a) needs, what the rotation (c) needs.
 __device__ __forceinline__ void minres_pre_a(const Slot &s, KryPre &q)
 {
-    q.Anorm = s.tnorm2;  // Anorm^2: the tests below compare squares and products, no sqrt, no division (minres_post_a)
-    q.test2 = s.root;    // root^2 (the slot keeps the square)
-    q.Acond = s.gmax;
+    // scipy: test1 = rnorm / (Anorm ynorm), test2 = root / Anorm, Acond = gmax / gmin, epsx = Anorm ynorm eps, then
+    // `1 + test <= 1`, `test <= rtol`, `Acond >= 0.1 / eps`, `epsx >= beta1`.  The same decisions on squares and
+    // products -- no square root and no division (they were 70 of the ~200 issue-bound f64 instructions of a step):
+    // for non-negative x, c, d:  x / d <= c  <=>  x^2 <= c^2 d^2 (d > 0),  and  1 + x <= 1  <=>  x <= 2^-53.
+    // Here: everything the slot alone decides (the slot keeps Anorm^2 and root^2); minres_post_a adds ||x||.
+    const double eps = DBL_EPSILON, rtol = 1e-5;
+    const double tn2 = s.tnorm2, root2 = s.root, tiny2 = 0x1p-106, rtol2 = rtol * rtol;
+    q.Anorm = tn2;
+    q.no_norm = tn2 == 0.0;  // scipy's tests are inf there
+    q.root_tiny = !q.no_norm && root2 <= tiny2 * tn2;
+    q.root_small = !q.no_norm && root2 <= rtol2 * tn2;
+    q.ill_cond = s.gmax >= (0.1 / eps) * s.gmin;
+    q.rn2 = s.phibar * s.phibar;  // rnorm^2 (phibar >= 0)
+    q.b1sq = s.beta1 * s.beta1;
 }
 __device__ __forceinline__ void minres_pre_c(const Slot &s, KryPre &q)
 {
@@ -1030,27 +1042,20 @@ __device__ __forceinline__ KryPre minres_pre(const Slot &s)
 __device__ __forceinline__ bool minres_post_a(Slot &s, const KryPre &q, int k, double xn2, long long maxiter)
 {
     if (k < 4) return false;
-    const double eps = DBL_EPSILON;
+    const double eps = DBL_EPSILON, rtol = 1e-5;
     const int j = k - 3;
-    const double rtol = 1e-5;
-    // scipy: test1 = rnorm / (Anorm ynorm), test2 = root / Anorm, Acond = gmax / gmin, epsx = Anorm ynorm eps, then
-    // `1 + test <= 1`, `test <= rtol`, `Acond >= 0.1 / eps`, `epsx >= beta1`.  The same decisions on squares and
-    // products -- no square root and no division (they were 70 of the ~200 issue-bound f64 instructions of a step):
-    // for non-negative x, c, d:  x / d <= c  <=>  x^2 <= c^2 d^2 (d > 0),  and  1 + x <= 1  <=>  x <= 2^-53.
-    const double tn2 = q.Anorm, root2 = q.test2;        // Anorm^2, root^2
-    const double ay2 = tn2 * xn2;                        // (Anorm ynorm)^2
-    const double rn2 = s.phibar * s.phibar;              // rnorm^2 (phibar >= 0)
-    const bool inf1 = (xn2 == 0.0 || tn2 == 0.0), inf2 = (tn2 == 0.0);  // scipy's tests are inf there
+    const double ay2 = q.Anorm * xn2;                     // (Anorm ynorm)^2
+    const bool inf1 = (xn2 == 0.0 || q.no_norm);
     const double tiny2 = 0x1p-106, rtol2 = rtol * rtol;
     int istop = s.istop;
-    if (istop == 0) {
-        if (!inf2 && root2 <= tiny2 * tn2) istop = 2;
-        if (!inf1 && rn2 <= tiny2 * ay2) istop = 1;
+    if (istop == 0) {  // scipy's order: the last test that holds names the reason
+        if (q.root_tiny) istop = 2;
+        if (!inf1 && q.rn2 <= tiny2 * ay2) istop = 1;
         if ((long long)j >= maxiter) istop = 6;
-        if (q.Acond >= (0.1 / eps) * s.gmin) istop = 4;
-        if (ay2 * (eps * eps) >= s.beta1 * s.beta1) istop = 3;
-        if (!inf2 && root2 <= rtol2 * tn2) istop = 2;
-        if (!inf1 && rn2 <= rtol2 * ay2) istop = 1;
+        if (q.ill_cond) istop = 4;
+        if (ay2 * (eps * eps) >= q.b1sq) istop = 3;
+        if (q.root_small) istop = 2;
+        if (!inf1 && q.rn2 <= rtol2 * ay2) istop = 1;
     }
     if (istop != 0) {
         s.istop = istop; s.itn = j; s.done = 1;

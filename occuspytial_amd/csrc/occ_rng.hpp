@@ -195,6 +195,9 @@ __device__ inline double pg_rtigauss(Cursor &c, double Z)
 __device__ inline double pg1_draw(Cursor &c, double z)
 {
     const double Z = 0.5 * fabs(z);
+    // (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loops below, and a
+    // wave that never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it)
+    if (!(Z < 1.0e300)) return z - z;
     const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
     const double ptail = pg_mass_texpon(Z);
     for (;;) {
@@ -221,6 +224,7 @@ __device__ inline double pg1_draw(Cursor &c, double z)
 __device__ inline double std_gamma(Cursor &c, double shape)
 {
     double boost = 1.0, a = shape;
+    if (!(a > 0.0 && a < 1.0e300)) return a - a + __longlong_as_double(0x7ff8000000000000LL);  // (NaN in, NaN out: see pg1_draw)
     if (a < 1.0) {
         boost = pow(c.unif(), 1.0 / a);
         a += 1.0;
