@@ -82,6 +82,8 @@ struct occ_sampler {
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
     int xl_per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... per XCD, when the XCDs that host a chain get more than the others (first entry 0: evenly)
     int main_hot_cus = 0;    // CUs the main stream's mask holds on XCD 0 (a chain's XCD)
+    std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
+    bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
     int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
@@ -646,9 +648,17 @@ int enqueue_sequence(occ_sampler *s)
 
 int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
 {
-    std::vector<ChainScalars> h;
-    int rc = read_scalars(s, h);
-    if (rc) return rc;
+    // (a call of a dozen iterations is all host round trips: the scalars the snapshot has just read are not read again, and
+    // what goes to the device is ordered on the stream ahead of the kernels -- no wait; win_sc is a member because the
+    // copy outlives this function, and the next write to it follows a stream synchronisation)
+    std::vector<ChainScalars> &h = s->win_sc;
+    if (s->snap_fresh) {
+        h = s->snap_sc;
+        s->snap_fresh = false;
+    } else {
+        int rc = read_scalars(s, h);
+        if (rc) return rc;
+    }
     for (auto &sc : h) {
         Ctl &ctl = sc.ctl[s->parity];
         sc.it_base = ctl.it;
@@ -659,8 +669,9 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
     }
     // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
     // error may have left them anywhere)
-    if (s->ctx.claim) HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
-    return write_scalars(s, h);
+    if (s->ctx.claim) HIP_TRY(hipMemsetAsync(s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
+    return OCC_OK;
 }
 
 
@@ -1904,6 +1915,7 @@ static int snapshot_take(occ_sampler *s)
         if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
     }
     if ((rc = read_scalars(s, s->snap_sc))) return rc;
+    s->snap_fresh = true;  // set_window, next, takes these
     s->snap_parity = s->parity;
     HIP_TRY(hipMemcpyAsync(s->snap_eta, c.eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->snap_z, c.z, Cn, hipMemcpyDeviceToDevice, s->stream));
