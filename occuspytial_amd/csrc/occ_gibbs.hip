@@ -1055,6 +1055,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 if (hot < XL_SLOTS) {
                     rest = 4 * (int)std::lround((double)(base - hot * need) / (4.0 * (XL_SLOTS - hot)));
                     rest = std::max(8, std::min(rest, need));
+                    while (hot * need + (XL_SLOTS - hot) * rest > ncu - 96 && rest > 8) rest -= 4;  // the side stream keeps 96 CUs
                 }
                 for (int x = 0; x < XL_SLOTS; ++x) { wide_xcd[x] = x < hot ? need : rest; wide_main += wide_xcd[x]; }
             }

@@ -37,8 +37,9 @@ tail -n 1 $out/rsr.log > profiles/${tag}_rsr_bench.txt
 # 5. other sizes and paths, one line each (chain-iterations/s; which path every case takes): BASELINE configs 1, 3 (its 8
 #    chains on one GPU), 4, 5, the any-placement form and the launch-per-step path on the headline workload
 {
-  python3 tools/sizes.py 20,20,1,2000 60,60,8,1500 100,100,1,1500 100,100,2,1500 100,100,4,2000 100,100,8,1500 100,100,16,800 100,100,32,400 250,250,1,400 500,500,1,300
+  python3 tools/sizes.py 20,20,1,2000 60,60,8,1500 60,60,24,500 100,100,1,1500 100,100,2,1500 100,100,4,2000 100,100,5,1200 100,100,6,1200 100,100,8,1500 100,100,16,800 100,100,32,400 150,150,2,600 250,250,1,400 500,500,1,300
   python3 tools/c5.py 4
+  echo "OCC_NO_SCALAR_WAVE=1 (one XCD per chain, eight site waves per workgroup, the first one leads):"; OCC_NO_SCALAR_WAVE=1 python3 tools/sizes.py 100,100,4,1000
   echo "OCC_NO_XCD_LOCAL=1 (any placement):"; OCC_NO_XCD_LOCAL=1 python3 tools/sizes.py 100,100,4,1000
   echo "OCC_NO_PERSISTENT=1 (one launch per MINRES step):"; OCC_NO_PERSISTENT=1 python3 tools/sizes.py 100,100,4,1000
 } > profiles/${tag}_sizes.txt 2> $out/sizes.err
