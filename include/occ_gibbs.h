@@ -224,6 +224,9 @@ int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out);
  * sub-stream (key, index i, iteration, stream) exactly as a kernel of the iteration would draw it.
  * kind 0: PG(1, param[i]);  1: standard gamma of shape param[i];  2: standard normal;  3: uniform on (0, 1)
  * (param is ignored for kinds 2 and 3).  Host pointers (or device pointers of `device`); n < 2^31.
+ * kind 4 is a device self-test, not a variate: n (a multiple of 64) values in param, out[i] = the wave sum of one of four
+ * quantities derived from them, NaN where the three forms of the engine's wave sum (plain, four at once, transposed)
+ * disagree in a bit (tests/test_gpu_rng.py).
  * Errors are reported through occ_last_error(NULL). */
 int occ_draw(int32_t device, int32_t kind, uint64_t key, uint32_t iteration, uint32_t stream, int64_t n, const double *param,
              double *out);

@@ -623,6 +623,27 @@ def test_barrier_timeout_falls_back_to_launch_per_step_with_the_same_bits(monkey
             assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize('env, main_cus', [({'OCC_NO_SCALAR_WAVE': '1'}, 160), ({'OCC_NO_XCD_SHARES': '1'}, 160), ({'OCC_CU_SPLIT': '192'}, 192),
+                                           ({'OCC_CU_SPLIT': '0'}, 0)])
+def test_scalar_wave_form_and_its_cu_partition_do_not_change_a_bit(monkeypatch, env, main_cus):
+    """The headline workload takes the one-XCD form with a scalar wave beside seven site waves (448 sites per workgroup, 24
+    CUs on the XCDs that host a chain and 16 on the others, tiles of the device-filling kernels in proportion).  The same
+    run with eight site waves per workgroup, with even tile shares, on an even 192 + 64 partition and without any
+    partition: same records, same state, bit for bit -- the summation order does not depend on the workgroup geometry,
+    the slot a workgroup claims does not matter, and where a tile runs never changes what it computes."""
+    ref = _headline_run()
+    assert ref[2]['persistent_solve'] == 2 and ref[2]['main_stream_cus'] == 160
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = _headline_run()
+    assert alt[2]['persistent_solve'] == 2 and alt[2]['main_stream_cus'] == main_cus and alt[3]['fused_fallbacks'] == 0
+    for u, v in zip(ref[0], alt[0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(ref[1], alt[1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+
+
 # ---- the reference's own form of the prior draw, and precisions the edge form cannot represent ---------------------
 def _general_singular_precision(n, seed):
     """A symmetric positive semi-definite singular Q that is NOT an ICAR precision: Q = M'M with every row of M summing
