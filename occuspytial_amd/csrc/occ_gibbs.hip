@@ -65,7 +65,7 @@ struct occ_sampler {
     double *snap_eta = nullptr;
     uint8_t *snap_z = nullptr;
     double2 *snap_x = nullptr;
-    double *snap_theta = nullptr;
+    double *snap_theta = nullptr;  // reduced-rank model: the basis coefficients
     std::vector<ChainScalars> snap_sc;
     // fixed problem arrays on the device, in upload order: what a group broadcasts from its root (occ_create_group /
     // occ_create_distributed); defer_fixed: allocate only, the bytes arrive by broadcast
@@ -302,7 +302,22 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
             break;
         case K_RSR_SOLVE:
-            hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
+            if (s->rsr.m <= RSR_MAX_DIM) {
+                hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
+            } else {  // the m x m system in global memory, factorised panel by panel (occ_rsr.hpp, k_rsrb_*)
+                const int m = s->rsr.m;
+                hipLaunchKernelGGL(k_rsrb_tau, dim3(1, (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
+                hipLaunchKernelGGL(k_rsrb_assemble, dim3((unsigned)m, (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
+                for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
+                    const int kb = std::min(RSR_PANEL, m - k0), cols = m - k0 - kb;
+                    hipLaunchKernelGGL(k_rsrb_panel, dim3((unsigned)std::max(1, (cols + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
+                    if (cols > 0) {
+                        const unsigned tt = (unsigned)((cols + 15) / 16);
+                        hipLaunchKernelGGL(k_rsrb_update, dim3(tt, tt, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
+                    }
+                }
+                hipLaunchKernelGGL(k_rsrb_solve, dim3(1, (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
+            }
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
@@ -670,6 +685,7 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
     // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
     // error may have left them anywhere)
     if (s->ctx.claim) HIP_TRY(hipMemsetAsync(s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16, s->stream));
+    if (s->ctx.sync) HIP_TRY(hipMemsetAsync(s->ctx.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
     HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
     return OCC_OK;
 }
@@ -691,9 +707,9 @@ int create_plain_streams(occ_sampler *s)
 
 // ICAR model on the launch-per-step path: no CU partition, hand-overs by events (the device-counter hand-overs and
 // the partition exist for the fused kernel's sake).
-int demote_streams(occ_sampler *s)
+int demote_streams(occ_sampler *s, bool also_reduced_rank = false)
 {
-    if (s->rsr.m > 0 || s->main_cus == 0) return OCC_OK;
+    if ((s->rsr.m > 0 && !also_reduced_rank) || s->main_cus == 0) return OCC_OK;
     if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
     if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); s->side = nullptr; }
     return create_plain_streams(s);
@@ -796,8 +812,8 @@ static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
     if (pb->p < 1 || pb->p > OCC_MAX_COVARIATES || pb->q < 1 || pb->q > OCC_MAX_COVARIATES)
         return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 32]");
     if (pb->rsr_dim > 0 && (pb->p > MAXC || pb->q > MAXC)) return set_error(s, OCC_E_BADARG, "the reduced-rank model takes at most 8 covariates of each kind");
-    if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_MAX_DIM || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
-        return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 128 columns (rsr_K, rsr_Q, rsr_E)");
+    if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_BIG_MAX || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
+        return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 2048 columns (rsr_K, rsr_Q, rsr_E)");
     if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
     const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q;
     L.n = n; L.S = S; L.R = R; L.p = p; L.q = q; L.rsr_dim = pb->rsr_dim;
@@ -1230,6 +1246,10 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     if (s->flag_sync) {
         if ((rc = dev_alloc(s, &c.sync, (size_t)SYNC_WORDS))) return rc;
         s->iter.sync = c.sync;
+        if (std::getenv("OCC_DEBUG_BREAK_HANDOVER")) {  // tests of the run-time fallback: the side stream never announces its noise
+            const unsigned one = 1u;
+            HIP_TRY(copy_on(s, c.sync + SYNC_DEBUG, &one, sizeof(one), hipMemcpyHostToDevice));
+        }
     }
     if (s->persistent) {
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
@@ -1331,8 +1351,16 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         r.scs = c.sc;
         r.sync = c.sync;
         s->rsr_K_host = Kh;
-        HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
+        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr;
+        if (m <= RSR_MAX_DIM) {
+            HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
+        } else {  // the global-memory solve (k_rsrb_*)
+            if ((rc = upload(s, &r.E, Eh))) return rc;
+            if ((rc = dev_alloc(s, &r.big_eps, (size_t)C * m))) return rc;
+            if ((rc = dev_alloc(s, &r.big_scal, (size_t)C * 2))) return rc;
+            if ((rc = dev_alloc(s, &r.big_rhs, (size_t)C * m))) return rc;
+        }
     }
     HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
@@ -1914,6 +1942,7 @@ static int snapshot_take(occ_sampler *s)
         if ((rc = dev_alloc(s, &s->snap_eta, Cn, false))) return rc;
         if ((rc = dev_alloc(s, &s->snap_z, Cn, false))) return rc;
         if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
+        if (s->rsr.m > 0 && (rc = dev_alloc(s, &s->snap_theta, (size_t)c.C * s->rsr.m, false))) return rc;
     }
     if ((rc = read_scalars(s, s->snap_sc))) return rc;
     s->snap_fresh = true;  // set_window, next, takes these
@@ -1921,6 +1950,7 @@ static int snapshot_take(occ_sampler *s)
     HIP_TRY(hipMemcpyAsync(s->snap_eta, c.eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->snap_z, c.z, Cn, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->snap_x, c.Xv, sizeof(double2) * Cn, hipMemcpyDeviceToDevice, s->stream));
+    if (s->rsr.m > 0) HIP_TRY(hipMemcpyAsync(s->snap_theta, s->rsr.theta, sizeof(double) * (size_t)c.C * s->rsr.m, hipMemcpyDeviceToDevice, s->stream));
     return OCC_OK;
 }
 
@@ -1932,22 +1962,24 @@ static int fallback_to_launch_per_step(occ_sampler *s)
     if (s->side) (void)hipStreamSynchronize(s->side);
     (void)hipGetLastError();
     if (std::getenv("OCC_VERBOSE") || !std::getenv("OCC_QUIET"))
-        std::fprintf(stderr, "[occ] device-side wait timed out in the fused iteration kernel (%s); re-running the call with one launch per MINRES step\n",
-                     s->err.c_str());
+        std::fprintf(stderr, "[occ] a device-side wait timed out (%s); re-running the call without hand-overs between the streams%s\n",
+                     s->err.c_str(), s->rsr.m > 0 ? "" : ", one launch per MINRES step");
     destroy_graph(s);
     s->persistent = false;
     s->xcd_local = false;
     s->device_timeout = false;
     s->launch_rc = OCC_OK;
     int rc;
-    if ((rc = demote_streams(s))) return rc;
+    if ((rc = demote_streams(s, true))) return rc;
     s->flag_sync = false;
     c.sync = nullptr;
     s->iter.sync = nullptr;
+    s->rsr.sync = nullptr;
     HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(copy_on(s, c.eta, s->snap_eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice));
     HIP_TRY(copy_on(s, c.z, s->snap_z, Cn, hipMemcpyDeviceToDevice));
     HIP_TRY(copy_on(s, c.Xv, s->snap_x, sizeof(double2) * Cn, hipMemcpyDeviceToDevice));
+    if (s->rsr.m > 0) HIP_TRY(copy_on(s, s->rsr.theta, s->snap_theta, sizeof(double) * (size_t)c.C * s->rsr.m, hipMemcpyDeviceToDevice));
     for (auto &sc : s->snap_sc) sc.err = 0;
     if ((rc = write_scalars(s, s->snap_sc))) return rc;
     s->parity = s->snap_parity;
@@ -1961,7 +1993,7 @@ int occ_step(occ_sampler *s)
 {
     if (!s) return OCC_E_BADARG;
     HIP_TRY(hipSetDevice(s->device));
-    const bool fused = s->persistent && s->rsr.m == 0;
+    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;  // paths with device-side waits: re-run without them if one gives up
     int rc;
     if (fused && (rc = snapshot_take(s))) return rc;
     s->device_timeout = false;
@@ -1979,7 +2011,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     if (n_iter < 1 || burnin < 0 || burnin >= n_iter) return set_error(s, OCC_E_BADARG, "burnin value cannot be larger than sample size");
     if (!out_alpha || !out_beta || !out_tau) return set_error(s, OCC_E_BADARG, "null output buffer");
     HIP_TRY(hipSetDevice(s->device));
-    const bool fused = s->persistent && s->rsr.m == 0;
+    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;
     int rc;
     if (fused && (rc = snapshot_take(s))) return rc;
     s->device_timeout = false;

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const bool synced = sync_on && ia.sync != nullptr;
     if (synced && threadIdx.x == 0) {
         const unsigned j = ia.sync[SYNC_MAIN_SEQ + e];      // this sequence's number (the previous sequence left it)
-        s_noise_ok = sync_wait(ia.sync + SYNC_NOISE, j) ? 1 : 0;
+        s_noise_ok = sync_wait(ia.sync, SYNC_NOISE, j) ? 1 : 0;
     }
     const uint32_t it = ctl.it;
     // the scalar wave (SW): a wave-uniform fact the compiler can see (a scalar register), so that the two roles of the

@@ -659,8 +659,8 @@ __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)
 // SYNC_SIDE_SEQ: written by k_noise, read by k_gate).
 // Consumers that wait inside a running kernel (k_iter, k_z_ob) read the data with L1-bypassing agent-scope
 // loads; kernels launched after k_gate rely on the kernel boundary.  Waits are bounded.
-enum : int { SYNC_MAIN = 0, SYNC_ALPHA = 16, SYNC_NOISE = 32, SYNC_MAIN_SEQ = 48, SYNC_SIDE_SEQ = 52, SYNC_WORDS = 64 };
-constexpr unsigned SYNC_SPIN_LIMIT = 1u << 21;
+enum : int { SYNC_MAIN = 0, SYNC_ALPHA = 16, SYNC_NOISE = 32, SYNC_MAIN_SEQ = 48, SYNC_SIDE_SEQ = 52, SYNC_ABORT = 56, SYNC_DEBUG = 57, SYNC_WORDS = 64 };
+constexpr unsigned SYNC_SPIN_LIMIT = 1u << 19;  // about a second
 
 __device__ __forceinline__ unsigned sync_read(const unsigned *p)
 {
@@ -670,13 +670,22 @@ __device__ __forceinline__ void sync_set(unsigned *p, unsigned v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane: wait until *p has reached `target` (modulo 2^32); false when the wait gave up
-__device__ __forceinline__ bool sync_wait(const unsigned *p, unsigned target)
+// one lane: wait until sync[word] has reached `target` (modulo 2^32); false when the wait gave up.  A wait that gives up
+// says so in sync[SYNC_ABORT], and every wait looks at that word: when the streams do not run beside each other (seen
+// once in ~10 runs of one test on ROCm 7.2: a fresh engine whose two streams were served one after the other) the first
+// wait to time out ends them all -- the enqueued batch drains at once instead of one time-out per hand-over, three per
+// iteration -- and the host re-runs the call without hand-overs (occ_gibbs.hip, fallback_to_plain_path).
+__device__ __forceinline__ bool sync_wait(unsigned *sync, int word, unsigned target)
 {
     unsigned spins = 0;
-    while ((int)(sync_read(p) - target) < 0) {
+    while ((int)(sync_read(sync + word) - target) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > SYNC_SPIN_LIMIT) return false;
+        ++spins;
+        if ((spins & 63u) == 0u && sync_read(sync + SYNC_ABORT) != 0u) return false;
+        if (spins > SYNC_SPIN_LIMIT) {
+            sync_set(sync + SYNC_ABORT, 1u);
+            return false;
+        }
     }
     return true;
 }
@@ -692,8 +701,9 @@ __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainSc
     const Ctx &c = *cp;
     if (c.sync == nullptr || threadIdx.x != 0) return;
     const unsigned j = c.sync[SYNC_SIDE_SEQ];
+    if (c.sync[SYNC_DEBUG] != 0u) return;  // test knob (OCC_DEBUG_BREAK_HANDOVER): a side stream that never announces its noise
     sync_set(c.sync + SYNC_NOISE, j);
-    if (!sync_wait(c.sync + SYNC_MAIN, j)) scs[0].err = -2;
+    if (!sync_wait(c.sync, SYNC_MAIN, j)) scs[0].err = -2;
 }
 
 // =================================================================================================
@@ -1828,7 +1838,7 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     const int Q = c.q;
     double alpha[MAXC];
     if (synced) {
-        if (threadIdx.x == 0) s_wait_ok = sync_wait(c.sync + SYNC_ALPHA, seq + 1u) ? 1 : 0;
+        if (threadIdx.x == 0) s_wait_ok = sync_wait(c.sync, SYNC_ALPHA, seq + 1u) ? 1 : 0;
         __syncthreads();
         if (!s_wait_ok && writer) sc.err = -2;
 #pragma unroll

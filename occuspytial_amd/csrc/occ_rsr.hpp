@@ -22,6 +22,8 @@
 namespace occ {
 
 constexpr int RSR_MAX_DIM = 128;  // m x m doubles of LDS for the Cholesky factor: 128 KB of the CU's 160 KB
+constexpr int RSR_BIG_MAX = 2048; // beyond RSR_MAX_DIM: the factor lives in global memory, factorised panel by panel (k_rsrb_*)
+constexpr int RSR_PANEL = 32;     // ... columns per panel
 constexpr uint32_t STREAM_RSR = 9;
 
 struct RsrArgs {
@@ -38,6 +40,11 @@ struct RsrArgs {
     double *rhs;        // [C][nchunk][m] K'u (nchunk = 1: k_rsr_gram writes the finished sums)
     int nchunk;
     double *eta;        // [C][n]
+    // m > RSR_MAX_DIM only (k_rsrb_*): E row-major, the noise of the prior term, {tau, sqrt(tau)}, the finished right-hand side
+    const double *E;    // [m][m]
+    double *big_eps;    // [C][m]
+    double *big_scal;   // [C][2]
+    double *big_rhs;    // [C][m]
     double tau_rate, tau_shape;
     ChainScalars *scs;
     unsigned *sync;     // hand-over counters of the two streams (Ctx::sync), or null
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
         const double *en = a.enorm[ctl.it & 1] + co;
         const uint8_t *z = a.z + co;
         if (synced) {  // the noise of this iteration comes from the side stream's previous sequence
-            if (threadIdx.x == 0) s_noise_ok = sync_wait(a.sync + SYNC_NOISE, a.sync[SYNC_MAIN_SEQ + e]) ? 1 : 0;
+            if (threadIdx.x == 0) s_noise_ok = sync_wait(a.sync, SYNC_NOISE, a.sync[SYNC_MAIN_SEQ + e]) ? 1 : 0;
             __syncthreads();
             if (!s_noise_ok) {
                 if (threadIdx.x == 0) a.scs[chain].err = -2;  // OCC_E_HIP: the side stream never arrived
@@ -485,7 +492,7 @@ __global__ void __launch_bounds__(256) k_rsr_solve(const RsrArgs a, int e)
 template <int P>
 __global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS)
 {
-    __shared__ double s_th[RSR_MAX_DIM];
+    __shared__ double s_th[RSR_BIG_MAX];
     const Ctx &c = *cp;
     const Tile tile = tile_of_block(chain_base);
     const int chain = tile.chain, blk = tile.blk;
@@ -535,6 +542,211 @@ __global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS
         for (int aa = 0; aa < P; ++aa) acc[t++] = x[aa] * tt;
     }
     block_partials<nacc(P)>(acc, c.part_beta + (size_t)chain * nacc(P) * c.nb_n, c.nb_n, blk);
+}
+
+
+// ==== m > RSR_MAX_DIM: the same conditional with the m x m system in GLOBAL memory ===================================
+// The reference keeps every Moran eigenvector above its threshold (logit.py:415-446: about 13 % of the sites of a
+// lattice at the default r = 0.5 -- 1 280 columns at 100x100); the LDS-resident solve above stops at 128.  Here:
+//   k_rsrb_tau       eps2, theta' Qr theta, tau                                       one workgroup per chain
+//   k_rsrb_assemble  prec = G + tau Qr (upper triangle, in place in `gram`), rhs = K'u + sqrt(tau) E eps2   one per row
+//   k_rsrb_panel     panel by panel (RSR_PANEL rows): the diagonal block's upper Cholesky factor in LDS (every workgroup
+//                    for itself), then U_kk' X = P_k,rest for the block row right of it, one column per thread
+//   k_rsrb_update    P_ij -= sum_t U_ti U_tj over the panel's rows t, 16 x 16 tiles of the trailing upper triangle
+//   k_rsrb_solve     U'y = rhs, U theta = y, blocked by panels                          one workgroup per chain
+// k_rsr_gram and k_rsr_eta_beta are the general kernels above.  Every sum has a fixed order (no atomics); the order
+// is not the small path's (the two agree to rounding, like the oracle).  Plain kernels: at m = 1 280 the conditional is
+// ~10^9 flops of Cholesky per chain and iteration beside a 2 10^10-flop Gram matrix -- milliseconds where the
+// reference's host code takes seconds -- and not the path BASELINE's metric is quoted on.
+__global__ void __launch_bounds__(1024) k_rsrb_tau(const RsrArgs a, int e)
+{
+    __shared__ double s_th[RSR_BIG_MAX];
+    __shared__ double s_part[16];
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const uint32_t it = ctl.it;
+    for (int t = tid; t < m; t += 1024) {
+        s_th[t] = a.theta[(size_t)chain * m + t];
+        a.big_eps[(size_t)chain * m + t] = block_normal(sc.key, (uint32_t)t, 0, it, STREAM_RSR);
+    }
+    __syncthreads();
+    double part = 0.0;  // this wave's rows r = wave, wave + 16, ...: theta_r (Qr theta)_r, columns over the lanes
+    for (int r = wave; r < m; r += 16) {
+        double acc = 0.0;
+        for (int c = lane; c < m; c += 64) acc = fma(a.Qr[(size_t)r * m + c], s_th[c], acc);
+        part = fma(s_th[r], wave_sum(acc), part);
+    }
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double quad = 0.0;
+        for (int w = 0; w < 16; ++w) quad += s_part[w];
+        const double rate = 0.5 * quad + a.tau_rate;
+        const double tau = (1.0 / rate) * load_agent(&sc.tau_gamma[it & 1]);  // the variate was drawn ahead by k_noise
+        sc.tau = tau;
+        a.big_scal[chain * 2] = tau;
+        a.big_scal[chain * 2 + 1] = sqrt(tau);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rsrb_assemble(const RsrArgs a, int e)
+{
+    __shared__ double s_part[4];
+    const int chain = blockIdx.y, r = blockIdx.x, m = a.m, tid = threadIdx.x;
+    const ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const double tau = a.big_scal[chain * 2], st = a.big_scal[chain * 2 + 1];
+    double *P = a.gram + (size_t)chain * m * m;
+    for (int c = r + tid; c < m; c += 256) P[(size_t)r * m + c] = fma(tau, a.Qr[(size_t)r * m + c], P[(size_t)r * m + c]);
+    double es = 0.0;
+    const double *eps = a.big_eps + (size_t)chain * m;
+    for (int j = tid; j < m; j += 256) es = fma(a.E[(size_t)r * m + j], eps[j], es);
+    es = wave_sum(es);
+    if ((tid & 63) == 0) s_part[tid >> 6] = es;
+    __syncthreads();
+    if (tid == 0) {
+        const double ee = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+        a.big_rhs[(size_t)chain * m + r] = fma(st, ee, a.rhs[(size_t)chain * a.nchunk * m + r]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int k0)
+{
+    __shared__ double D[RSR_PANEL][RSR_PANEL + 1];
+    __shared__ int s_bad;
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x;
+    ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    const int kb = min(RSR_PANEL, m - k0);
+    double *P = a.gram + (size_t)chain * m * m;
+    for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
+        const int i = t / RSR_PANEL, j = t % RSR_PANEL;
+        D[i][j] = (i < kb && j < kb && j >= i) ? P[(size_t)(k0 + i) * m + k0 + j] : 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int i = 0; i < kb; ++i) {  // upper Cholesky of the diagonal block, row by row
+        if (tid == 0) {
+            const double piv = D[i][i];
+            if (!(piv > 0.0)) s_bad = 1;
+            D[i][i] = sqrt(piv);
+        }
+        __syncthreads();
+        const double d = D[i][i];
+        if (tid > i && tid < kb) D[i][tid] = D[i][tid] / d;
+        __syncthreads();
+        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
+            const int r = t / RSR_PANEL, c = t % RSR_PANEL;
+            if (r > i && c >= r && c < kb) D[r][c] = fma(-D[i][r], D[i][c], D[r][c]);
+        }
+        __syncthreads();
+    }
+    if (s_bad) {
+        if (blockIdx.x == 0 && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
+        return;
+    }
+    if (blockIdx.x == 0)
+        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
+            const int i = t / RSR_PANEL, j = t % RSR_PANEL;
+            if (i < kb && j < kb && j >= i) P[(size_t)(k0 + i) * m + k0 + j] = D[i][j];
+        }
+    // the block row right of the diagonal block: U_kk' x = p, one column per thread
+    const int j = k0 + kb + (int)blockIdx.x * 256 + tid;
+    if (j < m) {
+        double x[RSR_PANEL];
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb) ? P[(size_t)(k0 + t) * m + j] : 0.0;
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) {
+            if (t < kb) {
+                double v = x[t];
+#pragma unroll
+                for (int q = 0; q < RSR_PANEL; ++q)
+                    if (q < t) v = fma(-D[q][t], x[q], v);
+                x[t] = v / D[t][t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t)
+            if (t < kb) P[(size_t)(k0 + t) * m + j] = x[t];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rsrb_update(const RsrArgs a, int e, int k0)
+{
+    const int chain = blockIdx.z, m = a.m, ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    if (blockIdx.x < blockIdx.y) return;  // upper triangle of tiles: tile column >= tile row
+    const int kb = min(RSR_PANEL, m - k0), base = k0 + kb;
+    const int i = base + 16 * (int)blockIdx.y + ty, j = base + 16 * (int)blockIdx.x + tx;
+    if (i >= m || j >= m || j < i) return;
+    double *P = a.gram + (size_t)chain * m * m;
+    double acc = P[(size_t)i * m + j];
+    for (int t = 0; t < kb; ++t) acc = fma(-P[(size_t)(k0 + t) * m + i], P[(size_t)(k0 + t) * m + j], acc);
+    P[(size_t)i * m + j] = acc;
+}
+
+__global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
+{
+    __shared__ double y[RSR_BIG_MAX];
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x;
+    const ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    const double *U = a.gram + (size_t)chain * m * m;
+    for (int t = tid; t < m; t += 1024) y[t] = a.big_rhs[(size_t)chain * m + t];
+    __syncthreads();
+    // U'y = rhs, forward: the panel's own rows by one wave (lane t owns entry k0 + t), then everything right of it
+    for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
+        const int kb = min(RSR_PANEL, m - k0);
+        if (tid < 64) {
+            double v = (tid < kb) ? y[k0 + tid] : 0.0;
+            for (int s2 = 0; s2 < kb; ++s2) {
+                const double us = (tid >= s2 && tid < kb) ? U[(size_t)(k0 + s2) * m + k0 + tid] : 1.0;  // row s2 of the block
+                const double ys = readlane_f64(v, s2) / readlane_f64(us, s2);
+                if (tid == s2) v = ys;
+                else if (tid > s2 && tid < kb) v = fma(-us, ys, v);
+            }
+            if (tid < kb) y[k0 + tid] = v;
+        }
+        __syncthreads();
+        for (int j = k0 + kb + tid; j < m; j += 1024) {
+            double v = y[j];
+            for (int s2 = 0; s2 < kb; ++s2) v = fma(-U[(size_t)(k0 + s2) * m + j], y[k0 + s2], v);
+            y[j] = v;
+        }
+        __syncthreads();
+    }
+    // U theta = y, backward: the last panel first
+    const int last = ((m - 1) / RSR_PANEL) * RSR_PANEL;
+    for (int k0 = last; k0 >= 0; k0 -= RSR_PANEL) {
+        const int kb = min(RSR_PANEL, m - k0);
+        if (tid < 64) {
+            double v = (tid < kb) ? y[k0 + tid] : 0.0;
+            const double dg = (tid < kb) ? U[(size_t)(k0 + tid) * m + k0 + tid] : 1.0;
+            for (int s2 = kb - 1; s2 >= 0; --s2) {
+                const double ts = readlane_f64(v, s2) / readlane_f64(dg, s2);
+                const double us = (tid < s2) ? U[(size_t)(k0 + tid) * m + k0 + s2] : 0.0;  // column s2 of the block
+                if (tid == s2) v = ts;
+                else if (tid < s2) v = fma(-us, ts, v);
+            }
+            if (tid < kb) y[k0 + tid] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += 1024) {
+            double v = y[i];
+            for (int s2 = 0; s2 < kb; ++s2) v = fma(-U[(size_t)i * m + k0 + s2], y[k0 + s2], v);
+            y[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < m; t += 1024) a.theta[(size_t)chain * m + t] = y[t];
 }
 
 }  // namespace occ

@@ -218,8 +218,9 @@ class LogitRSRGibbs(LogitICARGibbs):
     :math:`K^\top Q K`, ``fixed.K`` is :math:`K`, ``fixed.q`` its number of columns, and the default
     ``tau_shape`` becomes ``0.5 + 0.5 q`` -- all as in the reference.  The basis is computed on the host with dense
     n x n linear algebra, once (as the reference does); per iteration the device forms
-    :math:`K^\top\Omega K + \tau K^\top QK` and solves the q x q system (``csrc/occ_rsr.hpp``).  At most 128
-    basis columns.  ``device`` selects the HIP device.
+    :math:`K^\top\Omega K + \tau K^\top QK` and solves the q x q system (``csrc/occ_rsr.hpp``: in LDS and registers up to
+    128 basis columns, panel by panel in device memory up to 2048 -- the reference's default threshold keeps about 13 % of a
+    lattice's sites: 1 280 columns at 100x100).  ``device`` selects the HIP device.
     """
 
     def __init__(self, Q, W, X, y, hparams=None, random_state=None, r=0.5, q=None, device=0, devices=None):
@@ -228,8 +229,8 @@ class LogitRSRGibbs(LogitICARGibbs):
 
     def _configure_rsr(self, r, q, hparams):
         rsr = self._problem.enable_rsr(r=r, q=q, default_tau_shape=not hparams)
-        if rsr['dim'] > 128:
-            raise ValueError(f'{rsr["dim"]} basis columns selected; the device path supports at most 128 '
+        if rsr['dim'] > 2048:
+            raise ValueError(f'{rsr["dim"]} basis columns selected; the device path supports at most 2048 '
                              '(raise the threshold `r` or pass `q`)')
         fixed = self.fixed
         fixed.q = rsr['dim']

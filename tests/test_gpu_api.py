@@ -185,3 +185,22 @@ def test_reduced_rank_sampler_api(data):
     tail = LogitRSRGibbs(*data, random_state=77, q=10).resume(first.checkpoint(), 18, progressbar=False)
     for k in ('alpha', 'beta', 'tau'):
         assert np.array_equal(tail[k], whole[k][:, 12:])
+
+
+def test_reduced_rank_default_threshold_keeps_more_than_128_columns():
+    """The reference's default threshold r = 0.5 keeps about 13 % of a lattice's sites (logit.py:415-446): 204 columns at
+    40x40.  The sampler takes them (device-memory solve, csrc/occ_rsr.hpp k_rsrb_*): shapes, same seed => same draws,
+    eta = K theta, chains differ."""
+    from occuspytial_amd import LogitRSRGibbs
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(40, 40, visits=3, p=2, q=2, random_state=3)
+    s = LogitRSRGibbs(Q, W, X, y, random_state=4)
+    m = s.fixed.q
+    assert 150 < m <= 2048 and s.fixed.K.shape == (1600, m)
+    out = s.sample(12, burnin=2, chains=2, progressbar=False)
+    assert out['alpha'].shape == (2, 10, 2) and out['beta'].shape == (2, 10, 2) and out['tau'].shape == (2, 10)
+    assert np.all(np.isfinite(out['beta'])) and np.all(out['tau'] > 0) and not np.allclose(out['tau'][0], out['tau'][1])
+    out2 = LogitRSRGibbs(Q, W, X, y, random_state=4).sample(12, burnin=2, chains=2, progressbar=False)
+    for k in ('alpha', 'beta', 'tau'):
+        assert np.array_equal(out[k], out2[k])
+    assert np.allclose(s.state.spatial, s.fixed.K @ s.state.eta, atol=1e-11)

@@ -526,6 +526,53 @@ def test_reduced_rank_every_block_count_matches_oracle(oracle, q):
     eng.close()
 
 
+@pytest.mark.parametrize('q', [129, 160, 257, 333])
+def test_reduced_rank_large_basis_matches_oracle(oracle, q):
+    """Beyond 128 basis columns the m x m system lives in device memory and is factorised panel by panel (k_rsrb_*: 32-row
+    panels; sizes at a panel edge, inside a panel, with a ragged last panel): three iterations in lock step with the
+    oracle, then occ_run (graphs, two streams) against stepping for two chains.  The reference keeps every Moran
+    eigenvector above its threshold -- about 13 % of a lattice's sites -- so its default arguments need this path from
+    1 000 sites on (logit.py:415-446)."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(20, 25, visits=3, p=2, q=2, random_state=5)
+    prob = FlatProblem(Q, W, X, y)
+    m = prob.enable_rsr(q=q)['dim']
+    assert m == q
+    rng = np.random.default_rng(q)
+    start = dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.5, eta=0.3 * rng.standard_normal(m))
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    for it in range(3):
+        eng.step()
+        orc.step()
+        for name, tol in (('tau', 1e-11), ('theta', 1e-8), ('eta', 1e-8), ('beta', 1e-8), ('alpha', 1e-9)):
+            assert _rel(eng.get(name), orc.get(name)) < tol, (it, name, _rel(eng.get(name), orc.get(name)))
+        assert np.array_equal(eng.get('z'), orc.get('z'))
+        for name in ('alpha', 'beta', 'tau', 'theta', 'z'):
+            eng.set(name, orc.get(name))
+    eng.close()
+    keys = [KEY + c for c in range(2)]
+    starts = [dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.0 + c, eta=0.3 * rng.standard_normal(m)) for c in range(2)]
+    batch = Engine(prob, keys)
+    for c in range(2):
+        batch.set_start(c, **starts[c])
+    A, B, T = batch.run(9, 1)
+    solo = Engine(prob, [keys[1]])
+    solo.set_start(0, **starts[1])
+    for i in range(9):
+        solo.step()
+        if i >= 1:
+            assert np.array_equal(solo.get('alpha'), A[1, i - 1]) and np.array_equal(solo.get('beta'), B[1, i - 1]) and solo.get('tau') == T[1, i - 1]
+    assert np.array_equal(solo.get('theta'), batch.get('theta', 1))
+    assert abs(batch.get('eta', 0) - prob.rsr['K'] @ batch.get('theta', 0)).max() < 1e-11
+    batch.close()
+    solo.close()
+
+
 @pytest.mark.parametrize('env', [{}, {'OCC_CU_SPLIT': '0'}, {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EVENT_SYNC': '1'}],
                          ids=['two-streams-flag-handovers', 'no-cu-partition', 'one-stream', 'no-flag-handovers'])
 def test_reduced_rank_graph_replay_equals_stepping_and_batching(monkeypatch, env):
@@ -642,6 +689,49 @@ def test_scalar_wave_form_and_its_cu_partition_do_not_change_a_bit(monkeypatch, 
     for su, sv in zip(ref[1], alt[1]):
         for u, v in zip(su, sv):
             assert np.array_equal(u, v)
+
+
+def test_broken_stream_handover_falls_back_with_the_same_bits(monkeypatch):
+    """The two streams hand over through device counters, which presumes they run beside each other.  Debug knob: the side
+    stream's gate never announces its noise, as if the streams were served one after the other.  The first wait to give up
+    ends every other wait of the enqueued batch (one time-out, not three per iteration), and the call is re-run from its
+    start state without hand-overs: same records, same state, bit for bit -- on the fused ICAR path and on the reduced-rank
+    model (whose two-stream schedule has no fused kernel to fall back from, only the hand-overs)."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    monkeypatch.setenv('OCC_QUIET', '1')
+    ref = _headline_run(iters=10)
+
+    def rsr_run():
+        Q, W, X, y, *_ = make_lattice_problem(24, 30, visits=3, p=2, q=2, random_state=4)
+        prob = FlatProblem(Q, W, X, y)
+        m = prob.enable_rsr(q=40)['dim']
+        rng = np.random.default_rng(8)
+        eng = Engine(prob, [KEY, KEY + 1])
+        for c in range(2):
+            eng.set_start(c, alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.0 + c, eta=rng.standard_normal(m))
+        rec = eng.run(8, 0) + eng.run(5, 1)
+        out = rec, [eng.get('theta', c) for c in range(2)], eng.stats()
+        eng.close()
+        return out
+
+    rsr_ref = rsr_run()
+    assert rsr_ref[2]['fused_fallbacks'] == 0
+    monkeypatch.setenv('OCC_DEBUG_BREAK_HANDOVER', '1')
+    alt = _headline_run(iters=10)
+    assert alt[3]['fused_fallbacks'] == 1 and alt[3]['persistent_solve'] == 0
+    for u, v in zip(ref[0], alt[0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(ref[1], alt[1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+    rsr_alt = rsr_run()
+    assert rsr_alt[2]['fused_fallbacks'] == 1
+    for u, v in zip(rsr_ref[0], rsr_alt[0]):
+        assert np.array_equal(u, v)
+    for u, v in zip(rsr_ref[1], rsr_alt[1]):
+        assert np.array_equal(u, v)
 
 
 # ---- the reference's own form of the prior draw, and precisions the edge form cannot represent ---------------------
