@@ -136,8 +136,10 @@ typedef struct occ_stats {
                                  MINRES step, omega_a/alpha/noise on a side stream */
     int32_t solve_workgroups; /* workgroups per chain of the persistent solve */
     int32_t main_stream_cus;  /* > 0: CUs reserved for the main stream (k_iter, k_z_ob); the side stream has the others */
-    int32_t fused_fallbacks;  /* calls that were re-run on the launch-per-step path after a device-side wait in the fused kernel
-                                 gave up (its workgroups were not resident together); the engine stays on that path */
+    int32_t fused_fallbacks;  /* calls that were re-run without device-side waits after one of them gave up -- a barrier of the
+                                 fused kernel (its workgroups were not resident together) or a hand-over between the two
+                                 streams (they were not running beside each other); the engine stays on that path: one
+                                 launch per MINRES step (ICAR) / one stream (reduced-rank model) */
     double profile_minres_iterations; /* mean MINRES iterations per solve over the k_iter launches of the last occ_profile */
     int64_t iter_kernel_launches;     /* k_iter launches of the last occ_run ... */
     double iter_kernel_mean_us;       /* ... and their mean duration, first workgroup in to last chain out, by the
