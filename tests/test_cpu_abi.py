@@ -129,6 +129,16 @@ def test_reduced_rank_sampler_api(cpu_abi, data):
     assert s.state.eta.shape == (10,) and np.allclose(s.state.spatial, s.fixed.K @ s.state.eta, atol=1e-12)
     with pytest.raises(ValueError, match='Threshold value needs to be in'):
         LogitRSRGibbs(*data, r=1.1)
+    # the reference's default threshold keeps ~13 % of a lattice's sites (logit.py:415-446): more than the 128 columns the
+    # device's LDS-resident solve holds -- the host side takes them (the device's second path is tested with a GPU)
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(36, 36, visits=3, p=2, q=2, random_state=3)
+    big = LogitRSRGibbs(Q, W, X, y, random_state=4)
+    m = big.fixed.q
+    assert 128 < m < 300 and big.fixed.K.shape == (1296, m)
+    out = big.sample(4, chains=1, progressbar=False)
+    assert out['tau'].shape == (1, 4) and np.all(out['tau'] > 0) and np.all(np.isfinite(out['beta']))
+    assert np.allclose(big.state.spatial, big.fixed.K @ big.state.eta, atol=1e-11)
 
 
 def test_errors_map_to_the_references_exceptions(cpu_abi, data):
