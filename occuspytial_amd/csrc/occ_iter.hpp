@@ -368,39 +368,51 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     // on the XCDs that host a chain and leaves the others to the side stream).  The grid is 8 x (nbg + 1) workgroups:
     // those on an XCD without a chain and those that find the chain complete return at once.
     __shared__ int s_claim;
-    int chain, wg;
+    int chain, wg = 0;
     const unsigned my_xcc = XL ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) : 0u;  // HW_REG_XCC_ID
+    const bool synced = sync_on && ia.sync != nullptr;
+    // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said by the
+    // first workgroup of the grid before anything can return or wait.
+    int ticket = 0;
     if (XL) {
         if ((int)my_xcc >= min(ia.C - ia.chain_base, XL_SLOTS)) return;
         chain = ia.chain_base + (int)my_xcc;
-        if (threadIdx.x == 0) s_claim = (int)__hip_atomic_fetch_add(ia.claim + (size_t)chain * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        wg = __builtin_amdgcn_readfirstlane(s_claim);
-        if (wg >= ia.nbg) return;
+        if (threadIdx.x == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + (size_t)chain * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         chain = (int)blockIdx.y;
         wg = (int)blockIdx.x;
     }
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
-    // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said
-    // before anything can return or wait.
-    if (sync_on && ia.sync != nullptr && wg == 0 && chain == 0 && threadIdx.x == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ + e]);
+    // what needs neither the slot nor the noise is on its way while the claim's atomic returns: the chain's control words,
+    // and one lane's wait for the noise of this iteration (from the side stream's previous sequence; normally it has been
+    // there for a whole iteration -- the workgroup looks at the result before phase A's loads of the noise)
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
-    const bool writer = (wg == 0 && threadIdx.x == 0);
-    // (a chain whose error word is set idles like a finished one: see chain_fail)
-    if (!probe && (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0)) {  // uniform over the chain's workgroups
-        if (writer) sc.mid[e] = ctl;
-        return;
+    const uint32_t it_stop = sc.it_stop;
+    const int err0 = sc.err;
+    if (XL) {
+        if (threadIdx.x == 0) s_claim = ticket;
+        __syncthreads();
+        wg = __builtin_amdgcn_readfirstlane(s_claim);
+        if (wg >= ia.nbg) return;
     }
-    const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
-    // the noise of this iteration comes from the side stream's previous sequence: one lane starts waiting for it
-    // now (normally it has been there for a whole iteration); the workgroup looks at the result before phase A's loads
-    const bool synced = sync_on && ia.sync != nullptr;
     if (synced && threadIdx.x == 0) {
         const unsigned j = ia.sync[SYNC_MAIN_SEQ + e];      // this sequence's number (the previous sequence left it)
         s_noise_ok = sync_wait(ia.sync, SYNC_NOISE, j) ? 1 : 0;
     }
+    const bool writer = (wg == 0 && threadIdx.x == 0);
+    // k_z_ob of the previous sequence is complete (stream order): the side stream may start this sequence.  Said before
+    // anything can return or wait -- but by the workgroup that claimed the first slot of chain 0, not at kernel entry: the
+    // side stream answers with grids of thousands of workgroups, and released a microsecond earlier (by the first
+    // workgroup of the grid, before its claim) they got between the dispatcher and k_iter's own workgroups: k_iter 44.7 ->
+    // 57 us.  (Later -- after the first barrier among the chain's workgroups -- changes nothing.)
+    if (synced && writer && chain == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ + e]);
+    // (a chain whose error word is set idles like a finished one: see chain_fail)
+    if (!probe && (ctl.koff || ctl.it >= it_stop || err0 != 0)) {  // uniform over the chain's workgroups
+        if (writer) sc.mid[e] = ctl;
+        return;
+    }
+    const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
     const uint32_t it = ctl.it;
     // the scalar wave (SW): a wave-uniform fact the compiler can see (a scalar register), so that the two roles of the
     // solve below are two loops, each with its own registers, not one loop under an execution mask
@@ -461,7 +473,25 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     double2 xn[NW];
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) { off[kk] = myoff; av[kk] = 0.0; xn[kk] = zero2; nm1[kk] = zero2; nm2[kk] = zero2; }
-    if (!scalar_wave) {  // (the scalar wave owns no site: nothing stands between it and tau -- its loads sat in front of tau's)
+    // (the scalar wave owns no site: nothing stands between it and tau.)  The site waves issue their first level of loads,
+    // pass the noise hand-over's barrier at once -- the scalar wave is waiting there to start on tau -- and only then
+    // take the neighbour gathers, whose addresses are loaded values
+    int jraw[NW];
+    double vraw[NW];
+#pragma unroll
+    for (int kk = 0; kk < NW; ++kk) { jraw[kk] = 0; vraw[kk] = 0.0; }
+    auto neighbours = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) {
+            const bool has = act && kk < width;
+            const int j = has ? jraw[kk] : ic;
+            off[kk] = has ? j * 16 : myoff;
+            av[kk] = vraw[kk];
+            hasmask |= has ? (1u << kk) : 0u;
+            xn[kk] = X0[j];
+        }
+    };
+    if (!scalar_wave) {
         om = a.omega_b[it & 1][ci];
         zval = (double)ia.z[ci];
         xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
@@ -469,16 +499,11 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         qd = a.qdiag[ic];
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) {
-            const bool has = act && kk < width;
             const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-            const int jraw = a.sell_col[slot];
-            const double vraw = a.sell_val[slot];
-            const int j = has ? jraw : ic;
-            off[kk] = has ? j * 16 : myoff;
-            av[kk] = vraw;
-            hasmask |= has ? (1u << kk) : 0u;
-            xn[kk] = X0[j];
+            jraw[kk] = a.sell_col[slot];
+            vraw[kk] = a.sell_val[slot];
         }
+        if (!SW) neighbours();  // (without a scalar wave nobody waits at the barrier below: no reason to hold the indices across it)
     }
     if (synced) {  // thread 0's wait for the side stream's noise kernel (started at kernel entry) is over: s_noise_ok is set
         __syncthreads();
@@ -486,12 +511,15 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     }
     double en = 0.0, up = 0.0;
     if (scalar_wave) {
-    } else if (synced) {
-        en = load_agent(&ia.enorm[it & 1][ci]);
-        up = load_agent(&ia.uprior[it & 1][ci]);
     } else {
-        en = ia.enorm[it & 1][ci];
-        up = ia.uprior[it & 1][ci];
+        if (synced) {
+            en = load_agent(&ia.enorm[it & 1][ci]);
+            up = load_agent(&ia.uprior[it & 1][ci]);
+        } else {
+            en = ia.enorm[it & 1][ci];
+            up = ia.uprior[it & 1][ci];
+        }
+        if (SW) neighbours();
     }
     double tau = 0.0;
     if (lead) {
