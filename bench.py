@@ -345,7 +345,7 @@ def main():
         split = {'value': 4 * args.steps / el4, 'unit': 'iterations/s', 'scaling': 'strong', 'total_chains': 4,
                  'chains_per_gpu': per, 'ms_per_step': 1e3 * el4 / args.steps,
                  'note': 'the metric\'s 4 chains, chain c on GPU c % N; one chain alone still pays the whole latency-bound '
-                         'iteration (about 85 us at 100x100), so this split gains little over 1 GPU -- the weak line above '
+                         'iteration (about 65 us at 100x100), so this split gains little over 1 GPU -- the weak line above '
                          '(4 chains on every GPU) is what more GPUs buy'}
 
     if rank == 0:

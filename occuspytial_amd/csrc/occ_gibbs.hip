@@ -1962,7 +1962,7 @@ static int fallback_to_launch_per_step(occ_sampler *s)
     if (s->side) (void)hipStreamSynchronize(s->side);
     (void)hipGetLastError();
     if (std::getenv("OCC_VERBOSE") || !std::getenv("OCC_QUIET"))
-        std::fprintf(stderr, "[occ] a device-side wait timed out (%s); re-running the call without hand-overs between the streams%s\n",
+        std::fprintf(stderr, "[occ] %s -- re-running the call without hand-overs between the streams%s\n",
                      s->err.c_str(), s->rsr.m > 0 ? "" : ", one launch per MINRES step");
     destroy_graph(s);
     s->persistent = false;
