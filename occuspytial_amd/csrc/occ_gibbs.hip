@@ -82,6 +82,7 @@ struct occ_sampler {
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
     int xl_per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... per XCD, when the XCDs that host a chain get more than the others (first entry 0: evenly)
     int main_hot_cus = 0;    // CUs the main stream's mask holds on XCD 0 (a chain's XCD)
+    bool streams_serialised = false;  // the stream probe at creation found the two streams served one after the other
     std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
     bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
     int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
@@ -1142,6 +1143,25 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 if (hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()) == hipSuccess) {
                     s->main_cus = nmain;
                     s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
+                    // Device-side hand-overs need the two streams to RUN beside each other.  Seen on ROCm 7.2 with several
+                    // engines alive in one process: both streams of a new engine served by one hardware queue -- every
+                    // hand-over of every iteration then runs into its time-out.  Ask: a kernel on the side stream waits (at
+                    // most ~20 ms) for a word that a kernel launched AFTER it on the main stream sets.
+                    if (s->flag_sync && !std::getenv("OCC_DEBUG_SKIP_STREAM_PROBE")) {
+                        unsigned *w = nullptr, seen = 0u;
+                        if ((rc = dev_alloc(s, &w, 32))) return rc;
+                        hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(64), 0, s->side, w);
+                        hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, w);
+                        HIP_TRY(hipStreamSynchronize(s->stream));
+                        HIP_TRY(hipStreamSynchronize(s->side));
+                        HIP_TRY(copy_on(s, &seen, w + 16, sizeof(seen), hipMemcpyDeviceToHost));
+                        if (std::getenv("OCC_DEBUG_STREAMS_SERIALISED")) seen = 0u;  // tests: take the branch below
+                        if (!seen) {
+                            s->flag_sync = false;  // hand-overs by event nodes (ICAR) / everything on one stream (reduced-rank model)
+                            s->streams_serialised = true;
+                            if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] the two streams do not run beside each other: no device-side hand-overs\n");
+                        }
+                    }
                 } else {
                     (void)hipStreamDestroy(s->stream);
                     s->stream = nullptr;

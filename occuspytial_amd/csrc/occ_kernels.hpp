@@ -694,6 +694,24 @@ __device__ __forceinline__ double load_agent(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Do the two streams run beside each other?  The hand-overs above presume it.  k_stream_probe_wait (side stream, launched
+// first) looks for the word k_stream_probe_set (main stream, launched second) writes: streams that share a hardware queue
+// run the two in launch order and the word is never seen (occ_gibbs.hip, create_impl).
+__global__ void __launch_bounds__(64) k_stream_probe_wait(unsigned *w)
+{
+    if (threadIdx.x != 0) return;
+    unsigned seen = 0u;
+    for (unsigned spins = 0; spins < (1u << 13); ++spins) {  // ~ 20 ms
+        if (sync_read(w) != 0u) { seen = 1u; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    w[16] = seen;
+}
+__global__ void __launch_bounds__(64) k_stream_probe_set(unsigned *w)
+{
+    if (threadIdx.x == 0) sync_set(w, 1u);
+}
+
 // First kernel of a side-stream sequence: one lane announces that the previous k_noise is complete, then waits
 // until the main stream has finished the previous sequence.
 __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs)
