@@ -287,7 +287,8 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
     switch (kind) {
         case K_OMEGA_B: hipLaunchKernelGGL(pick_omega_b(tp), gs, blk, 0, st, OCC_ARGS); break;
         case K_NOISE:
-            hipLaunchKernelGGL(k_noise, shared_grid(c, 2, c.nb_n), blk, 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
+            // (256-thread blocks whatever the other kernels take: the first block of a chain also draws alpha, a wave per quantity)
+            hipLaunchKernelGGL(k_noise, shared_grid(c, 2, (c.n + 255) / 256), dim3(256), 0, st, OCC_ARGS, extra, (extra == 1 && s->launch_sync) ? 1 : 0);
             if (c.dense_F != nullptr) {  // reference-form prior draw: uprior = F eps2, four chains per pass over F
                 const dim3 gd((unsigned)((c.n + 3) / 4));
                 for (int ch0 = 0; ch0 < c.C; ch0 += 4) hipLaunchKernelGGL(k_prior_dense<4>, gd, dim3(256), 0, st, s->ctx_dev, s->ctx.sc, ch0, e, extra);
@@ -442,7 +443,6 @@ int eager_krylov(occ_sampler *s, int k_from, int *k_last)
 int launch_rsr_sequence(occ_sampler *s, hipStream_t st, int e)
 {
     LAUNCH(s, st, K_OMEGA_A, e);
-    LAUNCH(s, st, K_ALPHA_DRAW, e);
     LAUNCH(s, st, K_NOISE, e, 1);
     LAUNCH(s, st, K_RSR_GRAM, e);
     LAUNCH(s, st, K_RSR_SOLVE, e);
@@ -467,7 +467,6 @@ int eager_sequence(occ_sampler *s)
         return take_launch_rc(s);
     }
     LAUNCH(s, s->stream, K_OMEGA_A, e);
-    LAUNCH(s, s->stream, K_ALPHA_DRAW, e);
     LAUNCH(s, s->stream, K_NOISE, e, 1);
     if (s->persistent) {
         LAUNCH(s, s->stream, K_ITER, e);
@@ -565,7 +564,6 @@ int build_graph(occ_sampler *s, int cap)
         for (int t = 0; t < GRAPH_SEQ; ++t) {
             LAUNCH(s, s->side, K_GATE, 0);
             LAUNCH(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
-            LAUNCH(s, s->side, K_ALPHA_DRAW, s->parity ^ (t & 1));
             LAUNCH(s, s->side, K_NOISE, s->parity ^ (t & 1), 1);
         }
         HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[0]));
@@ -603,7 +601,6 @@ int build_graph(occ_sampler *s, int cap)
             HIP_TRY(hipGraphAddEventWaitNode(&wait, s->tail_graph[e], nullptr, 0, s->ev_z[e ^ 1]));
             HIP_TRY(hipStreamBeginCaptureToGraph(s->side, s->tail_graph[e], &wait, nullptr, 1, hipStreamCaptureModeThreadLocal));
             LAUNCH(s, s->side, K_OMEGA_A, e);
-            LAUNCH(s, s->side, K_ALPHA_DRAW, e);
             LAUNCH(s, s->side, K_NOISE, e, 1);
             hipGraph_t same = nullptr;
             HIP_TRY(hipStreamEndCapture(s->side, &same));
@@ -612,7 +609,6 @@ int build_graph(occ_sampler *s, int cap)
         } else {
             HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
             LAUNCH(s, s->side, K_OMEGA_A, e);
-            LAUNCH(s, s->side, K_ALPHA_DRAW, e);
             LAUNCH(s, s->side, K_NOISE, e, 1);
             HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[e]));
         }
@@ -1073,6 +1069,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                     rest = 4 * (int)std::lround((double)(base - hot * need) / (4.0 * (XL_SLOTS - hot)));
                     rest = std::max(8, std::min(rest, need));
                     while (hot * need + (XL_SLOTS - hot) * rest > ncu - 96 && rest > 8) rest -= 4;  // the side stream keeps 96 CUs
+                    if (const char *cc = std::getenv("OCC_DEBUG_COLD_CUS")) rest = std::max(4, std::min(std::atoi(cc) / 4 * 4, need));  // developer knob
                 }
                 for (int x = 0; x < XL_SLOTS; ++x) { wide_xcd[x] = x < hot ? need : rest; wide_main += wide_xcd[x]; }
             }
@@ -1193,7 +1190,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     s->beta_split = tpb != 64 && c.nb_n >= 128 && !std::getenv("OCC_NO_BETA_SPLIT");
     c.nb_r = std::max(1, (R + tpb - 1) / tpb);
     if (c.share_on) {  // tiles of the device-filling kernels per XCD, in proportion to the CUs of their stream
-        const int per_chain[3] = {tpb == 64 ? 2 * ((n + 255) / 256) : 2 * c.nb_n, c.nb_r, c.nb_n}, which[3] = {0, 1, 1};
+        const int per_chain[3] = {tpb == 64 ? 2 * ((n + 255) / 256) : 2 * c.nb_n, c.nb_r, (n + 255) / 256}, which[3] = {0, 1, 1};
         c.surplus_last = 0;
         if (const char *sl = std::getenv("OCC_DEBUG_SURPLUS_LAST")) c.surplus_last = std::atoi(sl);
         if (const char *cw = std::getenv("OCC_DEBUG_MAIN_SHARE")) {  // developer knob: weight of an XCD without a chain in k_z_ob's shares
@@ -2250,7 +2247,6 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             if (ev) HIP_TRY(hipStreamWaitEvent(side, s->ev_z[pe ^ 1], 0));
             if (flags) LAUNCH(s, side, K_GATE, 0);
             LAUNCH(s, side, K_OMEGA_A, pe);
-            LAUNCH(s, side, K_ALPHA_DRAW, pe);
             LAUNCH(s, side, K_NOISE, pe, 1);
             if (ev) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
             HIP_TRY(hipEventRecord(s->ev0, s->stream));

@@ -652,7 +652,7 @@ __device__ __forceinline__ bool precision_mvnorm_reg(const double (&acc)[nacc(D)
 // kernel-boundary release make that exact and free -- no tickets, no fences, no write-through stores):
 //   sync[SYNC_MAIN]   = j  set by k_iter(j):  k_z_ob(j-1) is complete     k_gate(j) waits for >= j   (z, control words)
 //   sync[SYNC_NOISE]  = j  set by k_gate(j):  k_noise(j-1) is complete    k_iter(j) waits for >= j   (noise of j)
-//   sync[SYNC_ALPHA]  = j+1 set by k_noise(j): k_alpha_draw(j) is complete k_z_ob(j) waits for >= j+1 (alpha of j)
+//   sync[SYNC_ALPHA] += 1 per chain by k_noise(j) once alpha of j is stored       k_z_ob(j) waits for >= (j+1) C (alpha of j)
 // Every kernel sets before it waits, so the two streams cannot wait for each other.  Each stream counts its
 // own sequences in words only it touches (SYNC_MAIN_SEQ + parity of the sequence: the last kernel of a main-stream
 // sequence writes the word of the NEXT sequence's parity, so no kernel reads a word that is written while it runs;
@@ -895,24 +895,49 @@ __global__ void __launch_bounds__(256) k_prior_dense(const Ctx *__restrict__ cp,
     }
 }
 
+// k_noise also draws alpha ~ N(A^-1 r, A^-1) of THIS iteration (logit.py:224) from the partial sums of k_omega_a, the previous
+// kernel of the sequence: the first block of every chain, before its own tile of noise (ahead = 1 only: the stand-alone
+// launch after new start values draws no alpha).  As a kernel of its own between k_omega_a and k_noise (k_alpha_draw,
+// still used by occ_cond_alpha) the draw was 7 us of four busy workgroups plus a launch boundary on the side stream --
+// which bounds the iteration once the solves get short (K ~ 6 late in a run: 56.9 -> 50 us per iteration; the first
+// iterations of a run likewise).  With device-side hand-overs the drawing block publishes alpha itself (agent-scope
+// stores, then one count per chain in sync[SYNC_ALPHA]; k_z_ob waits for C counts per sequence).
 __global__ void __launch_bounds__(256) k_noise(OCC_KARGS, int ahead, int sync_on)
 {
+    __shared__ double s_red[NACC_G], s_U[MAXG * MAXG], s_work[2 * MAXG], s_alpha[MAXG];
     const Ctx &c = *cp;
-    const Tile tile = tile_of_block_shared(c, 2, c.nb_n, chain_base);
+    const Tile tile = tile_of_block_shared(c, 2, (c.n + (int)blockDim.x - 1) / (int)blockDim.x, chain_base);
     const int chain = tile.chain, blk = tile.blk;
-    if (sync_on && c.sync && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const bool synced = sync_on && c.sync;
+    if (synced && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const unsigned j = c.sync[SYNC_SIDE_SEQ];
-        sync_set(c.sync + SYNC_ALPHA, j + 1u);  // k_alpha_draw of this sequence, the previous kernel of the stream, is complete
         c.sync[SYNC_SIDE_SEQ] = j + 1u;         // read next by k_gate, the next kernel of the stream
     }
     if (chain < 0) return;
-    const ChainScalars &sc = scs[chain];
+    ChainScalars &sc = scs[chain];
     const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    const bool idle = ctl.koff || ctl.it >= sc.it_stop || sc.err != 0;  // (uniform over the chain's blocks)
+    if (ahead == 1 && blk == 0) {
+        if (!idle) {
+            const int Q = c.q;
+            reduce_partials_lds(c.part_alpha + (size_t)chain * nacc(Q) * c.nb_r, nacc(Q), c.nb_r, s_red);
+            if (threadIdx.x == 0) {
+                const double *a_prec = c.hyp, *a_pbm = c.hyp + Q * Q;
+                const bool ok = precision_mvnorm_dev(Q, s_red, a_prec, a_pbm, sc.key, ctl.it, STREAM_ALPHA, s_U, s_work, s_alpha, nullptr);
+                if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
+                for (int a = 0; a < Q; ++a) __hip_atomic_store(&sc.alpha[a], s_alpha[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (synced && threadIdx.x == 0) {  // (an idle chain counts too: k_z_ob waits for every chain of the sequence)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(c.sync + SYNC_ALPHA, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (idle) return;
     const uint32_t it_for = ctl.it + (uint32_t)ahead;
     if (blk == 0 && threadIdx.x == 0) {  // tau's standard gamma variate of that iteration (the rate comes later)
         Cursor g(sc.key, 0u, it_for, STREAM_TAU);
-        scs[chain].tau_gamma[it_for & 1] = std_gamma(g, c.tau_shape);
+        sc.tau_gamma[it_for & 1] = std_gamma(g, c.tau_shape);
     }
     const int i = blk * blockDim.x + threadIdx.x;
     if (i >= c.n) return;
@@ -1687,7 +1712,7 @@ __device__ __forceinline__ void omega_a_row_g(const Ctx &c, const ChainScalars &
 }
 
 template <int Q, int INJ = 0>
-__global__ void __launch_bounds__(256) k_omega_a(OCC_KARGS)
+__global__ void __launch_bounds__(256, 3) k_omega_a(OCC_KARGS)
 {
     const Ctx &c = *cp;
     const Tile tile = tile_of_block_shared(c, 1, c.nb_r, chain_base);
@@ -1856,7 +1881,7 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
     const int Q = c.q;
     double alpha[MAXC];
     if (synced) {
-        if (threadIdx.x == 0) s_wait_ok = sync_wait(c.sync, SYNC_ALPHA, seq + 1u) ? 1 : 0;
+        if (threadIdx.x == 0) s_wait_ok = sync_wait(c.sync, SYNC_ALPHA, (seq + 1u) * (unsigned)c.C) ? 1 : 0;  // one count per chain and sequence (k_noise)
         __syncthreads();
         if (!s_wait_ok && writer) sc.err = -2;
 #pragma unroll
