@@ -10,7 +10,7 @@
 // iteration t, so (with counter-based variates, results do not depend on execution order):
 //
 //   main stream  [tau, rhs, eta solve, projection, beta sums] -> k_z_ob
-//   side stream  k_omega_a -> k_alpha_draw -> k_noise(t+1)        (needed by k_z_ob / the next iteration)
+//   side stream  k_omega_a -> k_noise (alpha of t, noise of t+1)  (needed by k_z_ob / the next iteration)
 //
 // The bracket is ONE launch of k_iter (occ_iter.hpp) when all its workgroups fit on the device, else
 // k_eta_init -> k_minres x (cap+3) -> k_beta_partial, where a kernel boundary is the only grid-wide
@@ -19,15 +19,16 @@
 //   k_omega_b      omega_b ~ PG(1, x'beta + eta) per site; eta'Q eta partials (logit.py:195-204, 208);
 //                  stand-alone only for the first iteration after new start values -- afterwards it is
 //                  the second role of k_z_ob
-//   k_noise        the variates of the eta right-hand side that depend on nothing but the iteration
-//                  number: site normals and the edge form of the ICAR prior term (logit.py:75-77)
+//   k_noise        the alpha draw of this iteration (logit.py:224; first block of every chain), then the variates of the
+//                  eta right-hand side that depend on nothing but the iteration number, one iteration ahead: site
+//                  normals and the edge form of the ICAR prior term (logit.py:75-77), tau's gamma variate
 //   k_eta_init     tau ~ Gamma (logit.py:206-209); rhs y (logit.py:213, 78); r1 = [y;1] - Lambda x0
 //   k_minres       one Lanczos/MINRES iteration of the joint 2n system per launch
 //                  (scipy _isolve/minres.py as called at logit.py:87)
 //   k_beta_partial eta = x - (sum x / sum z) z (distributions.pyx:24-39); X' Omega X, X'(k - omega eta)
 //   k_omega_a      omega_a ~ PG(1, w'alpha) for rows of existing sites; W' Omega W, W'(y - 1/2)
 //                  (logit.py:180-193, 219-223)
-//   k_alpha_draw   alpha draw (logit.py:224), one block per chain
+//   k_alpha_draw   alpha draw (logit.py:224) as a kernel of its own: occ_cond_alpha (injected variates) and occ_profile
 //   k_z_ob         beta draw (logit.py:232, every wave); role 0: z update (logit.py:234-252), record
 //                  (alpha, beta, tau) (base.py:238-239), advance the iteration; role 1 (other half of the
 //                  grid): omega_b of the NEXT iteration
