@@ -1,7 +1,8 @@
 // occ_iter.hpp -- k_iter: the critical path of one Gibbs iteration of every chain in ONE persistent launch (gfx950).
 //
-// nbg workgroups of 256 (or, one XCD per chain on larger lattices, 512) threads per chain, one site per thread, ALL
-// of them resident at once (the host takes this path only when they fit at most two per CU).  Per chain, in order:
+// nbg workgroups of 256 (or, one XCD per chain on larger lattices, 512: 448 sites beside a scalar wave, or 512 sites)
+// threads per chain, one site per thread, ALL of them resident at once (the host takes this path only when they fit at
+// most two per CU).  Per chain, in order:
 //   A  tau ~ Gamma (logit.py:206-209), right-hand side of the eta system (logit.py:75-78, 213),
 //      p_0 = b - A x0 with the warm start x0 (logit.py:71, 82-88)                         [k_eta_init]
 //   B  joint MINRES for [x z] (logit.py:82-92), vectors in registers, one barrier per step AMONG THE WORKGROUPS
@@ -23,13 +24,16 @@
 //     chain's arrival counter (agent scope) and polls it, then every load of exchanged bytes is an sc1 load (per-CU
 //     L1 bypassed).  Visibility never depends on where a workgroup runs (the XCDs' L2s are not coherent with each
 //     other), and every hop is a round trip to the memory side: 2.3 us per store -> barrier -> load (tools/xcc_probe4).
-//   XL = 1, ONE XCD PER CHAIN: the grid is (8, nbg) and the chain is blockIdx.x -- workgroups are dealt to the eight
-//     XCDs round-robin in linear order, so all workgroups of a chain share one XCD and its L2.  Payload and one
-//     arrival FLAG per workgroup are PLAIN stores (they stay in that L2), every load of exchanged bytes and every
-//     poll is an sc1 load (L1 bypassed, L2-served): 0.7 us per store -> barrier -> load, no atomics.  A flag carries
-//     the XCC_ID of its writer and every poll checks it against the reader's: a launch whose placement differs
-//     fails loudly (OCC_E_HIP) instead of reading another XCD's stale lines.  The host verifies the placement with
-//     a probe launch before it takes this form (create_impl).
+//   XL = 1, ONE XCD PER CHAIN: a workgroup works for the chain of the XCD it runs on (HW_REG_XCC_ID) and claims its
+//     place among that chain's workgroups from a counter, so all workgroups of a chain share one XCD and its L2
+//     whatever the dispatcher does with the grid.  Payload and arrival flags are PLAIN stores (they stay in that L2),
+//     every load of exchanged bytes and every poll is an sc1 load (L1 bypassed, L2-served): 0.7 us per store ->
+//     barrier -> load, no atomics in the loop.  In the solve a slice's RECORD of a step is its arrival flag (see "XL
+//     step exchange" below); the barriers of phases A and C use one flag word per workgroup, which carries the XCC_ID
+//     of its writer -- every poll checks it against the reader's and a launch whose placement differs fails loudly
+//     (OCC_E_HIP) instead of reading another XCD's stale lines.  The host verifies residency with a probe launch
+//     before it takes this form (create_impl).  With 512 threads per workgroup the first wave owns no sites and runs
+//     the scalar recurrence for the seven site waves (template parameter W512 = 1; see k_iter).
 // The arrival counter / flag values are monotonic over the whole run (ChainScalars::bar_base).
 //
 // The arithmetic is that of the stand-alone kernels, through the same functions (minres_pre/post, kry_form_*,
