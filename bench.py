@@ -17,9 +17,11 @@ from this one process, a host thread each (EngineGroup).
 
 The JSON line also carries
   roofline     : the dominant kernel (k_iter: tau, right-hand side, the whole MINRES solve of eta, projection
-                 and beta sums of one iteration, all chains): algorithmic bytes per launch / its mean launch
-                 time, measured live right after the timed region with two HIP events around each of 200
-                 k_iter launches on the engine's main stream while the chains keep running (occ_profile);
+                 and beta sums of one iteration, all chains): algorithmic bytes per launch / its mean DISPATCH
+                 duration -- the start / stop events of hipExtLaunchKernel on the engine's main stream, i.e. the
+                 timestamps rocprofv3 reports for the kernel -- over 200 launches that continue the chains right after
+                 the timed region (occ_profile); roofline.in_kernel_clock: every launch of the timed region clocked
+                 from inside the kernel;
   cpu_baseline : the CPU oracle (C restatement of the reference loop, oracle/) in reference-faithful mode (dense
                  eigenfactor prior draw, one thread per chain): 4 chains on 4 threads, and one chain per host core
                  (rank 0, N = 1 only; bounded samples).
@@ -348,6 +350,15 @@ def main():
                          'iteration (about 65 us at 100x100), so this split gains little over 1 GPU -- the weak line above '
                          '(4 chains on every GPU) is what more GPUs buy'}
 
+    # ---- who took part (N > 1): every rank reports itself THROUGH the communicator the broadcast ran on -- with RCCL that
+    # is ncclBroadcast between the ranks' devices, so a rank that RCCL does not reach cannot appear
+    ranks_info = None
+    if n_dev > 1:
+        seen = comm.allgather_obj({'rank': rank, 'local_rank': local_rank, 'device': local_rank, 'chains': len(mine_ids), 'pid': os.getpid()})
+        ranks_info = {'ranks_seen_by_rccl' if 'rccl' in comm_note.split(' ')[0] else 'ranks_seen_by_file_rendezvous': len(seen),
+                      'distinct_devices': len({(r['device']) for r in seen}) if world > 1 else n_dev,
+                      'communicator': comm_note, 'members': seen}
+
     if rank == 0:
         # ---- roofline of the dominant kernel, live, HIP events on the engine's stream --------------
         eng0 = eng.engines[0] if in_process else eng
@@ -382,6 +393,29 @@ def main():
                       '(k_eta_init + k_minres launches 1..8, every launch cache-cold as in the real solve), '
                       'k_eta_init subtracted; = kernel duration + one dependent-launch boundary')
         achieved = bytes_launch / (ka['avg_us'] * 1e-6) / 1e9 if ka['avg_us'] > 0 else 0.0
+        # The number rocprofv3 reproduces (the in-kernel clock stops ~3 us short of what the profiler reports for
+        # the same launch -- launch ramp and end-of-kernel release are outside a kernel's own view): the DISPATCH duration
+        # of k_iter, from the start / stop events of hipExtLaunchKernel (the begin / end timestamps of the dispatch's
+        # completion signal, the profiler's own basis), over the 200 in-situ launches that follow the timed region, with the
+        # MINRES steps THOSE launches ran.  `frac` is quoted on this basis; the in-kernel clock of the timed region stays
+        # beside it.
+        in_kernel = {'achieved': round(achieved, 1), 'frac': round(achieved / HBM_PEAK_GBS, 4), 'avg_launch_us': round(ka['avg_us'], 3),
+                     'launches_timed': ka['launches'], 'bytes_per_launch': bytes_launch,
+                     'minres_steps_per_launch': round(steps, 2) if steps else None,
+                     'basis': 'device wall clock read inside k_iter, first workgroup in to last chain out, every launch of the timed region'}
+        stats_prof = eng0.stats()
+        disp_us = stats_prof.get('profile_iter_dispatch_us', 0.0)
+        if fused and disp_us > 0:
+            steps = stats_prof['profile_minres_iterations'] + 3.0
+            bytes_launch = iter_bytes_per_launch(prob, C, sell, steps)
+            ka = {'avg_us': disp_us, 'launches': prof['iter_in_situ_hip_events']['launches']}
+            achieved = bytes_launch / (disp_us * 1e-6) / 1e9
+            timing = ('DISPATCH duration of k_iter (hipExtLaunchKernel start / stop events = the begin / end timestamps of the '
+                      'dispatch\'s completion signal, which is what rocprofv3 --kernel-trace reports) over 200 real iterations '
+                      'that continue the chains right after the timed region, the side stream running as in occ_run; bytes from '
+                      'the MINRES steps those launches ran.  roofline.in_kernel_clock: every launch of the timed region clocked '
+                      'from inside the kernel (shorter: it cannot see the launch ramp and the end-of-kernel release); '
+                      'profiles/r03_bench_kernel_trace_region.json: rocprofv3 kernel trace of this command, the same launches')
         traffic, traffic_file = pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else (None, None)
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
         # SURVEY 8(d)'s whole-iteration accounting beside the dominant kernel's: B_iter(measured K, R_e = R, n_no = 0.4 n)
@@ -425,6 +459,7 @@ def main():
                 'launches_timed': ka['launches'],
                 'timing': timing,
                 'minres_steps_per_launch': round(steps, 2) if steps else None,
+                'in_kernel_clock': in_kernel,
                 'algorithmic_bytes_per_minres_step': minres_bytes_per_launch(prob, C, sell),
                 'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['iter' if fused else 'minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},
@@ -436,6 +471,15 @@ def main():
                     'frac': round(whole / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             },
         }
+        if n_dev > 1:
+            # how to read a SCALE curve from these lines: `value` is WEAK scaling -- every GPU runs the metric's
+            # 4 chains -- so value / n_gpus is what compares with the N = 1 line (BENCH); split_4_chains is the metric's
+            # literal 4 chains divided over the GPUs (strong scaling: one chain alone still pays the latency-bound iteration)
+            out['value_per_gpu'] = out['value'] / n_dev
+            out['n1_equivalent'] = {'value': out['value'] / n_dev, 'unit': 'iterations/s',
+                                    'note': 'value / n_gpus: each GPU runs the N = 1 workload (4 chains); compare with the N = 1 line'}
+            out['scale_curve'] = 'read `value` (weak: 4 chains per GPU); efficiency = value(N) / (N * value(1))'
+            out['ranks'] = ranks_info
         if split is not None:
             out['split_4_chains'] = split
         if n_dev == 1 and not args.no_cpu_baseline:

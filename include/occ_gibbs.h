@@ -14,9 +14,10 @@
  *  - input pointers may be host or device memory (copied with hipMemcpyDefault); the library never
  *    frees or keeps caller memory; outputs are host buffers owned by the caller;
  *  - all real data is IEEE float64, C-contiguous; index arrays are int32;
- *  - a handle is driven by one host thread at a time; different handles (one per GPU) are
- *    independent, and ctypes releases the GIL so host threads can drive several GPUs (occ_create_group;
- *    occuspytial_amd.gibbs.LogitICARGibbs(..., devices=[...]) does exactly that);
+ *  - a handle is driven by one host thread at a time; handles on DIFFERENT devices are independent, and ctypes
+ *    releases the GIL so host threads can drive several GPUs (occ_create_group;
+ *    occuspytial_amd.gibbs.LogitICARGibbs(..., devices=[...]) does exactly that); handles on the SAME device share
+ *    that device's pooled streams and their calls run one after the other (a per-device lock inside the library);
  *  - there is NO CPU fallback: creation fails with OCC_E_HIP when no gfx950 device is usable.
  */
 #ifndef OCC_GIBBS_H
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 4
+#define OCC_ABI_VERSION 5
 #define OCC_MAX_COVARIATES 32 /* p and q limit.  Up to 8 of each: kernels with the p x p / q x q accumulators in registers and the
                                 fused iteration kernel; 9 to 32: generic kernels (run-time p and q, terms reduced one at a time,
                                 Cholesky factor in LDS) on the launch-per-step path */
@@ -138,12 +139,26 @@ typedef struct occ_stats {
     int32_t main_stream_cus;  /* > 0: CUs reserved for the main stream (k_iter, k_z_ob); the side stream has the others */
     int32_t fused_fallbacks;  /* calls that were re-run without device-side waits after one of them gave up -- a barrier of the
                                  fused kernel (its workgroups were not resident together) or a hand-over between the two
-                                 streams (they were not running beside each other); the engine stays on that path: one
-                                 launch per MINRES step (ICAR) / one stream (reduced-rank model) */
+                                 streams (they were not running beside each other); the engine then runs one launch per
+                                 MINRES step (ICAR) / on one stream (reduced-rank model) until a later call finds the device
+                                 as creation found it (repromotions) */
     double profile_minres_iterations; /* mean MINRES iterations per solve over the k_iter launches of the last occ_profile */
     int64_t iter_kernel_launches;     /* k_iter launches of the last occ_run ... */
     double iter_kernel_mean_us;       /* ... and their mean duration, first workgroup in to last chain out, by the
                                          device's constant-rate wall clock read inside the kernel */
+    /* ABI 5: streams are pooled per (process, device, CU partition) -- a CU-masked stream holds one of the device's 24
+     * hardware queues for itself, and a process that oversubscribes them gets its queues time-sliced */
+    int32_t repromotions;         /* returns to the fused kernel / device-side hand-overs after a run-time fallback */
+    int32_t stream_probes;        /* "do my two streams run beside each other?" asked so far (creation + whenever the
+                                     process's set of streams changed before a call) */
+    int32_t handover_mode;        /* 2: device-side counters, 1: events (or one stream), between the two streams */
+    int32_t stream_pairs_masked;  /* live CU-masked stream pairs of this process on the handle's device ... */
+    int32_t stream_pairs_plain;   /* ... and unmasked ones (each pair is shared by all engines that want its partition) */
+    int32_t demoted;              /* 1: running without device-side waits after a fallback (see fused_fallbacks) */
+    double profile_iter_dispatch_us; /* mean DISPATCH duration of k_iter over the launches of the last occ_profile: start / stop
+                                        events of hipExtLaunchKernel, i.e. the begin / end timestamps of the dispatch's
+                                        completion signal -- what rocprofv3 --kernel-trace reports for a kernel (launch ramp
+                                        and end-of-kernel release included, which the in-kernel clock cannot see) */
 } occ_stats;
 int occ_get_stats(occ_sampler *s, occ_stats *out);
 

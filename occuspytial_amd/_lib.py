@@ -39,6 +39,9 @@ class OccStats(C.Structure):
         ('n_chains', C.c_int32), ('persistent_solve', C.c_int32), ('solve_workgroups', C.c_int32),
         ('main_stream_cus', C.c_int32), ('fused_fallbacks', C.c_int32), ('profile_minres_iterations', C.c_double),
         ('iter_kernel_launches', C.c_int64), ('iter_kernel_mean_us', C.c_double),
+        ('repromotions', C.c_int32), ('stream_probes', C.c_int32), ('handover_mode', C.c_int32),
+        ('stream_pairs_masked', C.c_int32), ('stream_pairs_plain', C.c_int32), ('demoted', C.c_int32),
+        ('profile_iter_dispatch_us', C.c_double),
     ]
 
 
@@ -88,7 +91,7 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built, or no usable gfx950 device)."""
 
 
-ABI_VERSION = 4  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
+ABI_VERSION = 5  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
 
 
 def load():

@@ -31,14 +31,24 @@ inline RcclApi &rccl()
 {
     static RcclApi api = [] {
         RcclApi a;
-        const char *names[] = {std::getenv("OCC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // OCC_RCCL_LIB: a library to try first; the word `none` tries nothing at all (the branch a machine without
+        // librccl takes -- occ_create_group then hands over by hipMemcpyPeer, init_comm by the file rendezvous)
+        const char *first = std::getenv("OCC_RCCL_LIB");
+        if (first && std::string(first) == "none") {
+            a.err = "librccl could not be opened: OCC_RCCL_LIB=none";
+            return a;
+        }
+        const char *names[] = {first, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string why;
         for (const char *nm : names) {
             if (!nm || !*nm) continue;
             a.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            const char *e = dlerror();  // (one call: it returns the message AND clears it)
+            why += std::string(why.empty() ? "" : "; ") + nm + ": " + (e ? e : "not found");
         }
         if (!a.lib) {
-            a.err = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "not found");
+            a.err = "librccl could not be opened: " + (why.empty() ? std::string("not found") : why);
             return a;
         }
 #define OCC_RCCL_SYM(field, name)                                                           \

@@ -4,6 +4,7 @@
 #include "../../include/occ_gibbs.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -11,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,10 +32,54 @@ enum Kind { K_OMEGA_B = 0, K_NOISE, K_ETA_INIT, K_MINRES, K_BETA_PARTIAL, K_OMEG
             K_RSR_GRAM, K_RSR_SOLVE, K_RSR_ETA_BETA /* reduced-rank model */ };
 static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with the header");
 
+// ---- streams are a PROCESS-WIDE resource, not an engine's ------------------------------------------------------------
+// An MI355X gives a device 24 hardware queue slots for compute (KFD topology: num_cp_queues 24), shared by everything
+// that runs on it.  The HIP runtime multiplexes ordinary streams onto a few queues per priority, but every CU-masked
+// stream gets a hardware queue OF ITS OWN (tools/queue_probe.hip: with 12 live pairs of masked streams -- 24 queues plus
+// the runtime's own -- the scheduler starts to time-slice the queues in quanta of about 10 ms; a kernel that polls for a
+// word only a kernel on ANOTHER queue can set then waits a quantum or more whenever that queue is not mapped: 10.1 ms and
+// 18 ms+ seen where a hand-over takes 30 us).  Round 2 gave every engine its own two masked streams, so a process that
+// kept a dozen samplers alive ran every device-side hand-over of a new engine into its time-out -- and the probe at
+// creation could not see it, because a fresh queue starts out mapped and loses its slot later, when other queues
+// get work.  Hence:
+//   * one (main, side) pair per (process, device, CU partition), shared by every engine that wants that partition and
+//     released (streams destroyed) with the last of them;
+//   * at most MAX_MASKED_PAIRS masked pairs alive per device; an engine that would need one more takes the unmasked
+//     pair and hands over through events -- decided by counting, not by probing;
+//   * engines of one device run their calls ONE AFTER THE OTHER (DeviceSlot::busy, taken by every entry point): they
+//     share streams, and two fused engines at once take each other's CUs anyway (their barriers need residency);
+//   * every creation / destruction of a pair bumps g_stream_gen; an engine whose last stream probe is older than that
+//     asks again at its next occ_run / occ_step (the mapping can change after creation).
+struct StreamPair {
+    int device = 0;
+    std::vector<uint32_t> m_main, m_side;  // empty: the unmasked pair (priority streams)
+    hipStream_t main = nullptr, side = nullptr;
+    int refs = 0;
+};
+struct DeviceSlot {
+    std::recursive_mutex busy;        // held for the length of every entry point that touches the device through a handle
+    std::vector<StreamPair *> pairs;  // guarded by g_pool_mu
+};
+constexpr int MAX_MASKED_PAIRS = 4;  // per device: 8 of its 24 hardware queues
+std::mutex g_pool_mu;
+std::map<int, DeviceSlot *> g_slots;  // never freed: a handle's lease may outlive every pair
+std::atomic<unsigned long long> g_stream_gen{1};
+
+DeviceSlot &device_slot(int device)
+{
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    DeviceSlot *&sl = g_slots[device];
+    if (!sl) sl = new DeviceSlot();
+    return *sl;
+}
+using DeviceLease = std::unique_lock<std::recursive_mutex>;
+inline DeviceLease lease_device(int device) { return DeviceLease(device_slot(device).busy); }
+
 }  // namespace
 
 struct occ_sampler {
     int device = 0;
+    StreamPair *pair = nullptr;    // the streams below belong to this pooled pair (shared with other engines of the device)
     hipStream_t stream = nullptr;  // main: eta_init -> minres ... -> beta -> z_ob
     hipStream_t side = nullptr;    // side: omega_a -> alpha_draw -> noise(t+1), forked/joined inside the graph
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -70,6 +118,7 @@ struct occ_sampler {
     // fixed problem arrays on the device, in upload order: what a group broadcasts from its root (occ_create_group /
     // occ_create_distributed); defer_fixed: allocate only, the bytes arrive by broadcast
     std::vector<std::pair<void *, size_t>> fixed_list;
+    std::vector<const char *> fixed_names;  // ... and what each one is (error messages of the after-broadcast check)
     bool defer_fixed = false;
     std::string group_transport = "none";
     Inject *inj_dev = nullptr;  // injected variates of the occ_cond_* entry points
@@ -82,7 +131,21 @@ struct occ_sampler {
     int xl_per_cu = 1, xl_main = 0;  // its workgroups per CU; CUs of the main stream it wants (0: no partition)
     int xl_per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... per XCD, when the XCDs that host a chain get more than the others (first entry 0: evenly)
     int main_hot_cus = 0;    // CUs the main stream's mask holds on XCD 0 (a chain's XCD)
-    bool streams_serialised = false;  // the stream probe at creation found the two streams served one after the other
+    bool streams_serialised = false;  // the last stream probe found the two streams NOT running beside each other: hand-overs by events
+    unsigned *probe_w = nullptr;      // the stream probe's words
+    unsigned long long probe_gen = 0; // g_stream_gen at the last stream probe
+    int64_t stream_probes = 0, repromotions = 0;
+    unsigned *sync_buf = nullptr;     // the hand-over counters (Ctx::sync points here while they are in use)
+    // What creation decided -- the form of the fused kernel, the CU partition, device-side hand-overs -- kept so that an
+    // engine that had to leave it at run time (fallback_to_launch_per_step) can come back (try_repromote)
+    struct Preferred {
+        bool valid = false, persistent = false, xcd_local = false, flag_sync = false;
+        int share_on = 0, main_cus = 0;
+        std::vector<uint32_t> m_main, m_side;
+    } pref;
+    bool demoted = false;             // running without device-side waits after one of them gave up
+    int promote_wait = 0, promote_backoff = 1;  // calls until the next attempt to come back; doubled after a failed one
+    std::string pair_note;            // why the engine did not get the masked pair it wanted (empty: it did, or wanted none)
     std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
     bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
     int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
@@ -119,6 +182,8 @@ struct occ_sampler {
     int krylov_last = 0;
     double last_run_ms = 0.0;
     double profile_minres_iterations = 0.0;
+    double profile_iter_dispatch_us = 0.0;
+    hipEvent_t ext_ev0 = nullptr, ext_ev1 = nullptr;  // occ_profile: start / stop events of the next k_iter dispatch (hipExtLaunchKernel)
     int calib_max = 0;
     unsigned long long seen_tot = 0, seen_sq = 0, seen_solves = 0;  // counters at the last cap decision
     // record buffer (alpha | beta | tau rows of the current occ_run), kept between runs
@@ -173,13 +238,16 @@ int dev_alloc(occ_sampler *s, T **out, size_t count, bool zero = true)
 }
 
 template <class T>
-int upload(occ_sampler *s, const T **out, const std::vector<T> &h)
+int upload(occ_sampler *s, const T **out, const std::vector<T> &h, const char *name = "array")
 {
     T *d = nullptr;
     int rc = dev_alloc(s, &d, h.size(), false);
     if (rc) return rc;
     if (!h.empty() && !s->defer_fixed) HIP_TRY(copy_on(s, d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    if (!h.empty()) s->fixed_list.emplace_back((void *)d, h.size() * sizeof(T));
+    if (!h.empty()) {
+        s->fixed_list.emplace_back((void *)d, h.size() * sizeof(T));
+        s->fixed_names.push_back(name);
+    }
     *out = d;
     return OCC_OK;
 }
@@ -295,7 +363,7 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             }
             break;
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
-        case K_MINRES: hipLaunchKernelGGL(k_minres, gs, blk, 0, st, s->kry, 0, e, extra); break;
+        case K_MINRES: hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(tp), gs, blk, lds_p, st, OCC_ARGS, extra); break;
         case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), shared_grid(c, 1, c.nb_r), blk, lds_q, st, OCC_ARGS); break;
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
@@ -327,10 +395,22 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                 for (int base = 0; base < c.C; base += XL_SLOTS) {
                     IterArgs ia = s->iter;
                     ia.chain_base = base;
+                    if (s->ext_ev0 && base == 0) {  // occ_profile: the dispatch's own begin / end timestamps
+                        const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
+                        if (s->xl_wide == 1) hipExtLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
+                        else if (s->xl_wide == 2) hipExtLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
+                        else hipExtLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
+                        continue;
+                    }
                     if (s->xl_wide == 1) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else if (s->xl_wide == 2) hipLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                 }
+            }
+            else if (s->ext_ev0) {
+                const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
+                if (s->iter_window == 8) hipExtLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
+                else hipExtLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
             }
             else if (s->iter_window == 8) hipLaunchKernelGGL((k_iter<8, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
             else hipLaunchKernelGGL((k_iter<16, 0, 0>), dim3((unsigned)s->iter.nbg, (unsigned)c.C), dim3(ITER_WG), 0, st, s->iter, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
@@ -545,7 +625,14 @@ int build_graph(occ_sampler *s, int cap)
     }
     if (s->flag_sync) {
         // GRAPH_SEQ sequences (alternating parity) per graph and stream, no event nodes: the kernels hand over through
-        // the device counters of Ctx::sync
+        // the device counters of Ctx::sync.  The counters restart with the capture: the main stream's sequence numbers
+        // live in two words indexed by the sequence PARITY, and a capture that starts with the other parity than the last
+        // one ended with (an odd number of stepped iterations in between: occ_step hands over by stream order and leaves
+        // the counters alone) would read the older of the two -- one sequence behind the side stream, whose gate then
+        // waits for a number the main stream never announces (found by the MINRES-limit test, round 3).  Both streams are
+        // idle here.  (SYNC_DEBUG, the tests' broken-hand-over word, is not a counter and stays.)
+        if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+        HIP_TRY(fill_on(s, s->ctx.sync, 0, sizeof(unsigned) * SYNC_DEBUG));
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         for (int t = 0; t < GRAPH_SEQ; ++t) {
             const int e = s->parity ^ (t & 1);
@@ -688,14 +775,104 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
 }
 
 
-// The two streams without a CU partition: the main stream (critical path) at the higher priority.
+// ---- the pooled stream pairs (see StreamPair above) --------------------------------------------------------------------
+// -> the pair with these masks on `device` (created when no engine holds one yet); nullptr when it cannot be had -- the cap
+// on masked pairs is reached, or the runtime cannot create the streams -- with the reason in *why.  The device is current.
+StreamPair *acquire_pair(int device, const std::vector<uint32_t> &m_main, const std::vector<uint32_t> &m_side, std::string *why)
+{
+    DeviceSlot &slot = device_slot(device);
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    int masked = 0, cap = MAX_MASKED_PAIRS;
+    if (const char *mc = std::getenv("OCC_MAX_MASKED_PAIRS")) cap = std::max(0, std::atoi(mc));  // tests
+    for (StreamPair *p : slot.pairs) {
+        if (p->m_main == m_main && p->m_side == m_side) {
+            p->refs += 1;
+            return p;
+        }
+        masked += p->m_main.empty() ? 0 : 1;
+    }
+    if (!m_main.empty() && masked >= cap) {
+        *why = std::to_string(masked) + " CU-masked stream pairs are alive on device " + std::to_string(device) +
+               " already (each masked stream holds one of the device's 24 hardware queues)";
+        return nullptr;
+    }
+    StreamPair *p = new StreamPair();
+    p->device = device;
+    p->m_main = m_main;
+    p->m_side = m_side;
+    hipError_t e;
+    if (m_main.empty()) {  // the main stream (critical path) at the higher priority
+        int prio_low = 0, prio_high = 0;
+        e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+        if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->main, hipStreamNonBlocking, prio_high);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_low);
+    } else {
+        e = hipExtStreamCreateWithCUMask(&p->main, (uint32_t)m_main.size(), m_main.data());
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&p->side, (uint32_t)m_side.size(), m_side.data());
+    }
+    if (e != hipSuccess) {  // (an error here is not sticky)
+        *why = std::string("stream creation failed: ") + hipGetErrorString(e);
+        if (p->main) (void)hipStreamDestroy(p->main);
+        if (p->side) (void)hipStreamDestroy(p->side);
+        (void)hipGetLastError();
+        delete p;
+        return nullptr;
+    }
+    p->refs = 1;
+    slot.pairs.push_back(p);
+    g_stream_gen.fetch_add(1);
+    return p;
+}
+
+void release_pair(StreamPair *p)
+{
+    if (!p) return;
+    DeviceSlot &slot = device_slot(p->device);
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (--p->refs > 0) return;
+    slot.pairs.erase(std::remove(slot.pairs.begin(), slot.pairs.end(), p), slot.pairs.end());
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->main);
+    (void)hipStreamSynchronize(p->side);
+    (void)hipStreamDestroy(p->side);
+    (void)hipStreamDestroy(p->main);
+    delete p;
+    g_stream_gen.fetch_add(1);
+}
+
+// live pairs of a device: {masked, unmasked} (occ_stats, OCC_VERBOSE)
+void count_pairs(int device, int *masked, int *plain)
+{
+    DeviceSlot &slot = device_slot(device);
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    *masked = *plain = 0;
+    for (StreamPair *p : slot.pairs) (p->m_main.empty() ? *plain : *masked) += 1;
+}
+
+void adopt_pair(occ_sampler *s, StreamPair *p)
+{
+    s->pair = p;
+    s->stream = p ? p->main : nullptr;
+    s->side = p ? p->side : nullptr;
+}
+
+// The engine lets go of its streams (everything it enqueued has completed).
+void drop_pair(occ_sampler *s)
+{
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->side) (void)hipStreamSynchronize(s->side);
+    release_pair(s->pair);
+    adopt_pair(s, nullptr);
+}
+
+// The two streams without a CU partition (the pooled unmasked pair of the device).
 int create_plain_streams(occ_sampler *s)
 {
-    int prio_low = 0, prio_high = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-    if (std::getenv("OCC_NO_STREAM_PRIORITY")) prio_high = prio_low;
-    HIP_TRY(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_high));
-    HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_low));
+    std::string why;
+    StreamPair *p = acquire_pair(s->device, {}, {}, &why);
+    if (!p) return set_error(s, OCC_E_HIP, why.c_str());
+    adopt_pair(s, p);
     s->main_cus = 0;
     s->flag_sync = false;
     s->ctx.share_on = 0;
@@ -707,9 +884,49 @@ int create_plain_streams(occ_sampler *s)
 int demote_streams(occ_sampler *s, bool also_reduced_rank = false)
 {
     if ((s->rsr.m > 0 && !also_reduced_rank) || s->main_cus == 0) return OCC_OK;
-    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
-    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); s->side = nullptr; }
+    drop_pair(s);
     return create_plain_streams(s);
+}
+
+// Do the engine's two streams run BESIDE each other?  The device-side hand-overs presume it.  A kernel on the side stream
+// waits (at most ~20 ms) for a word that a kernel launched AFTER it on the main stream sets: streams that share a hardware
+// queue, or whose queues the scheduler is time-slicing (more live queues on the device than hardware slots), show up as
+// "never seen" or as a wait of a scheduling quantum.  Asked at creation and again whenever the process's set of
+// streams has changed since the last answer (g_stream_gen).
+int stream_probe(occ_sampler *s, bool *beside)
+{
+    *beside = true;
+    s->probe_gen = g_stream_gen.load();
+    s->stream_probes += 1;
+    if (std::getenv("OCC_DEBUG_SKIP_STREAM_PROBE")) return OCC_OK;
+    int rc;
+    if (!s->probe_w && (rc = dev_alloc(s, &s->probe_w, 32))) return rc;
+    unsigned seen[2] = {0u, 0u};
+    // (the pair of launches is timed: first a launch on each stream that is not -- the kernels' code object is loaded at a
+    // process's first launch, milliseconds, and a queue's very first packet costs 0.5 ms)
+    hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->side, s->probe_w + 24);
+    hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, s->probe_w + 24);
+    HIP_TRY(hipStreamSynchronize(s->side));
+    HIP_TRY(hipMemsetAsync(s->probe_w, 0, 32 * sizeof(unsigned), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(64), 0, s->side, s->probe_w);
+    hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, s->probe_w);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->side));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(copy_on(s, seen, s->probe_w + 16, sizeof(seen), hipMemcpyDeviceToHost));
+    // beside each other the pair of launches completes in 30-50 us (470 us on a queue's very first launch); a queue that
+    // has to be scheduled in first costs a quantum: 10 ms and more (tools/queue_probe.hip)
+    *beside = seen[0] != 0u && us < 3000.0;
+    if (std::getenv("OCC_DEBUG_STREAMS_SERIALISED")) *beside = false;  // tests: take the caller's "not beside" branch
+    if (std::getenv("OCC_VERBOSE")) {
+        int masked = 0, plain = 0;
+        count_pairs(s->device, &masked, &plain);
+        std::fprintf(stderr, "[occ] stream probe: word %s after %u polls, %.0f us; live stream pairs on device %d: %d CU-masked, %d unmasked -> %s\n",
+                     seen[0] ? "seen" : "NOT seen", seen[1], us, s->device, masked, plain, *beside ? "beside each other" : "NOT beside each other");
+    }
+    return OCC_OK;
 }
 
 // Residency probe of the fused iteration kernel in the form s->xcd_local / xl_wide / iter_window / iter.nbg select:
@@ -761,16 +978,18 @@ const char *occ_last_error(const occ_sampler *s) { return s ? s->err.c_str() : g
 int occ_destroy(occ_sampler *s)
 {
     if (!s) return OCC_OK;
-    (void)hipSetDevice(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->side) (void)hipStreamSynchronize(s->side);
-    destroy_graph(s);
-    for (void *p : s->allocs) (void)hipFree(p);
-    if (s->rec_buf) (void)hipFree(s->rec_buf);
-    for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
-        if (ev) (void)hipEventDestroy(ev);
-    if (s->side) (void)hipStreamDestroy(s->side);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    {
+        DeviceLease lease = lease_device(s->device);
+        (void)hipSetDevice(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->side) (void)hipStreamSynchronize(s->side);
+        destroy_graph(s);
+        for (void *p : s->allocs) (void)hipFree(p);
+        if (s->rec_buf) (void)hipFree(s->rec_buf);
+        for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
+            if (ev) (void)hipEventDestroy(ev);
+        drop_pair(s);  // the streams go with the last engine that shares them
+    }
     delete s;
     return OCC_OK;
 }
@@ -992,6 +1211,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
 {
     if (!keys || n_chains < 1) return set_error(s, OCC_E_BADARG, "bad keys / n_chains");
     struct { int rsr_dim; } pbv = {L.rsr_dim}, *pb = &pbv;  // (the body below reads pb->rsr_dim)
+    DeviceLease lease = lease_device(s->device);  // probes and uploads run on streams other engines of the device share
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (s->device < 0 || s->device >= ndev) return set_error(s, OCC_E_HIP, "no such HIP device");
@@ -1135,36 +1355,27 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 if (per[x] != per[0]) c.share_on = 1;
             }
             if (std::getenv("OCC_NO_XCD_SHARES")) c.share_on = 0;
-            // a runtime that cannot mask CUs (an error here is not sticky) gets the unpartitioned streams below
-            if (hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)m_main.size(), m_main.data()) == hipSuccess) {
-                if (hipExtStreamCreateWithCUMask(&s->side, (uint32_t)m_side.size(), m_side.data()) == hipSuccess) {
-                    s->main_cus = nmain;
-                    s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
-                    // Device-side hand-overs need the two streams to RUN beside each other.  Seen on ROCm 7.2 with several
-                    // engines alive in one process: both streams of a new engine served by one hardware queue -- every
-                    // hand-over of every iteration then runs into its time-out.  Ask: a kernel on the side stream waits (at
-                    // most ~20 ms) for a word that a kernel launched AFTER it on the main stream sets.
-                    if (s->flag_sync && !std::getenv("OCC_DEBUG_SKIP_STREAM_PROBE")) {
-                        unsigned *w = nullptr, seen = 0u;
-                        if ((rc = dev_alloc(s, &w, 32))) return rc;
-                        hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(64), 0, s->side, w);
-                        hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, w);
-                        HIP_TRY(hipStreamSynchronize(s->stream));
-                        HIP_TRY(hipStreamSynchronize(s->side));
-                        HIP_TRY(copy_on(s, &seen, w + 16, sizeof(seen), hipMemcpyDeviceToHost));
-                        if (std::getenv("OCC_DEBUG_STREAMS_SERIALISED")) seen = 0u;  // tests: take the branch below
-                        if (!seen) {
-                            s->flag_sync = false;  // hand-overs by event nodes (ICAR) / everything on one stream (reduced-rank model)
-                            s->streams_serialised = true;
-                            if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] the two streams do not run beside each other: no device-side hand-overs\n");
-                        }
+            // the pooled pair with this partition; a runtime that cannot mask CUs, or a device that has its share of masked
+            // pairs already, gets the unpartitioned streams below
+            if (StreamPair *pr = acquire_pair(s->device, m_main, m_side, &s->pair_note)) {
+                adopt_pair(s, pr);
+                s->pair_note.clear();
+                s->pref.m_main = m_main;
+                s->pref.m_side = m_side;
+                s->main_cus = nmain;
+                s->flag_sync = std::getenv("OCC_EVENT_SYNC") == nullptr;  // diagnostic: hand-overs by event nodes
+                if (s->flag_sync) {
+                    bool beside = true;
+                    if ((rc = stream_probe(s, &beside))) return rc;
+                    if (!beside) {
+                        s->flag_sync = false;  // hand-overs by event nodes (ICAR) / everything on one stream (reduced-rank model)
+                        s->streams_serialised = true;
                     }
-                } else {
-                    (void)hipStreamDestroy(s->stream);
-                    s->stream = nullptr;
                 }
+            } else {
+                c.share_on = 0;
+                if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] no CU partition for this engine: %s\n", s->pair_note.c_str());
             }
-            (void)hipGetLastError();
         }
         if (s->main_cus == 0 && (rc = create_plain_streams(s))) return rc;
     }
@@ -1206,26 +1417,26 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     }
 
     // ---- device memory ------------------------------------------------------------------------------
-    if ((rc = upload(s, &c.sell_ptr, sell_ptr))) return rc;
-    if ((rc = upload(s, &c.sell_col, sell_col))) return rc;
-    if ((rc = upload(s, &c.sell_val, sell_val))) return rc;
-    if ((rc = upload(s, &c.qdiag, qdiag))) return rc;
-    if (!dia_off.empty() && (rc = upload(s, &dia_mask_dev, dia_mask))) return rc;
-    if ((rc = upload(s, &c.Xt, Xt))) return rc;
-    if ((rc = upload(s, &c.Wt, Wt))) return rc;
-    if ((rc = upload(s, &c.yrow, yrow))) return rc;
-    if ((rc = upload(s, &c.row_site, row_site))) return rc;
-    if ((rc = upload(s, &c.site_sidx, site_sidx))) return rc;
+    if ((rc = upload(s, &c.sell_ptr, sell_ptr, "sell_ptr"))) return rc;
+    if ((rc = upload(s, &c.sell_col, sell_col, "sell_col"))) return rc;
+    if ((rc = upload(s, &c.sell_val, sell_val, "sell_val"))) return rc;
+    if ((rc = upload(s, &c.qdiag, qdiag, "qdiag"))) return rc;
+    if (!dia_off.empty() && (rc = upload(s, &dia_mask_dev, dia_mask, "dia_mask_dev"))) return rc;
+    if ((rc = upload(s, &c.Xt, Xt, "Xt"))) return rc;
+    if ((rc = upload(s, &c.Wt, Wt, "Wt"))) return rc;
+    if ((rc = upload(s, &c.yrow, yrow, "yrow"))) return rc;
+    if ((rc = upload(s, &c.row_site, row_site, "row_site"))) return rc;
+    if ((rc = upload(s, &c.site_sidx, site_sidx, "site_sidx"))) return rc;
     {
         std::vector<int> sp(s->site_ptr.begin(), s->site_ptr.end());
-        if ((rc = upload(s, &c.site_ptr, sp))) return rc;
+        if ((rc = upload(s, &c.site_ptr, sp, "site_ptr"))) return rc;
     }
-    if ((rc = upload(s, &c.obs_site, s->obs_site))) return rc;
-    if ((rc = upload(s, &c.hyp, hyp))) return rc;
+    if ((rc = upload(s, &c.obs_site, s->obs_site, "obs_site"))) return rc;
+    if ((rc = upload(s, &c.hyp, hyp, "hyp"))) return rc;
     c.dense_F = nullptr;
     c.dense_m = 0;
     if (L.prior_m > 0) {  // reference-form prior draw
-        if ((rc = upload(s, &c.dense_F, L.prior_F))) return rc;
+        if ((rc = upload(s, &c.dense_F, L.prior_F, "dense_F"))) return rc;
         c.dense_m = L.prior_m;
         for (int b = 0; b < 2; ++b)
             if ((rc = dev_alloc(s, &c.dense_eps[b], (size_t)C * L.prior_m))) return rc;
@@ -1260,13 +1471,16 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     c.claim = nullptr;
     c.iter_clock = nullptr;
     c.sync = nullptr;
-    if (s->flag_sync) {
-        if ((rc = dev_alloc(s, &c.sync, (size_t)SYNC_WORDS))) return rc;
-        s->iter.sync = c.sync;
+    if (s->main_cus > 0) {  // a CU partition: the counters exist even while events hand over (the mode can change at run time)
+        if ((rc = dev_alloc(s, &s->sync_buf, (size_t)SYNC_WORDS))) return rc;
         if (std::getenv("OCC_DEBUG_BREAK_HANDOVER")) {  // tests of the run-time fallback: the side stream never announces its noise
             const unsigned one = 1u;
-            HIP_TRY(copy_on(s, c.sync + SYNC_DEBUG, &one, sizeof(one), hipMemcpyHostToDevice));
+            HIP_TRY(copy_on(s, s->sync_buf + SYNC_DEBUG, &one, sizeof(one), hipMemcpyHostToDevice));
         }
+    }
+    if (s->flag_sync) {
+        c.sync = s->sync_buf;
+        s->iter.sync = c.sync;
     }
     if (s->persistent) {
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
@@ -1350,13 +1564,13 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         r.ldk = 16 * ((m + 15) / 16);
         std::vector<double> Kp((size_t)n * r.ldk, 0.0);  // rows padded to whole 128-byte lines
         for (int i = 0; i < n; ++i) std::copy(Kh.begin() + (size_t)i * m, Kh.begin() + (size_t)(i + 1) * m, Kp.begin() + (size_t)i * r.ldk);
-        if ((rc = upload(s, &r.K, Kp))) return rc;
-        if ((rc = upload(s, &r.Kt, Kth))) return rc;
-        if ((rc = upload(s, &r.Qr, Qh))) return rc;
+        if ((rc = upload(s, &r.K, Kp, "rsr_K"))) return rc;
+        if ((rc = upload(s, &r.Kt, Kth, "rsr_Kt"))) return rc;
+        if ((rc = upload(s, &r.Qr, Qh, "rsr_Qr"))) return rc;
         std::vector<double> Eth((size_t)m * m);
         for (int a = 0; a < m; ++a)
             for (int j = 0; j < m; ++j) Eth[(size_t)j * m + a] = Eh[(size_t)a * m + j];
-        if ((rc = upload(s, &r.Et, Eth))) return rc;
+        if ((rc = upload(s, &r.Et, Eth, "rsr_Et"))) return rc;
         r.Xt = c.Xt; r.z = c.z;
         for (int b = 0; b < 2; ++b) { r.omega_b[b] = c.omega_b[b]; r.enorm[b] = c.enorm[b]; }
         if ((rc = dev_alloc(s, &r.theta, (size_t)C * m))) return rc;
@@ -1368,19 +1582,28 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         r.scs = c.sc;
         r.sync = c.sync;
         s->rsr_K_host = Kh;
-        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr;
+        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr; r.big_dfac = nullptr;
         if (m <= RSR_MAX_DIM) {
             HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
         } else {  // the global-memory solve (k_rsrb_*)
-            if ((rc = upload(s, &r.E, Eh))) return rc;
+            if ((rc = upload(s, &r.E, Eh, "rsr_E"))) return rc;
             if ((rc = dev_alloc(s, &r.big_eps, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_scal, (size_t)C * 2))) return rc;
             if ((rc = dev_alloc(s, &r.big_rhs, (size_t)C * m))) return rc;
+            if ((rc = dev_alloc(s, &r.big_dfac, (size_t)C * ((m + RSR_PANEL - 1) / RSR_PANEL) * RSR_PANEL * RSR_PANEL))) return rc;
         }
     }
     HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
+    // what the engine comes back to after a run-time fallback (try_repromote)
+    s->pref.valid = true;
+    s->pref.persistent = s->persistent;
+    s->pref.xcd_local = s->xcd_local;
+    s->pref.flag_sync = s->main_cus > 0 && s->sync_buf != nullptr && std::getenv("OCC_EVENT_SYNC") == nullptr;
+    s->pref.share_on = c.share_on;
+    s->pref.main_cus = s->main_cus;
+    if (s->main_cus == 0) { s->pref.m_main.clear(); s->pref.m_side.clear(); }
     return OCC_OK;
 }
 
@@ -1493,6 +1716,37 @@ void size_peer_layout(HostLayout &L, const LayoutHeader &h)
     L.obs_site.assign((size_t)h.S, 0);
 }
 
+// Checksums of the sampler's fixed arrays as they sit on ITS device (k_checksum), in fixed_list order: what a group
+// compares after the broadcast -- a first multi-GPU run must be able to tell a wrong broadcast from a right one.
+int fixed_checksums(occ_sampler *s, std::vector<unsigned long long> &sums)
+{
+    const size_t na = s->fixed_list.size();
+    sums.assign(na, 0ull);
+    if (na == 0) return OCC_OK;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned long long) * na));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long) * na, s->stream);
+    for (size_t i = 0; i < na && e == hipSuccess; ++i) {
+        const size_t bytes = s->fixed_list[i].second;
+        const unsigned blocks = (unsigned)std::min<size_t>(1024, (bytes / 8 + 255) / 256 + 1);
+        hipLaunchKernelGGL(k_checksum, dim3(blocks), dim3(256), 0, s->stream, (const unsigned char *)s->fixed_list[i].first, (unsigned long long)bytes, d + i);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d, sizeof(unsigned long long) * na, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        s->err = std::string("checksum of the fixed arrays failed: ") + hipGetErrorString(e);
+        return OCC_E_HIP;
+    }
+    if (const char *dbg = std::getenv("OCC_DEBUG_CORRUPT_BROADCAST")) {  // tests: as if array <n> had arrived damaged on a peer
+        const size_t k = (size_t)std::atoi(dbg);
+        if (s->defer_fixed && k < na) sums[k] ^= 1ull;
+    }
+    return OCC_OK;
+}
+
 // A peer's host mirrors (site numbers, row offsets, detection flags) from the device arrays it has just received
 int refresh_host_mirrors(occ_sampler *s)
 {
@@ -1583,6 +1837,7 @@ int occ_comm_broadcast_host(occ_comm *cm, void *buf, int64_t bytes, int32_t root
 int occ_synchronize(occ_sampler *s)
 {
     if (!s) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     return OCC_OK;
@@ -1626,13 +1881,48 @@ int occ_create_distributed(const occ_problem *problem, occ_comm *cm, int32_t roo
         s->defer_fixed = true;
     }
     rc = create_impl(s, L, n_chains, keys);
+    // every rank holds the arrays the root is about to send, in its order and sizes (a mismatch would hang or misroute the
+    // broadcasts): the root's (count, sizes[]) go round first
+    {
+        std::vector<long long> want(65, -1);
+        if (cm->rank == root && rc == OCC_OK) {
+            want[0] = (long long)s->fixed_list.size();
+            for (size_t i = 0; i < s->fixed_list.size() && i < 64; ++i) want[1 + i] = (long long)s->fixed_list[i].second;
+        }
+        if ((crc = comm_bcast_host(cm, want.data(), sizeof(long long) * want.size(), root))) return fail(crc);
+        if (rc == OCC_OK) {
+            bool same = want[0] == (long long)s->fixed_list.size() && s->fixed_list.size() <= 64;
+            for (size_t i = 0; same && i < s->fixed_list.size(); ++i) same = want[1 + i] == (long long)s->fixed_list[i].second;
+            if (!same) rc = set_error(s, OCC_E_HIP, "internal: this rank's fixed arrays differ in number or size from the root's");
+        }
+    }
     double bad = rc != OCC_OK ? 1.0 : 0.0;  // all ranks or none go on to the broadcasts
     if ((crc = comm_allreduce(cm, &bad, 1, ncclMax))) return fail(crc);
     if (bad != 0.0) return fail(rc ? rc : set_error(s, OCC_E_HIP, "another rank failed to create its sampler"));
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) bad = 1.0;  // (reported after the collectives below: nobody is left inside a broadcast)
     for (auto &fa : s->fixed_list)
         if ((crc = comm_bcast_dev(cm, fa.first, fa.second, root))) return fail(crc);
-    if (hipStreamSynchronize(cm->stream) != hipSuccess) return fail(set_error(s, OCC_E_HIP, "the broadcast stream failed"));
+    if (hipStreamSynchronize(cm->stream) != hipSuccess) bad = 1.0;
+    // ... and what arrived is what was sent: every rank checksums its copies on the device, the root's sums go round,
+    // the first array that differs anywhere is named on every rank
+    {
+        std::vector<unsigned long long> mine, roots;
+        if (bad == 0.0 && fixed_checksums(s, mine) != OCC_OK) bad = 1.0;
+        roots = mine;
+        roots.resize(s->fixed_list.size(), 0ull);
+        if ((crc = comm_bcast_host(cm, roots.data(), sizeof(unsigned long long) * roots.size(), root))) return fail(crc);
+        double first_diff = 0.0;  // 1 + index of the first differing array over all ranks (max: any)
+        for (size_t i = 0; bad == 0.0 && i < roots.size(); ++i)
+            if (mine[i] != roots[i]) { first_diff = (double)(i + 1); break; }
+        double flags[2] = {bad, first_diff};
+        if ((crc = comm_allreduce(cm, flags, 2, ncclMax))) return fail(crc);
+        if (flags[0] != 0.0) return fail(set_error(s, OCC_E_HIP, "a rank failed while the problem was broadcast"));
+        if (flags[1] != 0.0) {
+            const size_t k = (size_t)flags[1] - 1;
+            const std::string nm = k < s->fixed_names.size() ? s->fixed_names[k] : "?";
+            return fail(set_error(s, OCC_E_HIP, ("the broadcast of the problem did not arrive intact: array `" + nm + "` differs from the root's on at least one rank").c_str()));
+        }
+    }
     if (cm->rank != root && (rc = refresh_host_mirrors(s))) return fail(rc);
     s->group_transport = "rccl broadcast (ncclCommInitRank), " + std::to_string(cm->world) + " ranks";
     *out = s;
@@ -1672,6 +1962,14 @@ int occ_create_group(const occ_problem *problem, int32_t n_devices, const int32_
         if (rc) return fail(rc, ss[g]->err);
         if (hipDeviceSynchronize() != hipSuccess) return fail(OCC_E_HIP, "device synchronisation failed");
         koff += (size_t)chains_per_device[g];
+    }
+    // the hand-over below runs on the samplers' (pooled) streams: nobody else's calls in between
+    std::vector<DeviceLease> leases;
+    {
+        std::vector<int> ds(devices, devices + n_devices);
+        std::sort(ds.begin(), ds.end());
+        ds.erase(std::unique(ds.begin(), ds.end()), ds.end());
+        for (int d : ds) leases.push_back(lease_device(d));
     }
     const size_t narr = ss[0]->fixed_list.size();
     for (int g = 1; g < n_devices; ++g) {
@@ -1723,6 +2021,18 @@ int occ_create_group(const occ_problem *problem, int32_t n_devices, const int32_
             transport = "hipMemcpyPeer (" + why + ")";
         }
     }
+    // what arrived is what was sent: every sampler checksums its copies on its own device; a difference names the array
+    if (n_devices > 1 || (force && std::string(force) == "rccl")) {
+        std::vector<unsigned long long> root_sums, sums;
+        if (fixed_checksums(ss[0], root_sums) != OCC_OK) return fail(OCC_E_HIP, ss[0]->err);
+        for (int g = 1; g < n_devices; ++g) {
+            if (fixed_checksums(ss[g], sums) != OCC_OK) return fail(OCC_E_HIP, ss[g]->err);
+            for (size_t i = 0; i < narr; ++i)
+                if (sums[i] != root_sums[i])
+                    return fail(OCC_E_HIP, std::string("the broadcast of the problem did not arrive intact: array `") + ss[0]->fixed_names[i] + "` on device " +
+                                               std::to_string(devices[g]) + " (sampler " + std::to_string(g) + ") differs from the root's (" + transport + ")");
+        }
+    }
     for (int g = 0; g < n_devices; ++g) {
         ss[g]->group_transport = transport;
         out[g] = ss[g];
@@ -1755,6 +2065,7 @@ int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const doub
     if (!s) return OCC_E_BADARG;
     const Ctx &c = s->ctx;
     if (chain < 0 || chain >= c.C || !alpha || !beta || !eta) return set_error(s, OCC_E_BADARG, "bad chain / null start pointer");
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     std::vector<ChainScalars> h;
     int rc = read_scalars(s, h);
@@ -1785,6 +2096,7 @@ int occ_set_start(occ_sampler *s, int32_t chain, const double *alpha, const doub
 int occ_set_keys(occ_sampler *s, const uint64_t *keys)
 {
     if (!s || !keys) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     std::vector<ChainScalars> h;
     int rc = read_scalars(s, h);
@@ -1971,6 +2283,23 @@ static int snapshot_take(occ_sampler *s)
     return OCC_OK;
 }
 
+// Hand-overs between the two streams: device counters (`flags`) or events / one stream.  The captured graphs belong to a
+// mode and go with it; the counters restart from zero (a consistent state: sequence 0, whatever the parity).
+static int set_handover(occ_sampler *s, bool flags)
+{
+    if (s->flag_sync == flags) return OCC_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+    destroy_graph(s);
+    s->flag_sync = flags;
+    s->ctx.sync = flags ? s->sync_buf : nullptr;
+    s->iter.sync = s->ctx.sync;
+    s->rsr.sync = s->ctx.sync;
+    if (flags) HIP_TRY(fill_on(s, s->sync_buf, 0, sizeof(unsigned) * SYNC_WORDS));
+    HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    return OCC_OK;
+}
+
 static int fallback_to_launch_per_step(occ_sampler *s)
 {
     Ctx &c = s->ctx;
@@ -2003,15 +2332,97 @@ static int fallback_to_launch_per_step(occ_sampler *s)
     s->need_prologue = true;
     s->calib_max = 0;
     s->fused_fallbacks += 1;
+    s->demoted = true;                       // ... until try_repromote finds the device as creation found it
+    s->promote_wait = s->promote_backoff;
+    return OCC_OK;
+}
+
+// Back to the paths creation chose, after a run-time fallback.  A device-side wait gives up because of what ELSE is on the
+// device at that moment (another process's kernels on the CUs the fused kernel's barrier needs; more live hardware queues
+// than slots): transient conditions.  At the next call -- then after 2, 4, ... 64 calls -- the engine takes its CU
+// partition again, asks the stream probe and the residency probe what creation asked, and returns to the fused kernel and
+// the device-side hand-overs when both pass (occ_stats::repromotions); otherwise it stays where it is.  The paths are
+// bitwise equal and omega_b / the noise of the coming iteration are where the next kernel looks for them: nothing else to do.
+static int try_repromote(occ_sampler *s)
+{
+    if (!s->demoted || !s->pref.valid || std::getenv("OCC_NO_REPROMOTE")) return OCC_OK;
+    if (--s->promote_wait > 0) return OCC_OK;
+    Ctx &c = s->ctx;
+    int rc;
+    auto stay = [&](const char *why) {
+        if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] not back on the fused path: %s\n", why);
+        s->promote_backoff = std::min(64, s->promote_backoff * 2);
+        s->promote_wait = s->promote_backoff;
+        return OCC_OK;
+    };
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+    destroy_graph(s);
+    if (s->pref.main_cus > 0) {  // the CU partition
+        std::string why;
+        StreamPair *pr = acquire_pair(s->device, s->pref.m_main, s->pref.m_side, &why);
+        if (!pr) return stay(why.c_str());
+        drop_pair(s);
+        adopt_pair(s, pr);
+        s->main_cus = s->pref.main_cus;
+        c.share_on = s->pref.share_on;
+    }
+    auto back_out = [&](const char *why) -> int {  // to the demoted state
+        s->persistent = false;
+        s->xcd_local = false;
+        int brc = demote_streams(s, true);
+        if (brc) return brc;
+        s->flag_sync = false;
+        c.sync = nullptr; s->iter.sync = nullptr; s->rsr.sync = nullptr;
+        HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+        return stay(why);
+    };
+    bool ok = true;
+    if (s->pref.flag_sync) {
+        if ((rc = stream_probe(s, &ok))) return rc;
+        if (!ok) return back_out("the two streams do not run beside each other");
+    }
+    s->persistent = s->pref.persistent;
+    s->xcd_local = s->pref.xcd_local;
+    HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    if (s->pref.persistent) {
+        if ((rc = residency_probe(s, &ok))) return rc;
+        if (!ok) return back_out("the fused kernel's workgroups are not resident together");
+    }
+    s->flag_sync = false;
+    if ((rc = set_handover(s, s->pref.flag_sync))) return rc;
+    if (!s->pref.flag_sync) HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
+    s->streams_serialised = false;
+    s->demoted = false;
+    s->promote_backoff = 1;
+    s->repromotions += 1;
+    if (std::getenv("OCC_VERBOSE")) std::fprintf(stderr, "[occ] back on the paths creation chose (fused kernel %d, device-side hand-overs %d)\n", (int)s->persistent, (int)s->flag_sync);
+    return OCC_OK;
+}
+
+// Head of every occ_run / occ_step: come back from a fallback when the device allows it; ask the stream probe again
+// when the process's set of streams has changed since the last answer (a queue can lose its hardware slot AFTER creation).
+static int refresh_paths(occ_sampler *s)
+{
+    int rc;
+    if ((rc = try_repromote(s))) return rc;
+    if (!s->demoted && s->main_cus > 0 && s->sync_buf && s->pref.flag_sync && s->probe_gen != g_stream_gen.load()) {
+        bool beside = true;
+        if ((rc = stream_probe(s, &beside))) return rc;
+        s->streams_serialised = !beside;
+        if ((rc = set_handover(s, beside))) return rc;
+    }
     return OCC_OK;
 }
 
 int occ_step(occ_sampler *s)
 {
     if (!s) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
-    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;  // paths with device-side waits: re-run without them if one gives up
     int rc;
+    if ((rc = refresh_paths(s))) return rc;
+    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;  // paths with device-side waits: re-run without them if one gives up
     if (fused && (rc = snapshot_take(s))) return rc;
     s->device_timeout = false;
     rc = step_impl(s);
@@ -2027,9 +2438,11 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     if (!s) return OCC_E_BADARG;
     if (n_iter < 1 || burnin < 0 || burnin >= n_iter) return set_error(s, OCC_E_BADARG, "burnin value cannot be larger than sample size");
     if (!out_alpha || !out_beta || !out_tau) return set_error(s, OCC_E_BADARG, "null output buffer");
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
-    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;
     int rc;
+    if ((rc = refresh_paths(s))) return rc;
+    const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;
     if (fused && (rc = snapshot_take(s))) return rc;
     s->device_timeout = false;
     rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
@@ -2045,6 +2458,7 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     if (!s || !name || !len) return OCC_E_BADARG;
     const Ctx &c = s->ctx;
     if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const std::string nm(name);
@@ -2107,6 +2521,7 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
     if (!s || !name || !in) return OCC_E_BADARG;
     const Ctx &c = s->ctx;
     if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const std::string nm(name);
@@ -2132,6 +2547,17 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
         std::vector<double2> x(n);
         for (size_t i = 0; i < n; ++i) x[i] = make_double2(in[i], in[n + i]);
         HIP_TRY(copy_on(s, c.Xv + chain * n, x.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    } else if (nm == "debug_maxiter") {
+        // tests of the MINRES-did-not-converge exit (logit.py:91-92): the iteration limit of every chain's solve; 0 restores
+        // scipy's default 5 * (2n).  The limit travels by value in the kernels' argument blocks: the graphs are re-captured.
+        if (!need(1) || in[0] < 0.0) return set_error(s, OCC_E_STATE, "wrong length");
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+        destroy_graph(s);
+        s->ctx.maxiter = in[0] > 0.0 ? (long long)in[0] : 10LL * c.n;
+        s->kry.maxiter = s->ctx.maxiter;
+        s->iter.a.maxiter = s->ctx.maxiter;
+        HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     } else {
         std::vector<ChainScalars> h;
         int rc = read_scalars(s, h);
@@ -2153,6 +2579,7 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
 int occ_get_stats(occ_sampler *s, occ_stats *out)
 {
     if (!s || !out) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     std::vector<ChainScalars> h;
     int rc = read_scalars(s, h);
@@ -2178,6 +2605,17 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->solve_workgroups = s->iter.nbg;
     out->main_stream_cus = s->main_cus;
     out->fused_fallbacks = (int32_t)s->fused_fallbacks;
+    out->repromotions = (int32_t)s->repromotions;
+    out->stream_probes = (int32_t)s->stream_probes;
+    out->handover_mode = s->flag_sync ? 2 : 1;
+    {
+        int masked = 0, plain = 0;
+        count_pairs(s->device, &masked, &plain);
+        out->stream_pairs_masked = masked;
+        out->stream_pairs_plain = plain;
+    }
+    out->demoted = s->demoted ? 1 : 0;
+    out->profile_iter_dispatch_us = s->profile_iter_dispatch_us;
     out->profile_minres_iterations = s->profile_minres_iterations;
     out->iter_kernel_launches = 0;
     out->iter_kernel_mean_us = 0.0;
@@ -2220,6 +2658,7 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int e, int extr
 int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS], double total_us[OCC_N_KERNEL_KINDS])
 {
     if (!s || reps < 1 || !counts || !total_us) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
     int rc = set_window(s, 1 << 30, 0, 0);  // no chain reaches its stop during the timing loops
     if (rc) return rc;
@@ -2241,6 +2680,11 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         const bool old_sync = s->launch_sync;
         s->launch_sync = flags;
         if (ev) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
+        hipEvent_t pev[2] = {nullptr, nullptr};
+        HIP_TRY(hipEventCreate(&pev[0]));
+        HIP_TRY(hipEventCreate(&pev[1]));
+        double dispatch_us = 0.0;
+        int dispatch_n = 0;
         for (int r = 0; r < reps; ++r) {
             const int pe = s->parity;
             hipStream_t side = one_stream ? s->stream : s->side;
@@ -2250,7 +2694,10 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             LAUNCH(s, side, K_NOISE, pe, 1);
             if (ev) HIP_TRY(hipEventRecord(s->ev_side[pe], side));
             HIP_TRY(hipEventRecord(s->ev0, s->stream));
+            s->ext_ev0 = pev[0];  // the dispatch's own start / stop (hipExtLaunchKernel): rocprofv3's basis for a kernel's duration
+            s->ext_ev1 = pev[1];
             LAUNCH(s, s->stream, K_ITER, pe);
+            s->ext_ev0 = s->ext_ev1 = nullptr;
             HIP_TRY(hipEventRecord(s->ev1, s->stream));
             if (ev) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
             LAUNCH(s, s->stream, K_Z_OB, pe);
@@ -2260,7 +2707,12 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             total_us[K_ITER] += 1000.0 * ms;
+            if (hipEventElapsedTime(&ms, pev[0], pev[1]) == hipSuccess) { dispatch_us += 1000.0 * ms; dispatch_n += 1; }
+            else (void)hipGetLastError();
         }
+        s->profile_iter_dispatch_us = dispatch_n ? dispatch_us / dispatch_n : 0.0;
+        (void)hipEventDestroy(pev[0]);
+        (void)hipEventDestroy(pev[1]);
         s->launch_sync = old_sync;
         counts[K_ITER] = reps;
         std::vector<ChainScalars> h;
@@ -2395,6 +2847,7 @@ int copy_out(occ_sampler *s, double *dst, const double *src, size_t count)
 int occ_cond_tau(occ_sampler *s, int32_t chain, double gamma_variate, double *tau_out)
 {
     if (!s) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     Inject inj{};
     inj.gamma = gamma_variate;
     inj.tau_from_gamma = 1;
@@ -2416,6 +2869,7 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
                  double *xz_out, double *eta_out, int32_t *itn_out)
 {
     if (!s) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     Inject inj{};
     inj.tau_from_gamma = 0;  // tau is the chain's
     uint32_t it;
@@ -2431,8 +2885,13 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
     hipLaunchKernelGGL(k_eta_init<1>, gs, blk, 0, s->stream, OCC_CARGS);
     int k_last = 0;
     Slot slot;
+    // OCC_DEBUG_EXACT_DIV=1: the scalar recurrence in scipy's own arithmetic (k_minres<1>, occ_kernels.hpp
+    // minres_scalars_exact) -- the tight-tolerance check of the vector part against the reference's recorded solves
+    const char *xd = std::getenv("OCC_DEBUG_EXACT_DIV");
+    const bool exact_div = xd && std::atoi(xd) != 0;
     for (int k = 1;; ++k) {  // one launch per MINRES step, the host watching this chain's `done` flag
-        hipLaunchKernelGGL(k_minres, gs, blk, 0, s->stream, s->kry, chain, e, k);
+        if (exact_div) hipLaunchKernelGGL(k_minres<1>, gs, blk, 0, s->stream, s->kry, chain, e, k);
+        else hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, s->stream, s->kry, chain, e, k);
         if (k < 4) continue;
         HIP_TRY(hipMemcpyAsync(&slot, c.slots + (size_t)chain * NSLOT + (k & (NSLOT - 1)), sizeof(Slot), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -2456,6 +2915,7 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
 int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const double *eps, double *beta_out)
 {
     if (!s || !eps) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     Inject inj{};
     inj.do_beta = 1;
     HIP_TRY(copy_on(s, inj.beta_eps, eps, sizeof(double) * s->ctx.p, hipMemcpyDefault));
@@ -2483,6 +2943,7 @@ int occ_cond_beta(occ_sampler *s, int32_t chain, const double *omega_b, const do
 int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const double *eps, double *alpha_out)
 {
     if (!s || !eps) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     Inject inj{};
     HIP_TRY(copy_on(s, inj.alpha_eps, eps, sizeof(double) * s->ctx.q, hipMemcpyDefault));
     uint32_t it;
@@ -2505,6 +2966,7 @@ int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const d
 int occ_cond_z(occ_sampler *s, int32_t chain, const double *u, double *z_out)
 {
     if (!s) return OCC_E_BADARG;
+    DeviceLease lease = lease_device(s->device);
     Inject inj{};
     inj.do_z = 1;
     uint32_t it;
@@ -2533,6 +2995,7 @@ int occ_draw(int32_t device, int32_t kind, uint64_t key, uint32_t iteration, uin
         return OCC_E_BADARG;
     }
     if (n == 0) return OCC_OK;
+    DeviceLease lease = lease_device(device);  // (a null-stream launch synchronises with the blocking streams of the device)
     double *d_par = nullptr, *d_out = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(double) * (size_t)n);

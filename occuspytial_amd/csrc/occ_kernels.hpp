@@ -697,20 +697,44 @@ __device__ __forceinline__ double load_agent(const double *p)
 
 // Do the two streams run beside each other?  The hand-overs above presume it.  k_stream_probe_wait (side stream, launched
 // first) looks for the word k_stream_probe_set (main stream, launched second) writes: streams that share a hardware queue
-// run the two in launch order and the word is never seen (occ_gibbs.hip, create_impl).
+// run the two in launch order and the word is never seen; streams whose queues the scheduler time-slices (more live
+// queues than the device's 24 hardware slots) take a scheduling quantum -- milliseconds -- to get both kernels onto the
+// device (occ_gibbs.hip, stream_probe).
 __global__ void __launch_bounds__(64) k_stream_probe_wait(unsigned *w)
 {
     if (threadIdx.x != 0) return;
-    unsigned seen = 0u;
-    for (unsigned spins = 0; spins < (1u << 13); ++spins) {  // ~ 20 ms
+    unsigned seen = 0u, spins = 0u;
+    for (; spins < (1u << 13); ++spins) {  // ~ 20 ms
         if (sync_read(w) != 0u) { seen = 1u; break; }
         __builtin_amdgcn_s_sleep(16);
     }
     w[16] = seen;
+    w[17] = spins;
 }
 __global__ void __launch_bounds__(64) k_stream_probe_set(unsigned *w)
 {
     if (threadIdx.x == 0) sync_set(w, 1u);
+}
+
+// Checksum of a device array (after-broadcast check of a group's fixed arrays: occ_gibbs.hip, array_checksum): the 64-bit
+// sum of every 8-byte word (a short tail zero-padded) mixed with its position -- integer adds commute, so the atomics
+// return the same value whatever the order; two arrays that differ in any bit, or hold the same words in another order,
+// differ in it (up to a 2^-64 accident).
+__global__ void __launch_bounds__(256) k_checksum(const unsigned char *__restrict__ data, unsigned long long bytes, unsigned long long *__restrict__ out)
+{
+    const unsigned long long nw = (bytes + 7ull) / 8ull;
+    unsigned long long acc = 0ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long w = 0ull;
+        if (8ull * i + 8ull <= bytes) w = *reinterpret_cast<const unsigned long long *>(data + 8ull * i);  // (hipMalloc: 256-byte aligned)
+        else
+            for (unsigned long long b = 8ull * i; b < bytes; ++b) w |= (unsigned long long)data[b] << (8ull * (b - 8ull * i));
+        unsigned long long x = w + 0x9E3779B97F4A7C15ull * (i + 1ull);  // splitmix64 finaliser of (word, position)
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        acc += x ^ (x >> 31);
+    }
+    atomicAdd(out, acc);
 }
 
 // First kernel of a side-stream sequence: one lane announces that the previous k_noise is complete, then waits
@@ -1227,6 +1251,94 @@ __device__ __forceinline__ KryStep minres_scalars(Slot &s, int k, double S0, dou
     return minres_post(s, q, k, S0, S1, S2, xn2, maxiter);
 }
 
+// The same step in SCIPY'S OWN ARITHMETIC -- a square root and a division wherever minres.py has one (beta = sqrt(.),
+// alfa / beta, beta / oldb, gbar / gamma, rhs1 / gamma, rnorm / (Anorm ynorm), root / Anorm, gmax / gmin), nothing
+// carried as a square or a reciprocal -- for the debug instantiation k_minres<1> only (OCC_DEBUG_EXACT_DIV=1 in
+// occ_cond_eta): the production step above replaces those by one reciprocal square root per divisor and products, which
+// moves the iterate by ~1e-8; this form stays within 1e-9 of the reference's recorded solves, so that the production
+// tolerance cannot hide an indexing or ordering error in the vector part (tests/test_gpu_golden.py).  A solve runs
+// entirely in one form (the slot's `root` is a root here, a square there; `ibeta` is not used here).
+__device__ __forceinline__ KryStep minres_scalars_exact(Slot &s, int k, double S0, double S1, double S2, double xn2, long long maxiter)
+{
+    const double eps = DBL_EPSILON, rtol = 1e-5;
+    KryStep st;
+    st.ca = st.cb = st.cc = 0.0;
+    st.sj = st.oldeps = st.delta = st.denom = st.phi = 0.0;
+    st.rotate = false;
+    st.stop = false;
+    if (k >= 4) {  // (a) stopping test of iteration k - 3 (minres.py, "Estimate various norms")
+        const int j = k - 3;
+        const double Anorm = sqrt(s.tnorm2), ynorm = sqrt(xn2);
+        const double epsx = Anorm * ynorm * eps, rnorm = s.phibar;
+        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+        const double test2 = (Anorm == 0.0) ? INFINITY : s.root / Anorm;
+        const double Acond = s.gmax / s.gmin;
+        int istop = s.istop;
+        if (istop == 0) {
+            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+            if (t2 <= 1.0) istop = 2;
+            if (t1 <= 1.0) istop = 1;
+            if ((long long)j >= maxiter) istop = 6;
+            if (Acond >= 0.1 / eps) istop = 4;
+            if (epsx >= s.beta1) istop = 3;
+            if (test2 <= rtol) istop = 2;
+            if (test1 <= rtol) istop = 1;
+        }
+        if (istop != 0) {
+            s.istop = istop; s.itn = j; s.done = 1;
+            st.stop = true;
+            return st;
+        }
+    }
+    if (k >= 2) {  // (b) beta_{k-1}, alfa_{k-1}
+        if (k == 2 && S0 == 0.0) {
+            s.done = 1; s.istop = 0; s.itn = 0;
+            st.stop = true;
+            return st;
+        }
+        const double beta_km1 = sqrt(S0), beta_km2 = s.beta;
+        double alfa_km1 = S1 / S0;
+        if (k >= 3) alfa_km1 = alfa_km1 - S2 / beta_km2;
+        if (k == 2) {
+            s.beta1 = beta_km1; s.oldb = 0.0; s.dbar = 0.0; s.epsln = 0.0; s.phibar = beta_km1;
+            s.rhs1 = beta_km1; s.rhs2 = 0.0; s.tnorm2 = 0.0; s.gmax = 0.0; s.gmin = DBL_MAX;
+            s.cs = -1.0; s.sn = 0.0; s.root = 0.0; s.istop = 0;
+        } else {  // (c) rotation of iteration k - 2
+            const double beta_n = beta_km1;
+            const double delta = fma(s.sn, s.alfa, s.cs * s.dbar), gbar = fma(-s.cs, s.alfa, s.sn * s.dbar);
+            s.oldb = beta_km2;
+            s.tnorm2 += fma(beta_n, beta_n, fma(beta_km2, beta_km2, s.alfa * s.alfa));
+            if (k == 3 && beta_n / s.beta1 <= 10.0 * eps) s.istop = -1;
+            st.oldeps = s.epsln;
+            st.delta = delta;
+            s.epsln = s.sn * beta_n;
+            s.dbar = -s.cs * beta_n;
+            s.root = sqrt(fma(s.dbar, s.dbar, gbar * gbar));
+            const double gamma = fmax(sqrt(fma(beta_n, beta_n, gbar * gbar)), eps);
+            s.cs = gbar / gamma;
+            s.sn = beta_n / gamma;
+            st.phi = s.cs * s.phibar;
+            s.phibar = s.sn * s.phibar;
+            st.denom = 1.0 / gamma;
+            s.gmax = fmax(s.gmax, gamma);
+            s.gmin = fmin(s.gmin, gamma);
+            const double zz = s.rhs1 / gamma;
+            s.rhs1 = fma(-delta, zz, s.rhs2);
+            s.rhs2 = -s.epsln * zz;
+            st.sj = 1.0 / beta_km2;
+            st.rotate = true;
+            st.cb = beta_km1 / beta_km2;
+        }
+        st.ca = 1.0 / beta_km1;
+        st.cc = alfa_km1 / beta_km1;
+        s.beta = beta_km1;
+        s.ibeta = st.ca;
+        s.alfa = alfa_km1;
+    }
+    s.itn = k;
+    return st;
+}
+
 // p_{k-1} = ca g_{k-1} - cb p_{k-3} - cc p_{k-2}, contracted the same way wherever it is formed
 __device__ __forceinline__ double2 kry_form_p(const KryStep &st, double2 g, double2 p3, double2 p2)
 {
@@ -1289,6 +1401,7 @@ struct KryArgs {
 // dependent chain of a launch is  kernel arguments -> {control word, slot, partial sums, neighbour
 // indices} -> {own vectors, neighbour gathers}.  A solve carried into the next launch sequence is
 // re-aligned to launch number 1 by k_beta_partial (realign_carried_solve).
+template <int EXACT>  // 1: the scalar step in scipy's own arithmetic (minres_scalars_exact; debug, occ_cond_eta only)
 __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base, int e, int k_launch)
 {
     OCC_STAMP(0)
@@ -1436,7 +1549,7 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     }
     OCC_STAMP(2)
     double part[4] = {0.0, 0.0, 0.0, 0.0};
-    const KryStep st = minres_scalars(s, k, S0, S1, S2, xn2, a.maxiter);
+    const KryStep st = EXACT ? minres_scalars_exact(s, k, S0, S1, S2, xn2, a.maxiter) : minres_scalars(s, k, S0, S1, S2, xn2, a.maxiter);
     if (st.stop) {
         if (writer) slot_store(out, s);
         projection_partials(a, chain, i, blk);

@@ -45,6 +45,7 @@ struct RsrArgs {
     double *big_eps;    // [C][m]
     double *big_scal;   // [C][2]
     double *big_rhs;    // [C][m]
+    double *big_dfac;   // [C][ceil(m / RSR_PANEL)][RSR_PANEL][RSR_PANEL] the factored diagonal blocks (k_rsrb_panel -> k_rsrb_solve)
     double tau_rate, tau_shape;
     ChainScalars *scs;
     unsigned *sync;     // hand-over counters of the two streams (Ctx::sync), or null
@@ -649,11 +650,14 @@ __global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int 
         if (blockIdx.x == 0 && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
         return;
     }
-    if (blockIdx.x == 0)
-        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
-            const int i = t / RSR_PANEL, j = t % RSR_PANEL;
-            if (i < kb && j < kb && j >= i) P[(size_t)(k0 + i) * m + k0 + j] = D[i][j];
-        }
+    // The factored diagonal block goes to a buffer of its own, NOT back into P: every workgroup of this launch loads the
+    // unfactored block from P above, and nothing orders those loads before a write-back by workgroup 0 -- a workgroup that
+    // starts late would factor an already factored (or half-written) block and solve its block row with the wrong U_kk
+    // (ADVICE r2).  P's diagonal block is never read again; k_rsrb_solve takes the factor from big_dfac.
+    if (blockIdx.x == 0) {
+        double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
+        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) F[t] = D[t / RSR_PANEL][t % RSR_PANEL];
+    }
     // the block row right of the diagonal block: U_kk' x = p, one column per thread
     const int j = k0 + kb + (int)blockIdx.x * 256 + tid;
     if (j < m) {
@@ -700,6 +704,7 @@ __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const double *U = a.gram + (size_t)chain * m * m;
+    const double *F = a.big_dfac + (size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);  // the diagonal blocks' factors
     for (int t = tid; t < m; t += 1024) y[t] = a.big_rhs[(size_t)chain * m + t];
     __syncthreads();
     // U'y = rhs, forward: the panel's own rows by one wave (lane t owns entry k0 + t), then everything right of it
@@ -708,7 +713,7 @@ __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
         if (tid < 64) {
             double v = (tid < kb) ? y[k0 + tid] : 0.0;
             for (int s2 = 0; s2 < kb; ++s2) {
-                const double us = (tid >= s2 && tid < kb) ? U[(size_t)(k0 + s2) * m + k0 + tid] : 1.0;  // row s2 of the block
+                const double us = (tid >= s2 && tid < kb) ? F[(size_t)(k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL) + s2 * RSR_PANEL + tid] : 1.0;  // row s2 of the block
                 const double ys = readlane_f64(v, s2) / readlane_f64(us, s2);
                 if (tid == s2) v = ys;
                 else if (tid > s2 && tid < kb) v = fma(-us, ys, v);
@@ -729,10 +734,11 @@ __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
         const int kb = min(RSR_PANEL, m - k0);
         if (tid < 64) {
             double v = (tid < kb) ? y[k0 + tid] : 0.0;
-            const double dg = (tid < kb) ? U[(size_t)(k0 + tid) * m + k0 + tid] : 1.0;
+            const double *Fk = F + (size_t)(k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
+            const double dg = (tid < kb) ? Fk[tid * RSR_PANEL + tid] : 1.0;
             for (int s2 = kb - 1; s2 >= 0; --s2) {
                 const double ts = readlane_f64(v, s2) / readlane_f64(dg, s2);
-                const double us = (tid < s2) ? U[(size_t)(k0 + tid) * m + k0 + s2] : 0.0;  // column s2 of the block
+                const double us = (tid < s2) ? Fk[tid * RSR_PANEL + s2] : 0.0;  // column s2 of the block
                 if (tid == s2) v = ts;
                 else if (tid < s2) v = fma(-us, ts, v);
             }

@@ -43,24 +43,62 @@ class FileComm:
     the files of the ranks it needs.  Operation numbers advance in lock step on all ranks (every rank must make the
     same calls in the same order, as with any communicator)."""
 
-    def __init__(self, rank, world, path, timeout=300.0):
+    def __init__(self, rank, world, path, timeout=300.0, session=False):
         self.rank, self.world, self.path, self.timeout = int(rank), int(world), path, float(timeout)
         self._op = 0
+        self._nonce = ''
         os.makedirs(path, exist_ok=True)
+        if session:
+            self._open_session()
+
+    def _open_session(self):
+        """A directory name can outlive a launch (a worker group restarted by the same agent, two launches from one shell,
+        a crashed run that never removed it): operation numbers restart at 0 and stale files -- an old ncclUniqueId, old
+        results -- would be read as current.  Rank 0 therefore opens a SESSION: it removes what it finds, then publishes a
+        nonce (its pid and start time) that prefixes every file name of this launch; the other ranks take a nonce only
+        from a LIVE rank 0 that is their sibling (same parent process), so the leftover of a dead launch is never taken."""
+        sess = os.path.join(self.path, 'session')
+        if self.rank == 0:
+            for f in os.listdir(self.path):
+                try:
+                    os.remove(os.path.join(self.path, f))
+                except OSError:
+                    pass
+            self._nonce = '%d-%x' % (os.getpid(), time.time_ns())
+            tmp = sess + '.tmp'
+            with open(tmp, 'w') as fh:
+                fh.write('%s %d' % (self._nonce, os.getppid()))
+            os.replace(tmp, sess)
+            return
+        t0 = time.monotonic()
+        while True:
+            try:
+                nonce, ppid = open(sess).read().split()
+                pid = int(nonce.split('-')[0])
+                alive = os.path.exists('/proc/%d' % pid) if os.path.isdir('/proc') else True
+                if alive and int(ppid) == os.getppid():
+                    self._nonce = nonce
+                    return
+            except (OSError, ValueError):
+                pass
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError('rank %d found no live session of rank 0 in %s within %.0f s' % (self.rank, self.path, self.timeout))
+            time.sleep(0.002)
 
     @classmethod
     def from_env(cls, timeout=300.0):
         """Rank / world size from the launcher's environment (``RANK``, ``WORLD_SIZE`` as torch.distributed.run and
-        most MPI-style launchers set them).  The directory is keyed by the rendezvous port and the launcher's PID --
-        all ranks of one launch are children of the same agent process -- so stale files of an earlier launch on the
-        same port are never read."""
+        most MPI-style launchers set them).  The directory is keyed by the rendezvous port, the run id, the elastic
+        restart count and the launcher's PID -- all ranks of one launch are children of the same agent process -- and
+        rank 0 opens a session in it (``_open_session``), so files of an earlier launch or attempt are never read."""
         rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
         base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
-        tag = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.getppid())
-        return cls(rank, world, os.path.join(base, 'occ_rdv_' + tag), timeout)
+        tag = '%s_%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'),
+                               os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), os.getppid())
+        return cls(rank, world, os.path.join(base, 'occ_rdv_' + tag), timeout, session=True)
 
     def _file(self, op, r):
-        return os.path.join(self.path, '%06d.%d' % (op, r))
+        return os.path.join(self.path, '%s%06d.%d' % (self._nonce + '.' if self._nonce else '', op, r))
 
     def _put(self, op, obj):
         tmp = self._file(op, self.rank) + '.tmp'
@@ -94,11 +132,22 @@ class FileComm:
         return np.max(np.stack([np.asarray(v, dtype=np.float64) for v in self.allgather_obj(np.asarray(x, dtype=np.float64))]), axis=0)
 
     def close(self):
-        """Collective: the last operation of the group; rank 0 removes the directory."""
+        """Collective, two-phase: after the last barrier every rank leaves a token saying it has read that barrier's files;
+        rank 0 removes the directory only when it has seen every token (a fixed sleep let a slow rank lose the file it was
+        still polling for)."""
         self.barrier()
-        if self.rank == 0:
-            time.sleep(0.05)   # the others have read this barrier's files or are about to
-            shutil.rmtree(self.path, ignore_errors=True)
+        bye = lambda r: os.path.join(self.path, '%sbye.%d' % (self._nonce + '.' if self._nonce else '', r))
+        if self.rank != 0:
+            try:
+                open(bye(self.rank), 'w').close()
+            except OSError:
+                pass
+            return
+        t0 = time.monotonic()
+        for r in range(1, self.world):
+            while not os.path.exists(bye(r)) and time.monotonic() - t0 < min(self.timeout, 30.0):
+                time.sleep(0.001)
+        shutil.rmtree(self.path, ignore_errors=True)
 
 
 class RcclComm:

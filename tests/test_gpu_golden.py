@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 KEY = 0x51ED270B27D9A4F5
 
 
+# Measured worst case of the device's solve against the REFERENCE's recorded solve, per fixture, over all recorded
+# iterations (tools/measure_golden_solve.py on an MI355X, round 3; production arithmetic): relative max-norm deviation of
+# [x z] and of eta.  The tests assert 2x these (the band the production arithmetic needs at 100x100 --
+# 1.4e-8, tests/test_gpu_parity.py -- must not be what small fixtures are held to: here it is 1e-11 at worst).
+MEASURED_SOLVE = {
+    'ref_queen150_ragged': (1.4e-15, 3.1e-15), 'ref_queen150_hparams': (9.4e-12, 1.7e-11), 'ref_rook400_v3': (1.6e-15, 1.9e-15),
+    'ref_queen400_v3': (4.3e-15, 5.4e-15), 'ref_graph300_weighted': (2.4e-13, 1.6e-13),
+}
+
+
 def _iters(g):
     return sorted({int(k[2:k.index('_')]) for k in g if k.startswith('it')})
 
@@ -27,6 +37,7 @@ def case(request):
     g = load_golden(request.param)
     prob, start = _problem_from_golden(request.param)
     eng = Engine(prob, [KEY])
+    eng.case_name = request.param
     yield g, prob, eng, start
     eng.close()
 
@@ -66,8 +77,9 @@ def test_eta_conditional_on_device(case):
         rhs, xz, eta, itn = eng.cond_eta(om, eps1, prior)
         assert np.abs(rhs - g[t + 'eta_rhs']).max() <= 1e-12 * np.abs(g[t + 'eta_rhs']).max()
         assert itn == int(g[t + 'eta_itn'])
-        assert np.abs(xz - g[t + 'eta_xz']).max() <= 5e-8 * np.abs(g[t + 'eta_xz']).max()
-        assert np.abs(eta - g[t + 'eta']).max() <= 1e-7 * np.abs(g[t + 'eta']).max()
+        bx, be = (max(2.0 * v, 2e-14) for v in MEASURED_SOLVE[eng.case_name])     # the measured worst case with 2x headroom (floor: 100 ulp)
+        assert np.abs(xz - g[t + 'eta_xz']).max() <= bx * np.abs(g[t + 'eta_xz']).max()
+        assert np.abs(eta - g[t + 'eta']).max() <= be * np.abs(g[t + 'eta']).max()
         assert abs(eta.sum()) < 1e-9 * max(1.0, np.abs(eta).sum())
 
 
@@ -142,6 +154,29 @@ def test_conditionals_chain_like_the_references_step(case):
         u[g['cfg_not_surveyed']] = g[t + 'z_u_ns']
     z = eng.cond_z(u)
     assert tau == pytest.approx(float(g[t + 'tau']), rel=1e-12)
-    assert np.abs(eta - g[t + 'eta']).max() <= 1e-7 * np.abs(g[t + 'eta']).max()
-    assert np.allclose(beta, g[t + 'beta'], rtol=1e-7) and np.allclose(alpha, g[t + 'alpha'], rtol=1e-10)
+    assert np.abs(eta - g[t + 'eta']).max() <= max(2.0 * MEASURED_SOLVE[eng.case_name][1], 2e-14) * np.abs(g[t + 'eta']).max()
+    assert np.allclose(beta, g[t + 'beta'], rtol=1e-9) and np.allclose(alpha, g[t + 'alpha'], rtol=1e-10)
     assert np.array_equal(z, g[t + 'z'])
+
+
+def test_eta_conditional_in_scipys_own_arithmetic_is_within_1e9_of_the_reference(case, monkeypatch):
+    """the production scalar step (one reciprocal square root per divisor, products for quotients) moves the
+    iterate by ~1e-8, so its tests carry a 5e-8 band -- wide enough to hide a small indexing or ordering error in the
+    vector part.  Debug knob OCC_DEBUG_EXACT_DIV=1: the same kernels (k_eta_init, k_minres, k_beta_partial: the vector
+    expressions, gathers, reduction orders of production) with the scalar step in scipy's own arithmetic
+    (minres_scalars_exact: a division and a square root wherever minres.py:10-372 has one) against the reference's recorded
+    solves (logit.py:80-92) at the tolerance SURVEY 8(c) names for an op-for-op replay: [x z] 1e-9, eta 1e-9 (measured:
+    8.4e-12 / 1.5e-11 at worst)."""
+    g, prob, eng, start = case
+    monkeypatch.setenv('OCC_DEBUG_EXACT_DIV', '1')
+    n = prob.n
+    for it in _iters(g):
+        t = f'it{it}_'
+        om, tau = g[t + 'omega_b'], float(g[t + 'tau'])
+        eps1 = g[t + 'eta_eps'][:n]
+        prior = (g[t + 'eta_rhs'] - g[t + 'eta_b'] - np.sqrt(om) * eps1) / np.sqrt(tau)
+        _seat(eng, start, beta=g[t + 'eta_beta'], tau=tau, z=g[t + 'eta_k'] + 0.5, xz=g[t + 'eta_x0'])
+        rhs, xz, eta, itn = eng.cond_eta(om, eps1, prior)
+        assert itn == int(g[t + 'eta_itn'])
+        assert np.abs(xz - g[t + 'eta_xz']).max() <= 1e-9 * np.abs(g[t + 'eta_xz']).max()
+        assert np.abs(eta - g[t + 'eta']).max() <= 1e-9 * np.abs(g[t + 'eta']).max()

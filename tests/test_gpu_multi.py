@@ -128,3 +128,75 @@ def test_rccl_communicator_and_distributed_creation_with_one_rank(tmp_path):
     A, B, T = run_sharded(prob, 2, size=8, burnin=2, random_state=3, device=0, comm=comm)
     assert A.shape == (2, 6, prob.q) and np.all(T > 0)
     comm.close()
+
+
+def test_a_broadcast_that_arrives_damaged_is_caught_and_named(monkeypatch):
+    """After the hand-over every sampler of a group checksums its copies of the fixed arrays ON ITS DEVICE and the sums are
+    compared with the root's (the first real multi-GPU run must be able to tell a wrong broadcast from a right one).
+    Debug knob: the peer's checksum of array 2 is flipped, as if those bytes had arrived damaged -- creation fails and
+    names the array."""
+    from occuspytial_amd._engine import EngineGroup
+    from occuspytial_amd._lib import EngineUnavailable
+    monkeypatch.setenv('OCC_GROUP_TRANSPORT', 'peer')
+    prob, _ = _problem_from_golden('ref_queen150_ragged')
+    keys = [KEY, KEY + 1, KEY + 2]
+    monkeypatch.setenv('OCC_DEBUG_CORRUPT_BROADCAST', '2')
+    with pytest.raises(EngineUnavailable, match='did not arrive intact: array `sell_val`'):
+        EngineGroup(prob, keys, [0, 0])
+    monkeypatch.delenv('OCC_DEBUG_CORRUPT_BROADCAST')
+    grp = EngineGroup(prob, keys, [0, 0])               # ... and the undamaged hand-over passes the same check
+    _run(grp, prob, 3)
+    grp.close()
+
+
+def test_without_librccl_the_group_copies_peer_to_peer_and_the_ranks_meet_through_files(tmp_path):
+    """A machine without librccl (ADVICE r2: that branch crashed -- dlerror() called twice -- and no test reached it;
+    OCC_RCCL_LIB=none skips the default names): in a fresh process (the library handle is looked up once per process) the
+    group's hand-over ends on hipMemcpyPeer with the reason, occ_comm_unique_id fails cleanly, and init_comm ends on the
+    file rendezvous."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    code = r'''
+import numpy as np
+from tests.test_gpu_parity import KEY, _problem_from_golden, _random_start
+from occuspytial_amd._engine import EngineGroup
+from occuspytial_amd.distributed import init_comm
+prob, _ = _problem_from_golden('ref_queen150_ragged')
+grp = EngineGroup(prob, [KEY, KEY + 1], [0, 0])
+assert grp.transport.startswith('hipMemcpyPeer (librccl could not be opened: OCC_RCCL_LIB=none'), grp.transport
+for c in range(2):
+    grp.set_start(c, **_random_start(prob, c))
+a, b, t = grp.run(6, 0)
+assert np.all(np.isfinite(a)) and np.all(t > 0)
+grp.close()
+comm, note = init_comm(device=0)
+assert note.startswith('file rendezvous (RCCL unusable'), note
+comm.close()
+print('ok')
+'''
+    env = dict(os.environ, OCC_RCCL_LIB='none', PYTHONPATH=ROOT, RANK='0', WORLD_SIZE='1', MASTER_PORT='29999',
+               TORCHELASTIC_RUN_ID='norccl_%d' % os.getpid())
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_rccl_broadcast_between_two_devices_equals_one_batch():
+    """The first thing a multi-GPU node runs (skipped on a one-GPU box): chains sharded over devices 0 and 1, the laid-out
+    problem broadcast device to device by RCCL (ncclCommInitAll + grouped ncclBroadcast over xGMI), checksummed on arrival
+    -- same chains as one batch on device 0, bit for bit (reference semantics: gibbs/parallel.py:20-41, base.py:293-306:
+    chain k owns generator k wherever it runs)."""
+    from occuspytial_amd import _lib
+    from occuspytial_amd._engine import Engine, EngineGroup
+    if _lib.load().occ_device_count() < 2:
+        pytest.skip('needs two GPUs')
+    prob, _ = _problem_from_golden('ref_graph300_weighted')
+    keys = [KEY + 3 * c for c in range(5)]
+    plain = Engine(prob, keys)
+    ref = _run(plain, prob, 5)
+    plain.close()
+    grp = EngineGroup(prob, keys, [0, 1])
+    assert grp.transport.startswith('rccl broadcast (ncclCommInitAll), 2 devices'), grp.transport
+    _same(ref, _run(grp, prob, 5))
+    grp.close()

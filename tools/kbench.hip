@@ -173,7 +173,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(k_omega_b<2>, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
     hipLaunchKernelGGL(k_noise, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 0);
     hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
-    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, k);
+    for (int k = 1; k <= 4; ++k) hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, st, ka, 0, 0, k);
     CK(hipStreamSynchronize(st));
 
     const bool eager = getenv("KB_EAGER") != nullptr;
@@ -204,7 +204,7 @@ int main(int argc, char **argv)
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         hipLaunchKernelGGL(k_eta_init, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0);
-        for (int k = 1; k <= 12; ++k) hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, k);
+        for (int k = 1; k <= 12; ++k) hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, st, ka, 0, 0, k);
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         for (int r = 0; r < 20; ++r) CK(hipGraphLaunch(ge, st));
@@ -224,7 +224,7 @@ int main(int argc, char **argv)
         }
     }
     for (int round = 0; round < 2; ++round) {
-        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres, gs, blk, 0, st, ka, 0, 0, 5); });
+        time_graph("minres k=5", [&] { hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, st, ka, 0, 0, 5); });
         time_graph("empty kernel", [&] { hipLaunchKernelGGL(k_empty, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("empty kernel 1 block", [&] { hipLaunchKernelGGL(k_empty, dim3(1), blk, 0, st, cp, c.sc, c.slots, 0, 0, 5); });
         time_graph("ctl-only kernel", [&] { hipLaunchKernelGGL(k_ctl_only, gs, blk, 0, st, cp, c.sc, c.slots, 0, 0, 5, (double *)c.rhs); });
