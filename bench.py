@@ -405,17 +405,27 @@ def main():
                      'basis': 'device wall clock read inside k_iter, first workgroup in to last chain out, every launch of the timed region'}
         stats_prof = eng0.stats()
         disp_us = stats_prof.get('profile_iter_dispatch_us', 0.0)
+        dispatch = None
         if fused and disp_us > 0:
-            steps = stats_prof['profile_minres_iterations'] + 3.0
-            bytes_launch = iter_bytes_per_launch(prob, C, sell, steps)
-            ka = {'avg_us': disp_us, 'launches': prof['iter_in_situ_hip_events']['launches']}
-            achieved = bytes_launch / (disp_us * 1e-6) / 1e9
-            timing = ('DISPATCH duration of k_iter (hipExtLaunchKernel start / stop events = the begin / end timestamps of the '
-                      'dispatch\'s completion signal, which is what rocprofv3 --kernel-trace reports) over 200 real iterations '
-                      'that continue the chains right after the timed region, the side stream running as in occ_run; bytes from '
-                      'the MINRES steps those launches ran.  roofline.in_kernel_clock: every launch of the timed region clocked '
-                      'from inside the kernel (shorter: it cannot see the launch ramp and the end-of-kernel release); '
-                      'profiles/r03_bench_kernel_trace_region.json: rocprofv3 kernel trace of this command, the same launches')
+            # the same 200 launches by both clocks: what the dispatch adds around the kernel's own view of itself
+            n0, m0 = stats['iter_kernel_launches'], stats['iter_kernel_mean_us']
+            n1, m1 = stats_prof['iter_kernel_launches'], stats_prof['iter_kernel_mean_us']
+            in_kernel_prof = (n1 * m1 - n0 * m0) / max(1, n1 - n0)
+            overhead = max(0.0, disp_us - in_kernel_prof)
+            est = m0 + overhead                     # dispatch duration of the TIMED REGION's launches
+            achieved = bytes_launch / (est * 1e-6) / 1e9
+            dispatch = {'dispatch_overhead_us': round(overhead, 3), 'profile_pass_dispatch_us': round(disp_us, 3),
+                        'profile_pass_in_kernel_us': round(in_kernel_prof, 3), 'profile_pass_launches': int(n1 - n0),
+                        'profile_pass_minres_steps_per_launch': round(stats_prof['profile_minres_iterations'] + 3.0, 2)}
+            ka = {'avg_us': est, 'launches': ka['launches']}
+            timing = ('mean DISPATCH duration of the k_iter launches of the timed region = their mean by the in-kernel clock '
+                      '(every launch; roofline.in_kernel_clock) + the dispatch overhead measured live on 200 further '
+                      'launches that continue the chains right after it: hipExtLaunchKernel start / stop events (the begin / '
+                      'end timestamps of the dispatch\'s completion signal = what rocprofv3 --kernel-trace reports; launch ramp '
+                      'and end-of-kernel release included) minus the in-kernel clock of the same launches '
+                      '(roofline.dispatch_basis).  HIP events cannot bracket a node of a replayed graph without adding nodes. '
+                      'Check: profiles/r03_bench_trace_region.json = the rocprofv3 kernel trace of this command averaged over '
+                      'the timed region\'s launches')
         traffic, traffic_file = pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else (None, None)
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
         # SURVEY 8(d)'s whole-iteration accounting beside the dominant kernel's: B_iter(measured K, R_e = R, n_no = 0.4 n)
@@ -460,6 +470,7 @@ def main():
                 'timing': timing,
                 'minres_steps_per_launch': round(steps, 2) if steps else None,
                 'in_kernel_clock': in_kernel,
+                'dispatch_basis': dispatch,
                 'algorithmic_bytes_per_minres_step': minres_bytes_per_launch(prob, C, sell),
                 'share_of_critical_path_launch_time': round(ka['avg_us'] * per_iter['iter' if fused else 'minres'] / total_us, 3) if total_us else None,
                 'avg_launch_us_by_kernel': {k: round(v['avg_us'], 3) for k, v in prof.items()},

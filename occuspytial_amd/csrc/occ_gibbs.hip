@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "occ_comm.hpp"
-#include "occ_iter.hpp"
+#include "occ_tiles.hpp"
 #include "occ_rsr.hpp"
 
 using namespace occ;
@@ -101,6 +101,12 @@ struct occ_sampler {
     int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
     bool xcd_local = false;  // k_iter<8, 1>: one XCD per chain, exchange through that XCD's L2 (occ_iter.hpp)
     bool xl_candidate = false, fused_fallback = false;
+    // k_tiles (occ_tiles.hpp): the persistent solve for problems too large for k_iter -- tiles of 256 sites with their vectors
+    // in LDS, T tiles per workgroup, G workgroups per chain in eight bands of B (one per XCD).  tiles_layout: the problem has
+    // that shape (256-thread blocks, the MINRES sums added in groups of T blocks: the launch-per-step kernels follow the
+    // same order, KryArgs::group_T); tiles: k_tiles is what K_ITER launches.
+    bool tiles_layout = false, tiles = false;
+    int tiles_T = 1, tiles_G = 0, tiles_B = 0;
     bool any_fits = false;   // the any-placement form fits the main stream's CUs (arithmetic; the residency probe decides)
     int nbg_any = 0;         // its workgroups per chain
     int tpb_plain = 256;     // threads per block of the launch-per-step path when no fused form applies
@@ -139,7 +145,7 @@ struct occ_sampler {
     // What creation decided -- the form of the fused kernel, the CU partition, device-side hand-overs -- kept so that an
     // engine that had to leave it at run time (fallback_to_launch_per_step) can come back (try_repromote)
     struct Preferred {
-        bool valid = false, persistent = false, xcd_local = false, flag_sync = false;
+        bool valid = false, persistent = false, xcd_local = false, flag_sync = false, tiles = false;
         int share_on = 0, main_cus = 0;
         std::vector<uint32_t> m_main, m_side;
     } pref;
@@ -391,7 +397,19 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             break;
         case K_RSR_ETA_BETA: hipLaunchKernelGGL(pick_rsr_eta_beta(c.p), gs, blk, 0, st, s->rsr, OCC_ARGS); break;
         case K_ITER:
-            if (s->xcd_local) {  // eight chains (one per XCD) per launch; more chains: the next eight right behind
+            if (s->tiles) {  // k_tiles: eight bands of B + 1 workgroups per chain (the surplus one of a band returns at once)
+                const dim3 gt(XL_SLOTS * (unsigned)(s->tiles_B + 1), (unsigned)c.C), bt(TILE);
+                const size_t lds = tiles_lds_bytes(s->tiles_T);
+                const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
+                if (s->ext_ev0) {
+                    if (s->tiles_T == 1) hipExtLaunchKernelGGL((k_tiles<8, 1>), gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
+                    else hipExtLaunchKernelGGL((k_tiles<8, 2>), gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
+                } else {
+                    if (s->tiles_T == 1) hipLaunchKernelGGL((k_tiles<8, 1>), gt, bt, lds, st, s->iter, e, fl);
+                    else hipLaunchKernelGGL((k_tiles<8, 2>), gt, bt, lds, st, s->iter, e, fl);
+                }
+            }
+            else if (s->xcd_local) {  // eight chains (one per XCD) per launch; more chains: the next eight right behind
                 for (int base = 0; base < c.C; base += XL_SLOTS) {
                     IterArgs ia = s->iter;
                     ia.chain_base = base;
@@ -929,6 +947,18 @@ int stream_probe(occ_sampler *s, bool *beside)
     return OCC_OK;
 }
 
+// k_tiles' invariant between launches (canaries in exchange buffer 1 and record buffer 1): established at creation and
+// after anything that may have left the buffers otherwise.
+int tiles_reset(occ_sampler *s)
+{
+    const Ctx &c = s->ctx;
+    hipLaunchKernelGGL(k_tiles_reset, dim3((unsigned)((c.n + 255) / 256), (unsigned)c.C), dim3(256), 0, s->stream, s->iter);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_tiles_reset failed");
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return OCC_OK;
+}
+
 // Residency probe of the fused iteration kernel in the form s->xcd_local / xl_wide / iter_window / iter.nbg select:
 // k_iter itself (flags bit 1) -- same grid, registers and LDS as the real launch -- runs ONE barrier among the
 // workgroups of every chain with a short time limit, three times.  It passes exactly when every chain's workgroups
@@ -955,8 +985,9 @@ int residency_probe(occ_sampler *s, bool *ok)
     HIP_TRY(fill_on(s, s->ctx.bar, 0, sizeof(unsigned) * (size_t)s->ctx.C * BAR_STRIDE));
     HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
     if ((rc = read_scalars(s, h))) return rc;
-    for (auto &sc : h) { sc.bar_base = 0; sc.err = 0; }
-    return write_scalars(s, h);
+    for (auto &sc : h) { sc.bar_base = s->tiles ? sc.bar_base + 16u : 0u; sc.err = 0; }  // (k_tiles: the tag of its tagged records, never reused)
+    if ((rc = write_scalars(s, h))) return rc;
+    return s->tiles ? tiles_reset(s) : OCC_OK;
 }
 
 }  // namespace
@@ -1259,8 +1290,30 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         s->iter_window = wmax <= 8 ? 8 : 16;
         const int wg_per_cu = s->iter_window == 8 ? 2 : 1;  // 255 and ~400 VGPRs
         s->generic = p > MAXC || q > MAXC;
-        const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && pb->rsr_dim == 0 && wmax <= 16 && !s->generic;
+        const bool fused_shape = pb->rsr_dim == 0 && wmax <= 16 && !s->generic;
+        const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && fused_shape;
         s->persistent = fused_ok && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
+        // k_tiles for what k_iter cannot hold (more sites than 64 workgroups of 512 per chain, more workgroups than two per
+        // CU): T tiles of 256 sites per workgroup on a 192-CU main stream -- four workgroups per CU at T = 1, three at T = 2
+        // (LDS: 24 KB per tile) -- and at most 512 workgroups per chain (one poll round of eight records per lane).  The
+        // LAYOUT (256-thread blocks, sums grouped by T) is decided by the shape alone, so that OCC_NO_PERSISTENT=1 and a
+        // run-time fallback run the launch-per-step kernels in the same summation order: same bits.
+        {
+            const int ntile = (n + TILE - 1) / TILE, main_t = ((prop.multiProcessorCount * 3 / 4) / 8) * 8;
+            const char *ft = std::getenv("OCC_FORCE_TILES");  // tests: 1 / 2 = that many tiles per workgroup whatever the size
+            int T = 0;
+            if ((long long)C * ntile <= 4LL * main_t && ntile <= 512) T = 1;
+            else if ((long long)C * ((ntile + 1) / 2) <= 3LL * main_t && (ntile + 1) / 2 <= 512) T = 2;
+            if (ft && std::atoi(ft) >= 1 && std::atoi(ft) <= 2) T = std::atoi(ft);
+            const bool big = n > XL_MAX_WG * ITER_WG_XL && (long long)nbg * C > 2LL * prop.multiProcessorCount;
+            s->tiles_layout = fused_shape && wmax <= 8 && T > 0 && !std::getenv("OCC_NO_TILES") && (big || ft != nullptr);
+            if (s->tiles_layout) {
+                s->tiles_T = T;
+                s->tiles_G = (ntile + T - 1) / T;
+                s->tiles_B = (s->tiles_G + XL_SLOTS - 1) / XL_SLOTS;
+                s->persistent = false;  // (k_iter's forms are out: decided below)
+            }
+        }
         // one XCD per chain (k_iter<8, 1, *>); candidates -- the probe below decides.  Per XCD the main stream has 20 CUs
         // (24 for larger lattices, 28 when few chains leave the side stream little to do), whole shader engines'
         // worth: an XCD deals a chain's workgroups round-robin over its four shader engines, so its CUs in the mask
@@ -1310,8 +1363,15 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         }
         s->fused_fallback = s->persistent;  // what holds without the XCD-local form
         s->persistent = s->persistent || s->xl_candidate;
+        if (s->tiles_layout) {
+            s->xl_candidate = false;
+            s->fused_fallback = false;
+            s->tiles = fused_ok;
+            s->persistent = s->tiles;
+            tpb = TILE;
+        }
         s->tpb_plain = tpb;  // what the launch-per-step path takes when no fused form applies
-        if (s->persistent) tpb = 64;
+        if (s->persistent && !s->tiles) tpb = 64;
     }
     // ---- streams.  The main stream carries the critical path (the eta solve); omega_a / alpha / noise of the
     // same iteration run beside it on the side stream.  With the fused iteration kernel the two streams get
@@ -1332,6 +1392,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // one XCD whatever the number of chains, two per CU
         if (s->xl_candidate) nmain = s->xl_main;  // 0: none
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
+        if (s->tiles) nmain = ((ncu * 3 / 4) / 8) * 8;         // k_tiles: six tiles of LDS per CU
         if (const char *split = std::getenv("OCC_CU_SPLIT")) {  // developer knob: CUs of the main stream; 0: no masks
             nmain = std::atoi(split);
             // a partition is cut in whole shader engines per XCD (see above): multiples of 32 CUs, both streams non-empty
@@ -1390,7 +1451,8 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
         const int hot_cus = s->main_cus > 0 ? s->main_hot_cus : prop.multiProcessorCount / XL_SLOTS;  // CUs of a chain's XCD
         if (!trust && s->xl_candidate && s->xl_nbg > s->xl_per_cu * hot_cus) s->xl_candidate = false;
-        s->persistent = s->xl_candidate || s->any_fits;
+        if (s->tiles && !trust && (long long)s->tiles_G * C > (long long)(s->tiles_T == 1 ? 4 : 3) * cus) s->tiles = false;
+        s->persistent = s->xl_candidate || s->any_fits || s->tiles;
         if (!s->persistent) {
             tpb = s->tpb_plain;
             if (pb->rsr_dim == 0 && (rc = demote_streams(s))) return rc;
@@ -1482,6 +1544,14 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         c.sync = s->sync_buf;
         s->iter.sync = c.sync;
     }
+    if (s->tiles) {
+        const size_t npad = ((size_t)n + 7) / 8 * 8;  // (a chain's exchange buffer starts on a 128-byte line)
+        s->iter.tiles_npad = (int)npad;
+        for (int b = 0; b < 3; ++b)
+            if ((rc = dev_alloc(s, &s->iter.tex[b], (size_t)C * npad))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.trec, (size_t)C * c.nb_n * 4))) return rc;
+        s->iter.tiles_T = s->tiles_T; s->iter.tiles_G = s->tiles_G; s->iter.tiles_B = s->tiles_B;
+    }
     if (s->persistent) {
         if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
         s->iter.clock = c.iter_clock;
@@ -1501,6 +1571,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     {
         KryArgs &k = s->kry;
         k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.maxiter = c.maxiter;
+        k.group_T = s->tiles_layout ? s->tiles_T : 1;
         k.dia_n = 0;
         k.dia_mask = nullptr;
         if (!dia_off.empty() && !std::getenv("OCC_NO_DIA")) {
@@ -1529,6 +1600,15 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     if (s->persistent) {
         const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
         bool ok = false;
+        if (s->tiles) {
+            ok = trust;
+            if (trust) { if ((rc = tiles_reset(s))) return rc; }
+            else if ((rc = residency_probe(s, &ok))) return rc;
+            if (std::getenv("OCC_VERBOSE"))
+                std::fprintf(stderr, "[occ] k_tiles: %d tiles per workgroup, %d workgroups per chain in bands of %d per XCD, main stream %d CUs: %s\n",
+                             s->tiles_T, s->tiles_G, s->tiles_B, s->main_cus, ok ? "resident" : "NOT resident");
+            if (!ok) s->tiles = false;
+        }
         if (s->xl_candidate) {
             s->xcd_local = true;
             s->iter.nbg = s->xl_nbg;
@@ -1600,6 +1680,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     s->pref.valid = true;
     s->pref.persistent = s->persistent;
     s->pref.xcd_local = s->xcd_local;
+    s->pref.tiles = s->tiles;
     s->pref.flag_sync = s->main_cus > 0 && s->sync_buf != nullptr && std::getenv("OCC_EVENT_SYNC") == nullptr;
     s->pref.share_on = c.share_on;
     s->pref.main_cus = s->main_cus;
@@ -2313,6 +2394,7 @@ static int fallback_to_launch_per_step(occ_sampler *s)
     destroy_graph(s);
     s->persistent = false;
     s->xcd_local = false;
+    s->tiles = false;
     s->device_timeout = false;
     s->launch_rc = OCC_OK;
     int rc;
@@ -2370,6 +2452,7 @@ static int try_repromote(occ_sampler *s)
     auto back_out = [&](const char *why) -> int {  // to the demoted state
         s->persistent = false;
         s->xcd_local = false;
+        s->tiles = false;
         int brc = demote_streams(s, true);
         if (brc) return brc;
         s->flag_sync = false;
@@ -2384,6 +2467,7 @@ static int try_repromote(occ_sampler *s)
     }
     s->persistent = s->pref.persistent;
     s->xcd_local = s->pref.xcd_local;
+    s->tiles = s->pref.tiles;
     HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     if (s->pref.persistent) {
         if ((rc = residency_probe(s, &ok))) return rc;
@@ -2601,8 +2685,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->n_blocks_rows = s->ctx.nb_r;
     out->threads_per_block = s->tpb;
     out->n_chains = s->ctx.C;
-    out->persistent_solve = s->persistent ? (s->xcd_local ? 2 : 1) : 0;
-    out->solve_workgroups = s->iter.nbg;
+    out->persistent_solve = s->persistent ? (s->tiles ? 3 : s->xcd_local ? 2 : 1) : 0;
+    out->solve_workgroups = s->tiles ? s->tiles_G : s->iter.nbg;
     out->main_stream_cus = s->main_cus;
     out->fused_fallbacks = (int32_t)s->fused_fallbacks;
     out->repromotions = (int32_t)s->repromotions;

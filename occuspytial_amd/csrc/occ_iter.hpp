@@ -87,6 +87,11 @@ struct IterArgs {
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
     double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
+    // k_tiles (occ_tiles.hpp): exchange buffers of p (three in rotation, [C][tiles_npad]), tagged records [C][nb_n][4],
+    // tiles per workgroup, workgroups per chain, workgroups per XCD band
+    double2 *tex[3];
+    double *trec;
+    int tiles_T, tiles_G, tiles_B, tiles_npad;
     int nbg;              // workgroups per chain
     int chain_base;       // one XCD per chain: first chain of this launch (more than eight chains run as several launches of eight)
     int C, p, q;

@@ -1380,6 +1380,8 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 // Everything k_minres needs to form its addresses, BY VALUE in the kernel argument block: with the
 // pointers in device memory every launch paid one more dependent (cache-cold) load level.
 struct KryArgs {
+    int group_T;                // > 1: the four sums of a step are added in groups of group_T consecutive blocks first (k_tiles'
+                                // order, occ_tiles.hpp: a workgroup of T tiles publishes one record); 1: block by block
     int n, nb_n, ell_w, dia_n;  // dia_n > 0: the off-diagonals lie on dia_n <= NPRE diagonals with one value each (any
                                 // unweighted lattice): column = row + dia_off[k] where bit k of dia_mask[row] is set --
                                 // one byte per row instead of 12 bytes per stored slot
@@ -1437,6 +1439,32 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
                     v[qi] = (slice < a.nb_n) ? t : 0.0;
                 }
             });
+        } else if (a.group_T > 1) {
+            // k_tiles' order: groups of group_T consecutive blocks (added in block order), lanes strided over the groups
+            const int gT = a.group_T, ngrp = (a.nb_n + gT - 1) / gT;
+            for (int g0 = ln; g0 < ngrp; g0 += 256) {
+                double v[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = g0 + 64 * r;
+#pragma unroll
+                    for (int qi = 0; qi < 4; ++qi) v[r][qi] = 0.0;
+                    for (int t = 0; t < gT; ++t) {
+                        const int b = g * gT + t;
+                        const int bc = min(b, a.nb_n - 1);
+#pragma unroll
+                        for (int qi = 0; qi < 4; ++qi) {
+                            const double tv = part[qi * a.nb_n + bc];
+                            v[r][qi] += (g < ngrp && b < a.nb_n) ? tv : 0.0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int qi = 0; qi < 4; ++qi) S[qi] += v[r][qi];
+                }
+            }
         } else
         // four rounds of loads in flight (a plain "load, add" loop waits for every round trip in turn: 15 of them at
         // 500x500); the sums are accumulated in the same order, rounds past the end add an exact 0
@@ -1950,7 +1978,10 @@ __device__ __forceinline__ void z_ob_body(const Ctx &c, ChainScalars *__restrict
         }
         // the next sequence has the other parity: its kernels read the word this sequence's kernels do not
         if (chain == chain_base && synced) c.sync[SYNC_MAIN_SEQ + (e ^ 1)] = seq + 1u;
-        if (c.claim != nullptr) c.claim[(size_t)chain * 16] = 0u;  // k_iter of this sequence is complete: the next one claims its slots from 0
+        if (c.claim != nullptr) {  // k_iter / k_tiles of this sequence is complete: the next one claims its places from 0
+#pragma unroll
+            for (int x = 0; x < 8; ++x) c.claim[(size_t)chain * 16 + x] = 0u;  // (k_tiles: one counter per XCD band)
+        }
     }
     if (skip) return;
     double beta[P];

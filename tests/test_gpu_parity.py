@@ -203,6 +203,48 @@ def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, latti
         assert out[mode][2] == out['launch_per_step'][2]
 
 
+@pytest.mark.parametrize('lattice, chains, tiles, iters', [((250, 250), 1, '1', 30), ((250, 250), 1, '2', 30), ((130, 170), 3, '2', 24),
+                                                           ((61, 67), 2, '1', 24), ((500, 500), 1, None, 12)])
+def test_tile_looping_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, tiles, iters):
+    """k_tiles (occ_tiles.hpp, BASELINE config 4's path): tiles of 256 sites with their vectors in LDS, one or two tiles per
+    workgroup, p exchanged through a canary-polled buffer (plain stores inside an XCD's band, write-through at the band
+    edges), one record per workgroup and step.  A stale, torn or early-read value anywhere would change the bits of eta.
+    Against the launch-per-step kernels in the same layout (256-thread blocks, sums grouped by T): every record, eta, xz,
+    z and every solve's iteration count agree exactly -- forced on mid-size lattices (one and two tiles, several chains, a
+    ragged last tile), and at 500x500 where it is what the engine takes by itself."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(*lattice, visits=3, p=2, q=2, random_state=5)
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY + 7 * c for c in range(chains)]
+    starts = [_random_start(prob, 11 + c) for c in range(chains)]
+    if tiles is not None:
+        monkeypatch.setenv('OCC_FORCE_TILES', tiles)
+    out = {}
+    for mode in ('tiles', 'launch_per_step'):
+        monkeypatch.delenv('OCC_NO_PERSISTENT', raising=False)
+        if mode == 'launch_per_step':
+            monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
+        eng = Engine(prob, keys)
+        st = eng.stats()
+        assert st['persistent_solve'] == (3 if mode == 'tiles' else 0) and st['threads_per_block'] == 256, st
+        for c in range(chains):
+            eng.set_start(c, **starts[c])
+        rec = eng.run(iters, 0)
+        eng.step()                                         # eager stepping through the same kernel
+        state = [(eng.get('eta', c), eng.get('xz', c), eng.get('z', c), eng.get('minres_itn', c)) for c in range(chains)]
+        out[mode] = (rec, state, eng.stats()['krylov_mean'], eng.stats()['fused_fallbacks'])
+        eng.close()
+    assert out['tiles'][3] == 0
+    for u, v in zip(out['tiles'][0], out['launch_per_step'][0]):
+        assert np.array_equal(u, v)
+    for su, sv in zip(out['tiles'][1], out['launch_per_step'][1]):
+        for u, v in zip(su, sv):
+            assert np.array_equal(u, v)
+    assert out['tiles'][2] == out['launch_per_step'][2]
+
+
 @pytest.mark.parametrize('env', [{'OCC_EVENT_SYNC': '1'}, {'OCC_EVENT_SYNC': '1', 'OCC_STREAM_EVENTS': '1'}, {'OCC_CU_SPLIT': '0'},
                                  {'OCC_DEBUG_STREAMS_SERIALISED': '1'},
                                  {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EAGER_ONLY': '1'}, {'OCC_NO_XCD_LOCAL': '1'},
