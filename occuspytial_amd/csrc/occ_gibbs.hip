@@ -401,13 +401,13 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                 const dim3 gt(XL_SLOTS * (unsigned)(s->tiles_B + 1), (unsigned)c.C), bt(TILE);
                 const size_t lds = tiles_lds_bytes(s->tiles_T);
                 const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
-                if (s->ext_ev0) {
-                    if (s->tiles_T == 1) hipExtLaunchKernelGGL((k_tiles<8, 1>), gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
-                    else hipExtLaunchKernelGGL((k_tiles<8, 2>), gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
-                } else {
-                    if (s->tiles_T == 1) hipLaunchKernelGGL((k_tiles<8, 1>), gt, bt, lds, st, s->iter, e, fl);
-                    else hipLaunchKernelGGL((k_tiles<8, 2>), gt, bt, lds, st, s->iter, e, fl);
-                }
+                const bool dia = s->kry.dia_n > 0;
+                void (*kt)(const IterArgs, int, int) = s->tiles_T == 1   ? (dia ? k_tiles<8, 1, 1> : k_tiles<8, 1, 0>)
+                                                       : s->tiles_T == 2 ? (dia ? k_tiles<8, 2, 1> : k_tiles<8, 2, 0>)
+                                                       : s->tiles_T == 3 ? (dia ? k_tiles<8, 3, 1> : k_tiles<8, 3, 0>)
+                                                                         : (dia ? k_tiles<8, 4, 1> : k_tiles<8, 4, 0>);
+                if (s->ext_ev0) hipExtLaunchKernelGGL(kt, gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
+                else hipLaunchKernelGGL(kt, gt, bt, lds, st, s->iter, e, fl);
             }
             else if (s->xcd_local) {  // eight chains (one per XCD) per launch; more chains: the next eight right behind
                 for (int base = 0; base < c.C; base += XL_SLOTS) {
@@ -947,7 +947,15 @@ int stream_probe(occ_sampler *s, bool *beside)
     return OCC_OK;
 }
 
-// k_tiles' invariant between launches (canaries in exchange buffer 1 and record buffer 1): established at creation and
+// CUs of the main stream with k_tiles: half the device (whole shader engines per XCD), OCC_TILES_MAIN_CUS overrides
+int tiles_main_cus(int ncu)
+{
+    int m = (ncu / 64) * 32;
+    if (const char *e = std::getenv("OCC_TILES_MAIN_CUS")) m = std::max(32, std::min((std::atoi(e) / 32) * 32, ncu - 32));
+    return m;
+}
+
+// k_tiles' invariant between launches (canaries in record buffer 1): established at creation and
 // after anything that may have left the buffers otherwise.
 int tiles_reset(occ_sampler *s)
 {
@@ -1294,17 +1302,21 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         const bool fused_ok = !std::getenv("OCC_NO_PERSISTENT") && fused_shape;
         s->persistent = fused_ok && (long long)nbg * C <= (long long)wg_per_cu * prop.multiProcessorCount;
         // k_tiles for what k_iter cannot hold (more sites than 64 workgroups of 512 per chain, more workgroups than two per
-        // CU): T tiles of 256 sites per workgroup on a 192-CU main stream -- four workgroups per CU at T = 1, three at T = 2
-        // (LDS: 24 KB per tile) -- and at most 512 workgroups per chain (one poll round of eight records per lane).  The
+        // CU): T tiles of 256 sites per workgroup, four workgroups per CU (128 registers; LDS: 16 KB per tile) on HALF the
+        // device -- the Polya-Gamma kernels of the side stream need the other half at these sizes (1.25 M draws per
+        // iteration at 500x500) -- and at most 512 workgroups per chain (a band's records: one per lane).  The
         // LAYOUT (256-thread blocks, sums grouped by T) is decided by the shape alone, so that OCC_NO_PERSISTENT=1 and a
         // run-time fallback run the launch-per-step kernels in the same summation order: same bits.
         {
-            const int ntile = (n + TILE - 1) / TILE, main_t = ((prop.multiProcessorCount * 3 / 4) / 8) * 8;
-            const char *ft = std::getenv("OCC_FORCE_TILES");  // tests: 1 / 2 = that many tiles per workgroup whatever the size
+            const int ntile = (n + TILE - 1) / TILE, main_t = tiles_main_cus(prop.multiProcessorCount);
+            const char *ft = std::getenv("OCC_FORCE_TILES");  // tests: 1 .. 4 = that many tiles per workgroup whatever the size
             int T = 0;
-            if ((long long)C * ntile <= 4LL * main_t && ntile <= 512) T = 1;
-            else if ((long long)C * ((ntile + 1) / 2) <= 3LL * main_t && (ntile + 1) / 2 <= 512) T = 2;
-            if (ft && std::atoi(ft) >= 1 && std::atoi(ft) <= 2) T = std::atoi(ft);
+            for (int t : {1, 2, 4, 3}) {  // the fewest tiles per workgroup whose workgroups are all resident (4 before 3: it keeps its registers)
+                if (T != 0) break;
+                const int g = (ntile + t - 1) / t;
+                if ((long long)C * g <= (long long)tiles_wg_per_cu(t) * main_t && g <= 512) T = t;
+            }
+            if (ft && std::atoi(ft) >= 1 && std::atoi(ft) <= 4) T = std::atoi(ft);
             const bool big = n > XL_MAX_WG * ITER_WG_XL && (long long)nbg * C > 2LL * prop.multiProcessorCount;
             s->tiles_layout = fused_shape && wmax <= 8 && T > 0 && !std::getenv("OCC_NO_TILES") && (big || ft != nullptr);
             if (s->tiles_layout) {
@@ -1392,7 +1404,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // one XCD whatever the number of chains, two per CU
         if (s->xl_candidate) nmain = s->xl_main;  // 0: none
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
-        if (s->tiles) nmain = ((ncu * 3 / 4) / 8) * 8;         // k_tiles: six tiles of LDS per CU
+        if (s->tiles) nmain = tiles_main_cus(ncu);             // k_tiles: eight tiles per CU
         if (const char *split = std::getenv("OCC_CU_SPLIT")) {  // developer knob: CUs of the main stream; 0: no masks
             nmain = std::atoi(split);
             // a partition is cut in whole shader engines per XCD (see above): multiples of 32 CUs, both streams non-empty
@@ -1451,7 +1463,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         const bool trust = std::getenv("OCC_DEBUG_SKIP_RESIDENCY_PROBE") != nullptr;  // tests of the run-time fallback
         const int hot_cus = s->main_cus > 0 ? s->main_hot_cus : prop.multiProcessorCount / XL_SLOTS;  // CUs of a chain's XCD
         if (!trust && s->xl_candidate && s->xl_nbg > s->xl_per_cu * hot_cus) s->xl_candidate = false;
-        if (s->tiles && !trust && (long long)s->tiles_G * C > (long long)(s->tiles_T == 1 ? 4 : 3) * cus) s->tiles = false;
+        if (s->tiles && !trust && (long long)s->tiles_G * C > (long long)tiles_wg_per_cu(s->tiles_T) * cus) s->tiles = false;
         s->persistent = s->xl_candidate || s->any_fits || s->tiles;
         if (!s->persistent) {
             tpb = s->tpb_plain;
@@ -1547,9 +1559,12 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
     if (s->tiles) {
         const size_t npad = ((size_t)n + 7) / 8 * 8;  // (a chain's exchange buffer starts on a 128-byte line)
         s->iter.tiles_npad = (int)npad;
-        for (int b = 0; b < 3; ++b)
-            if ((rc = dev_alloc(s, &s->iter.tex[b], (size_t)C * npad))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.tex[0], 3 * (size_t)C * npad))) return rc;  // (one allocation: k_tiles addresses the three through one descriptor)
+        s->iter.tex[1] = s->iter.tex[0] + (size_t)C * npad;
+        s->iter.tex[2] = s->iter.tex[0] + 2 * (size_t)C * npad;
         if ((rc = dev_alloc(s, &s->iter.trec, (size_t)C * c.nb_n * 4))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.tband, (size_t)C * 3 * XL_SLOTS * 4))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.tflag, (size_t)C * 2 * s->tiles_G))) return rc;
         s->iter.tiles_T = s->tiles_T; s->iter.tiles_G = s->tiles_G; s->iter.tiles_B = s->tiles_B;
     }
     if (s->persistent) {
@@ -1572,6 +1587,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         KryArgs &k = s->kry;
         k.n = c.n; k.nb_n = c.nb_n; k.ell_w = c.ell_w; k.maxiter = c.maxiter;
         k.group_T = s->tiles_layout ? s->tiles_T : 1;
+        k.group_B = s->tiles_layout ? s->tiles_B : 0;
         k.dia_n = 0;
         k.dia_mask = nullptr;
         if (!dia_off.empty() && !std::getenv("OCC_NO_DIA")) {

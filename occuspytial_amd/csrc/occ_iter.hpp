@@ -91,6 +91,8 @@ struct IterArgs {
     // tiles per workgroup, workgroups per chain, workgroups per XCD band
     double2 *tex[3];
     double *trec;
+    double *tband;               // [C][3][8][4] band records of a step (three buffers in rotation)
+    unsigned long long *tflag;   // [C][2][G] "p of step k is out" per workgroup: plain-stored / write-through copy
     int tiles_T, tiles_G, tiles_B, tiles_npad;
     int nbg;              // workgroups per chain
     int chain_base;       // one XCD per chain: first chain of this launch (more than eight chains run as several launches of eight)

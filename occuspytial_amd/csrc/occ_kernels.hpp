@@ -1380,8 +1380,9 @@ constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known
 // Everything k_minres needs to form its addresses, BY VALUE in the kernel argument block: with the
 // pointers in device memory every launch paid one more dependent (cache-cold) load level.
 struct KryArgs {
-    int group_T;                // > 1: the four sums of a step are added in groups of group_T consecutive blocks first (k_tiles'
-                                // order, occ_tiles.hpp: a workgroup of T tiles publishes one record); 1: block by block
+    int group_T, group_B;       // group_B > 0: k_tiles' order of the four sums of a step (occ_tiles.hpp): groups of group_T consecutive
+                                // blocks added in block order, bands of group_B consecutive groups (one group per lane, a wave
+                                // sum), the eight bands added in band order; group_B = 0: block by block, lanes strided
     int n, nb_n, ell_w, dia_n;  // dia_n > 0: the off-diagonals lie on dia_n <= NPRE diagonals with one value each (any
                                 // unweighted lattice): column = row + dia_off[k] where bit k of dia_mask[row] is set --
                                 // one byte per row instead of 12 bytes per stored slot
@@ -1439,31 +1440,25 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
                     v[qi] = (slice < a.nb_n) ? t : 0.0;
                 }
             });
-        } else if (a.group_T > 1) {
-            // k_tiles' order: groups of group_T consecutive blocks (added in block order), lanes strided over the groups
-            const int gT = a.group_T, ngrp = (a.nb_n + gT - 1) / gT;
-            for (int g0 = ln; g0 < ngrp; g0 += 256) {
-                double v[4][4];
+        } else if (a.group_B > 0) {
+            // k_tiles' order (see KryArgs::group_B); the totals are uniform when this is done: S0..xn2 below take them as they are
+            const int gT = a.group_T, gB = a.group_B, ngrp = (a.nb_n + gT - 1) / gT;
+            for (int x = 0; x < 8; ++x) {
+                const int g = x * gB + ln;
+                double v[4] = {0.0, 0.0, 0.0, 0.0};
+                const bool in = ln < gB && g < ngrp;
+                for (int t = 0; t < gT; ++t) {
+                    const int b = g * gT + t;
+                    const int bc = min(max(b, 0), a.nb_n - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int g = g0 + 64 * r;
-#pragma unroll
-                    for (int qi = 0; qi < 4; ++qi) v[r][qi] = 0.0;
-                    for (int t = 0; t < gT; ++t) {
-                        const int b = g * gT + t;
-                        const int bc = min(b, a.nb_n - 1);
-#pragma unroll
-                        for (int qi = 0; qi < 4; ++qi) {
-                            const double tv = part[qi * a.nb_n + bc];
-                            v[r][qi] += (g < ngrp && b < a.nb_n) ? tv : 0.0;
-                        }
+                    for (int qi = 0; qi < 4; ++qi) {
+                        const double tv = part[qi * a.nb_n + bc];
+                        v[qi] += (in && b < a.nb_n) ? tv : 0.0;
                     }
                 }
+                wave_sum4(v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int qi = 0; qi < 4; ++qi) S[qi] += v[r][qi];
-                }
+                for (int qi = 0; qi < 4; ++qi) S[qi] += v[qi];
             }
         } else
         // four rounds of loads in flight (a plain "load, add" loop waits for every round trip in turn: 15 of them at
@@ -1567,7 +1562,8 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
         if (blockDim.x == 64) {  // (already the totals, in the canonical order)
             S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3];
         } else if (threadIdx.x < 64) {
-            S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]);
+            if (a.group_B > 0) { S0 = S[0]; S1 = S[1]; S2 = S[2]; xn2 = S[3]; }  // (k_tiles' order: already the totals)
+            else { S0 = wave_sum(S[0]); S1 = wave_sum(S[1]); S2 = wave_sum(S[2]); xn2 = wave_sum(S[3]); }
             if (threadIdx.x == 0) { s_S[0] = S0; s_S[1] = S1; s_S[2] = S2; s_S[3] = xn2; }
         }
         if (blockDim.x != 64) {  // wave 0 reduced; the other waves take the totals from LDS

@@ -10,41 +10,54 @@
 //   * TILES of 256 sites, T consecutive tiles per 256-thread workgroup, the tile's own vectors (g, p_{k-2}, p_{k-3},
 //     w_{k-3}, w_{k-4}, x: 96 bytes per site) in LDS for the whole solve -- 24 KB per tile, six tiles per CU;
 //   * p EXCHANGED instead of re-formed at the neighbours: a step stores p_{k-1} (16 B per site) and gathers it at the
-//     eight neighbours -- no neighbour histories, 120 registers, three workgroups per CU.  An entry of the exchange
-//     buffer that still holds the CANARY has not been written yet: the gather polls it, so there is no barrier between
-//     "store p" and "apply A to p" -- the only chain-wide synchronisation of a step is the reduction of its four sums;
+//     eight neighbours -- no neighbour histories, three workgroups per CU.  A workgroup's p is ready when its FLAG of the step
+//     says so (every storing wave drained, workgroup barrier, one lane stores the flag): a workgroup waits for the flags of
+//     the few workgroups that hold its neighbours -- on a lattice the one before and the one after -- not for the chain;
+//     the rotation (w, x) of the step runs between "store p" and "look at the flags";
 //   * ONE XCD PER BAND of consecutive workgroups: a workgroup works for the band of the XCD it runs on (HW_REG_XCC_ID) and
 //     claims its place in it, as k_iter's one-XCD forms do for a chain.  Neighbours inside a band are read through that
 //     XCD's L2 (plain stores, L1-bypassing loads); only the 128-byte lines of the exchange buffer that hold a site with
-//     a neighbour in ANOTHER band are stored write-through (sc1) -- two lattice rows per band edge.  Every line is
-//     written whole by one store instruction of one wave in one of the two forms (MI355X_MICROARCH.md, Valid forms);
-//   * the four sums of a step per GROUP (= workgroup: its T tiles added in tile order) as one 32-byte record that is its
-//     own arrival flag (canary halves, three buffers in rotation -- occ_iter.hpp "XL step exchange"), stored
-//     write-through; every workgroup's first wave polls the records of all groups of the chain, all loads of a poll in
-//     flight at once, and runs the scalar recurrence for its workgroup.
+//     a neighbour in ANOTHER band are stored write-through (sc1) -- two lattice rows per band edge -- and a workgroup keeps
+//     two flags, a plain one for its band and a write-through one for the others.  Every line is written whole by one
+//     store instruction of one wave in one of the two forms (MI355X_MICROARCH.md, Valid forms);
+//   * the four sums of a step in TWO LEVELS: every workgroup (its T tiles added in tile order) stores one 32-byte record
+//     that is its own arrival flag (canary halves, three buffers in rotation -- occ_iter.hpp "XL step exchange") with
+//     plain stores; the first workgroup of a band adds up its band's records (one per lane, through the band's L2) and
+//     publishes the band's sums write-through; every workgroup polls the EIGHT band records and adds them in band order.
+//     (One level -- every workgroup polling all 489 group records across the XCDs -- cost 9 us per step.)
 // Same arithmetic, through the same functions (minres_pre / post, kry_form_*, eta_rhs_site, ...), and the same summation
-// order as the launch-per-step kernels at 256 threads per block with KryArgs::group_T = T (block partials combined in
-// wave order, groups of T consecutive blocks added in block order, lanes strided over the groups, one wave sum):
-// k_tiles, k_minres and the eager stepping path return the same bits.
+// order as the launch-per-step kernels at 256 threads per block with KryArgs::group_T = T, group_B = B (block partials
+// combined in wave order, groups of T consecutive blocks added in block order, a band's groups one per lane and a wave sum,
+// the bands added in band order): k_tiles, k_minres and the eager stepping path return the same bits.
 #pragma once
 #include "occ_iter.hpp"
 
 namespace occ {
 
 constexpr int TILE = 256;
-constexpr int TILE_VECS = 6;  // g, p (two by parity), w (two by parity), x
-enum : int { TV_G = 0, TV_P = 1, TV_W = 3, TV_X = 5 };
+constexpr int TILE_VECS = 4;  // in LDS: p (two by parity), w (two by parity); g and x live in registers
+enum : int { TV_P = 0, TV_W = 2 };
 __host__ __device__ constexpr size_t tiles_lds_bytes(int T) { return (size_t)T * TILE_VECS * TILE * sizeof(double2); }
+// Workgroups per CU by tiles per workgroup: registers (512 per lane and SIMD: 128 / 168 / 256 per wave at 4 / 3 / 2 workgroups
+// of four waves) and LDS (16 KB per tile of the CU's 160 KB).  Tiles per CU: 4, 6, 9, 8.
+__host__ __device__ constexpr int tiles_wg_per_cu(int T) { return T == 1 ? 4 : (T == 4 ? 2 : 3); }
 
-// The invariant between launches: every entry of exchange buffer 1 and every group record of record buffer 1 holds
-// the canary (step 1 of the next solve polls them).  k_tiles restores it at its end; this kernel establishes it at
-// creation and after anything that may have left the buffers in another state (residency probes, a failed launch).
+// The invariant between launches: every group record and every band record of record buffer 1 holds the canary (step 1
+// of the next solve polls them).  k_tiles restores it at its end; this kernel establishes it at creation and after
+// anything that may have left the buffers in another state (residency probes, a failed launch).
 __global__ void __launch_bounds__(256) k_tiles_reset(const IterArgs ia)
 {
-    const int chain = blockIdx.y, n = ia.a.n;
+    const int chain = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ia.tex[1][(size_t)chain * ia.tiles_npad + i] = rec_canary();
     if (i < 2LL * ia.tiles_G) reinterpret_cast<double2 *>(ia.part + ((size_t)chain * 3 + 1) * ia.a.nb_n * 4)[i] = rec_canary();
+    if (i < 2LL * XL_SLOTS) reinterpret_cast<double2 *>(ia.tband + ((size_t)chain * 3 + 1) * XL_SLOTS * 4)[i] = rec_canary();
+}
+
+// Broadcast of one lane's double; the lane index is wave-uniform.
+__device__ __forceinline__ double readlane_f64_t(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
 }
 
 // Records {half0, half1} of 16 bytes each with a TAG in the second double of both halves (the projection's sums, the
@@ -82,34 +95,48 @@ __device__ __forceinline__ bool poll_tagged(__amdgpu_buffer_rsrc_t buf, int nrec
     return true;
 }
 
-// The poll of a step: lane l reads the records of groups l, l + 64, ... (at most GR per lane, ALL loads in flight at once)
-// until none shows the canary, and adds them up in the canonical order.
-template <int GR>
-__device__ __forceinline__ bool poll_group_records(__amdgpu_buffer_rsrc_t buf, int ngroups, int lane, unsigned spin_limit, const ChainScalars &sc,
-                                                   double (&tot)[4])
+// A band's sums of a step: lane l reads the record of the band's l-th group (plain-stored by a workgroup of this XCD:
+// L2-served) until none shows the canary; one wave sum.  Returns false when it gave up.
+__device__ __forceinline__ bool poll_band_groups(__amdgpu_buffer_rsrc_t buf, int soff, int first, int count, int lane, unsigned spin_limit, const ChainScalars &sc,
+                                                 double (&tot)[4])
 {
     unsigned spins = 0;
     for (;;) {
-        double2 lo[GR], hi[GR];
-#pragma unroll
-        for (int r = 0; r < GR; ++r) {  // (records past the last group fall outside the descriptor: zeros)
-            lo[r] = load_sc1(buf, (64 * r + lane) * 32);
-            hi[r] = load_sc1(buf, (64 * r + lane) * 32 + 16);
-        }
-        bool pend = false;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tot[q] = 0.0;
-#pragma unroll
-        for (int r = 0; r < GR; ++r) {
-            pend = pend || rec_pending(lo[r]) || rec_pending(hi[r]);
-            tot[0] += lo[r].x; tot[1] += lo[r].y; tot[2] += hi[r].x; tot[3] += hi[r].y;
-        }
-        if (!__any(pend)) break;
+        const bool in = lane < count;
+        const int o = (first + (in ? lane : 0)) * 32;
+        const double2 lo = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(buf, o, soff, 16)), hi = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(buf, o + 16, soff, 16));
+        tot[0] = in ? lo.x : 0.0; tot[1] = in ? lo.y : 0.0; tot[2] = in ? hi.x : 0.0; tot[3] = in ? hi.y : 0.0;
+        if (!__any(in && (rec_pending(lo) || rec_pending(hi)))) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > spin_limit) return false;
         if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;
     }
     wave_sum4(tot);
+    return true;
+}
+// The chain's sums of a step: the eight band records (write-through stores, L1-bypassing loads), added in band order.
+// Lane x < nbands loads band x's record (eight registers where "every lane all eight" took 64); the totals are formed from
+// the lanes' values by v_readlane, band 0 first.  (`nbands`: bands that hold a workgroup.)
+__device__ __forceinline__ bool poll_bands(__amdgpu_buffer_rsrc_t buf, int soff, int nbands, int lane, unsigned spin_limit, const ChainScalars &sc, double (&tot)[4])
+{
+    unsigned spins = 0;
+    double2 lo, hi;
+    for (;;) {
+        const bool in = lane < nbands;
+        const int o = (in ? lane : 0) * 32;
+        lo = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(buf, o, soff, 16));
+        hi = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(buf, o + 16, soff, 16));
+        if (!__any(in && (rec_pending(lo) || rec_pending(hi)))) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit) return false;
+        if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[q] = 0.0;
+    for (int x = 0; x < nbands; ++x) {
+        tot[0] += readlane_f64_t(lo.x, x); tot[1] += readlane_f64_t(lo.y, x);
+        tot[2] += readlane_f64_t(hi.x, x); tot[3] += readlane_f64_t(hi.y, x);
+    }
     return true;
 }
 
@@ -142,19 +169,27 @@ __device__ __forceinline__ void tile_beta_terms(const double *Xt, int n, int i, 
 // flags: bit 0 = hand over to / from the side stream through the device counters; bit 1 = residency probe (one exchange
 // among the workgroups of every chain with a short time limit, nothing else -- same grid, registers and LDS as the real
 // launch).
-template <int NW, int T>
-__global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs ia, int e, int flags)
+// DIA = 1: the off-diagonals lie on at most eight diagonals with one value each (KryArgs::dia_*: any unweighted lattice) -- a
+// site's neighbours and coefficients are (mask bit, constant offset, constant value): one register per tile where the
+// general (SELL) form keeps 24, which is what lets two tiles per workgroup fit four workgroups of 128 registers on a CU.
+template <int NW, int T, int DIA>
+__global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterArgs ia, int e, int flags)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 s_state[];  // [T][TILE_VECS][TILE]
-    __shared__ int s_flag, s_noise_ok, s_claim;
+    extern __shared__ __attribute__((aligned(16))) double2 s_state[];  // [T][TILE_VECS][TILE]; phase C: the block partials of beta's system
+    __shared__ int s_flag, s_noise_ok, s_claim, s_wlo[4], s_whi[4];
     __shared__ double s_bcast[12];
-    __shared__ double s_part[T][4][NACC_MAX];  // per tile and wave: the block partials of a reduction (wave order)
+    __shared__ double s_part[T][4][4];  // per tile and wave: the block partials of a step's sums (wave order)
     __shared__ Slot s_slot;
     const bool probe = (flags & 2) != 0;
     const int sync_on = probe ? 0 : (flags & 1);
     const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
     const KryArgs &a = ia.a;
-    const int chain = (int)blockIdx.y, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (a scalar register by force: with plain `blockIdx.y` the compiler sank the 64-bit extension of the chain number into the
+    // one-lane branch of the claim below, merged it back as a VECTOR register, and every buffer descriptor derived from it
+    // became lane-dependent in its eyes: a waterfall loop around each of the kernel's 65 buffer accesses)
+    const int chain = (int)blockIdx.y, tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    size_t chain64 = (size_t)chain;
+    asm volatile("" : "+s"(chain64));  // pinned to scalar registers HERE, in front of the one-lane branch below
     const unsigned my_xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;  // HW_REG_XCC_ID
     const bool synced = sync_on && ia.sync != nullptr;
     // ---- which group?  The band of the XCD this workgroup runs on, the next free place in it
@@ -162,7 +197,7 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
     const int band_first = (int)my_xcc * B, band_size = min(B, G - band_first);
     if (band_size <= 0) return;
     int ticket = 0;
-    if (tid == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + (size_t)chain * 16 + my_xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + chain64 * 16 + my_xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_setprio(3);
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
@@ -186,21 +221,21 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
     const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
     const uint32_t it = ctl.it;
     const int n = a.n, nt = a.nb_n;  // sites; tiles (= blocks of 256 of the launch-per-step kernels)
-    const size_t co = (size_t)chain * n;
+    const size_t co = chain64 * n;
     const bool lead = tid < 64;
     const double2 zero2 = make_double2(0.0, 0.0);
     // exchange buffers (p of a step; three in rotation), group records (three in rotation), tagged records
-    const size_t cox = (size_t)chain * ia.tiles_npad;  // (a chain's exchange buffer starts on a 128-byte line)
-    const __amdgpu_buffer_rsrc_t ebuf[3] = {
-        __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tex[0] + cox), 0, n * 16, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tex[1] + cox), 0, n * 16, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tex[2] + cox), 0, n * 16, 0x00020000)};
-    double *part_base = ia.part + (size_t)chain * 3 * nt * 4;
-    const __amdgpu_buffer_rsrc_t pbuf[3] = {
-        __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, G * 32, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)nt * 4), 0, G * 32, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)nt * 8), 0, G * 32, 0x00020000)};
-    const __amdgpu_buffer_rsrc_t tbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.trec + (size_t)chain * nt * 4), 0, nt * 32, 0x00020000);
+    // ONE descriptor per family of rotating buffers, the buffer of a step chosen by the instruction's SCALAR offset (three
+    // descriptors each cost 36 more scalar registers, spilled and re-read every step).  The descriptors span all three
+    // buffers, so nothing is clipped at a buffer's end: lanes without a site store nothing and gather their own row n - 1.
+    const int e_stride = ia.C * ia.tiles_npad * 16, p_stride = nt * 32, b_stride = XL_SLOTS * 32;  // bytes between the rotating buffers
+    const __amdgpu_buffer_rsrc_t ebuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tex[0] + chain64 * ia.tiles_npad), 0, 2 * e_stride + n * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.part + chain64 * 3 * nt * 4), 0, 3 * p_stride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.trec + chain64 * nt * 4), 0, nt * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tband + chain64 * 3 * XL_SLOTS * 4), 0, 3 * b_stride, 0x00020000);
+    // "my p of step k is out": two words per workgroup -- [0][wg] plain (readers of this band), [1][wg] write-through (others)
+    const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tflag + chain64 * 2 * G), 0, 2 * G * 8, 0x00020000);
+    const bool band_leader = place == 0;
     const unsigned bar_base = sc.bar_base;
     auto st_vec = [&](int t, int v) -> double2 & { return s_state[((size_t)t * TILE_VECS + v) * TILE + tid]; };
 
@@ -222,14 +257,29 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
     }
 
     // ---- phase A: tau, right-hand side, p_0 = b - A x0 (inputs come from earlier launches: plain loads) -----------
-    int off[T][NW];    // byte offset of neighbour kk in a [n] double2 array (the site itself where there is none)
-    double av[T][NW];  // Q_ij, then tau * Q_ij
+    PHASE_STAMP(0, 0)
+    constexpr int TS = DIA ? 1 : T;  // (DIA: the two arrays below are not used)
+    int off[TS][NW];   // byte offset of neighbour kk in a [n] double2 array (the site itself where there is none)
+    double av[TS][NW]; // Q_ij, then tau * Q_ij
+    unsigned dmask = 0u;  // DIA: bits 8 t .. 8 t + 7 = which of the diagonals site t of this lane has
+    double tau_r = 0.0;   // DIA: tau (a coefficient is tau * dia_val[kk], formed where it is used: the same product)
     double dg[T];      // tau * Q_ii + omega_b
+    // neighbour kk of tile t's site: offset in the exchange buffers and coefficient
+    auto nb_off = [&](int t, int kk, int i, int myoff) -> int {
+        if constexpr (DIA) return ((dmask >> (8 * t + kk)) & 1u) ? (i + a.dia_off[kk]) * 16 : myoff;
+        else return off[t][kk];
+    };
+    auto nb_av = [&](int t, int kk) -> double {
+        if constexpr (DIA) return ((dmask >> (8 * t + kk)) & 1u) ? tau_r * a.dia_val[kk] : 0.0;
+        else return av[t][kk];
+    };
     unsigned sc1mask = 0u;  // bit t: this lane's 128-byte line of tile t holds a site with a neighbour in another band
     bool act[T];
     double om[T], zv[T];
+    double2 gr[T], xr[T];  // g_{k-1} and x of this lane's sites (registers: with them in LDS a CU held six tiles, now eight)
+    int wlo = wg, whi = wg;  // the workgroups that hold this workgroup's neighbours (a superset: the range between the extremes)
     {
-        double xb[T], qd[T], en[T], up[T];
+        double xb[T], qd[T], en[T], up[T], xav[T][NW];
         double2 x0[T], xn[T][NW];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -237,8 +287,8 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
             act[t] = i < n;
             const int ic = act[t] ? i : n - 1;
             const size_t ci = co + ic;
-            int base, width;
-            {
+            int base = 0, width = 0;
+            if constexpr (!DIA) {
                 const int sl = ic >> 6;
                 if (a.ell_w > 0) { width = a.ell_w; base = sl * a.ell_w * 64; }
                 else { base = a.sell_ptr[sl]; width = (a.sell_ptr[sl + 1] - base) >> 6; }
@@ -249,24 +299,43 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
             x0[t] = a.Xv[ci];
             qd[t] = a.qdiag[ic];
             bool remote = false;
+            const unsigned dm = (DIA && act[t]) ? (unsigned)a.dia_mask[ic] : 0u;
+            if constexpr (DIA) dmask |= dm << (8 * t);
 #pragma unroll
             for (int kk = 0; kk < NW; ++kk) {
-                const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);
-                const bool has = act[t] && kk < width;
-                const int j = has ? a.sell_col[slot] : ic;
-                av[t][kk] = has ? a.sell_val[slot] : 0.0;
-                off[t][kk] = has ? j * 16 : (act[t] ? i * 16 : n * 16);
+                bool has;
+                int j;
+                if constexpr (DIA) {
+                    has = kk < a.dia_n && ((dm >> kk) & 1u);
+                    j = has ? ic + a.dia_off[kk] : ic;
+                    xav[t][kk] = has ? a.dia_val[kk] : 0.0;
+                } else {
+                    const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);
+                    has = act[t] && kk < width;
+                    j = has ? a.sell_col[slot] : ic;
+                    xav[t][kk] = has ? a.sell_val[slot] : 0.0;
+                    off[t][kk] = (has ? j : ic) * 16;
+                }
                 xn[t][kk] = a.Xv[co + j];
-                remote = remote || (has && (j / (T * TILE)) / B != (int)my_xcc);
+                const int jw = j / (T * TILE);  // the workgroup that holds the neighbour
+                remote = remote || (has && jw / B != (int)my_xcc);
+                wlo = min(wlo, has ? jw : wg);
+                whi = max(whi, has ? jw : wg);
             }
             // (the 8 lanes of a 128-byte line decide together: a line is stored whole in ONE of the two forms)
             const unsigned long long m = __ballot(remote);
             if ((m >> (lane & 56)) & 0xffull) sc1mask |= 1u << t;
         }
-        if (synced) {
-            __syncthreads();
-            if (!s_noise_ok && writer) sc.err = -2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wlo = min(wlo, __shfl_xor(wlo, o));
+            whi = max(whi, __shfl_xor(whi, o));
         }
+        if (lane == 0) { s_wlo[wave] = wlo; s_whi[wave] = whi; }
+        __syncthreads();  // (also: thread 0's wait for the side stream's noise is over)
+        wlo = min(min(s_wlo[0], s_wlo[1]), min(s_wlo[2], s_wlo[3]));
+        whi = max(max(s_whi[0], s_whi[1]), max(s_whi[2], s_whi[3]));
+        if (synced && !s_noise_ok && writer) sc.err = -2;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = (wg * T + t) * TILE + tid;
@@ -279,10 +348,11 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
                 up[t] = ia.uprior[it & 1][ci];
             }
         }
+        PHASE_STAMP(0, 1)
         double tau = 0.0;
         if (lead) {  // the order of reduce_partials<1> (k_eta_init at 256 threads per block)
             double q = 0.0;
-            const double *pq = ia.part_quad + (size_t)chain * nt;
+            const double *pq = ia.part_quad + chain64 * nt;
             for (int b0 = lane; b0 < nt; b0 += 256) {
                 double v[4];
 #pragma unroll
@@ -308,6 +378,8 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
         }
         __syncthreads();
         tau = s_bcast[0];
+        tau_r = tau;
+        PHASE_STAMP(0, 2)
         const double sqt = sqrt(tau);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -317,18 +389,20 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
             double ax = dg[t] * x0[t].x, az = dg[t] * x0[t].y;
 #pragma unroll
             for (int kk = 0; kk < NW; ++kk) {
-                av[t][kk] = tau * av[t][kk];
-                ax = fma(av[t][kk], xn[t][kk].x, ax);
-                az = fma(av[t][kk], xn[t][kk].y, az);
+                const double c = tau * xav[t][kk];
+                if constexpr (!DIA) av[t][kk] = c;
+                ax = fma(c, xn[t][kk].x, ax);
+                az = fma(c, xn[t][kk].y, az);
             }
             if (act[t]) ia.rhs[co + i] = y;
-            st_vec(t, TV_G) = make_double2(y - ax, 1.0 - az);  // p_0: plays g at step 1 (ca = 1, cb = cc = 0)
+            gr[t] = make_double2(y - ax, 1.0 - az);  // p_0: plays g at step 1 (ca = 1, cb = cc = 0)
             st_vec(t, TV_P) = zero2; st_vec(t, TV_P + 1) = zero2;
             st_vec(t, TV_W) = zero2; st_vec(t, TV_W + 1) = zero2;
-            st_vec(t, TV_X) = x0[t];
+            xr[t] = x0[t];
         }
     }
 
+    PHASE_STAMP(0, 3)
     // ---- phase B: MINRES.  Step k: p_{k-1} formed and published, the rotation of iteration k - 2, g_k = A p_{k-1} from the
     // neighbours' p_{k-1}, the four sums; the coefficients of step k + 1 come from the sums of step k.
     Slot &s = s_slot;
@@ -343,68 +417,102 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
     }
     st.ca = 1.0; st.cb = 0.0; st.cc = 0.0; st.rotate = false; st.stop = false;
     int k = 1;
+    const unsigned long long flag_hi = (unsigned long long)bar_base << 32;  // flags of this launch: (launch counter, step)
     for (;; ++k) {
+        SOLVE_STAMP(0)
         if (st.stop) break;
-        const int kb = k % 3, kn = (k + 1) % 3, pa = TV_P + (k & 1), pb = TV_P + ((k + 1) & 1), wa = TV_W + (k & 1), wb = TV_W + ((k + 1) & 1);
+        // (the step number is wave-uniform, but the loop leaves on values read from LDS and the compiler then takes everything
+        // derived from k for lane-dependent: a buffer descriptor picked by k % 3 became a waterfall loop around EVERY gather,
+        // each with its own s_waitcnt -- 9.7 us per step.  Scalar registers by force.)
+        k = __builtin_amdgcn_readfirstlane(k);
+        const int kb = __builtin_amdgcn_readfirstlane(k % 3), kn = __builtin_amdgcn_readfirstlane((k + 1) % 3);
+        const int pa = TV_P + (k & 1), pb = TV_P + ((k + 1) & 1), wa = TV_W + (k & 1), wb = TV_W + ((k + 1) & 1);
+        const int e_so = kb * e_stride, p_so = kb * p_stride, p_sn = kn * p_stride, b_so = kb * b_stride, b_sn = kn * b_stride;  // scalar offsets
         double part[T][4];
-        // -- first half: p_{k-1} at the site (published), w_{k-2}, x_{k-2}
+        // -- p_{k-1} at the site, published
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = (wg * T + t) * TILE + tid;
-            const int myoff = act[t] ? i * 16 : n * 16;
-            const double2 g = st_vec(t, TV_G), p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
+            const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
             const double2 p = kry_form_p(st, g, p3, p2);
-            const int aux = ((sc1mask >> t) & 1u) ? 16 : 0;
             // (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
-            if (aux) {
-                __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf[kb], myoff, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), ebuf[kn], myoff, 0, 16);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf[kb], myoff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), ebuf[kn], myoff, 0, 0);
+            if (act[t]) {
+                if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf, i * 16, e_so, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf, i * 16, e_so, 0);
             }
             part[t][0] = dot2(p, p);
             part[t][2] = (k >= 2) ? dot2(p, p2) : 0.0;
             part[t][3] = 0.0;
+        }
+        // this group's record of step k + 1 (and, band leader, the band's) shows the canary before the one of step k is out
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_sn, 0);
+        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_sn, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's p is out (L2, or memory for the write-through lines)
+        __syncthreads();
+        if (tid < 2) {  // ... the workgroup's: say so
+            const unsigned long long v = flag_hi | (unsigned)k;
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v2u w2;
+            w2.x = (unsigned)v; w2.y = (unsigned)(v >> 32);
+            if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, wg * 8, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, (G + wg) * 8, 0, 16);
+        }
+        SOLVE_STAMP(1)
+        // -- while the flags travel: w_{k-2}, x_{k-2} (the rotation of iteration k - 2)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const double2 p3 = st_vec(t, pb);
             if (st.rotate) {
                 const double2 w = kry_form_w(st, p3, st_vec(t, wa), st_vec(t, wb));  // (p_{k-3}, w_{k-4}, w_{k-3})
-                double2 x = st_vec(t, TV_X);
-                x.x = fma(st.phi, w.x, x.x);
-                x.y = fma(st.phi, w.y, x.y);
+                xr[t].x = fma(st.phi, w.x, xr[t].x);
+                xr[t].y = fma(st.phi, w.y, xr[t].y);
                 st_vec(t, wa) = w;
-                st_vec(t, TV_X) = x;
-                part[t][3] = dot2(x, x);
+                part[t][3] = dot2(xr[t], xr[t]);
             }
-            st_vec(t, pb) = p;  // p_{k-1} takes p_{k-3}'s place
         }
-        // this group's record of step k + 1 shows the canary before its record of step k is out
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf[kn], wg * 32 + tid * 16, 0, 16);
-        // -- second half: g_k = A p_{k-1}; the neighbours' p_{k-1} are polled (the canary: not written yet)
-        bool gave_up = false;
+        // -- the neighbours' workgroups have published p_{k-1}?  One wave looks at their flags (lane l: workgroup wlo + l).
+        if (lead) {
+            const unsigned long long want = flag_hi | (unsigned)k;
+            unsigned spins = 0;
+            bool ok = true;
+            for (int w0 = wlo; w0 <= whi && ok; w0 += 64) {
+                for (;;) {
+                    const int w = w0 + lane;
+                    const bool in = w <= whi && w != wg;
+                    const int wc = in ? w : wg;
+                    const bool local = wc / B == (int)my_xcc;
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u f0 = __builtin_amdgcn_raw_buffer_load_b64(fbuf, (local ? wc : G + wc) * 8, 0, 16);
+                    const unsigned long long f = ((unsigned long long)f0.y << 32) | f0.x;
+                    if (!__any(in && f != want)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit || ((spins & 1023u) == 0u && chain_err(sc) != 0)) { ok = false; break; }
+                }
+            }
+            if (!ok && lane == 0) s_flag = 1;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no gather moves above the flags
+        SOLVE_STAMP(2)
+        // -- g_k = A p_{k-1} from the neighbours' p_{k-1}; p_{k-1} takes p_{k-3}'s place
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             double2 pj[NW];
-            unsigned spins = 0;
-            for (;;) {
-                bool pend = false;
+            const int i = (wg * T + t) * TILE + tid;
+            const int myoff = (act[t] ? i : n - 1) * 16;
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    pj[kk] = load_sc1(ebuf[kb], off[t][kk]);
-                    pend = pend || (av[t][kk] != 0.0 && rec_pending(pj[kk]));
-                }
-                if (!__any(pend)) break;
-                if (++spins > spin_limit || ((spins & 1023u) == 0u && chain_err(sc) != 0)) { gave_up = true; break; }
-            }
-            const double2 p = st_vec(t, pb);
+            for (int kk = 0; kk < NW; ++kk) pj[kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_so, 16));
+            const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);
+            const double2 p = kry_form_p(st, g, p3, p2);  // (re-formed: the same bits as the stored one, no LDS round trip)
             double gx = dg[t] * p.x, gy = dg[t] * p.y;
 #pragma unroll
             for (int kk = 0; kk < NW; ++kk) {
-                // (a slot without a neighbour has coefficient 0 and may hold the canary, a NaN: select, do not multiply)
-                const double2 q = (av[t][kk] != 0.0) ? pj[kk] : zero2;
-                gx = fma(av[t][kk], q.x, gx);
-                gy = fma(av[t][kk], q.y, gy);
+                const double c = nb_av(t, kk);
+                gx = fma(c, pj[kk].x, gx);
+                gy = fma(c, pj[kk].y, gy);
             }
-            st_vec(t, TV_G) = make_double2(gx, gy);
+            st_vec(t, pb) = p;
+            gr[t] = make_double2(gx, gy);
             part[t][1] = fma(p.y, gy, p.x * gx);
             if (!act[t]) { part[t][0] = 0.0; part[t][1] = 0.0; part[t][2] = 0.0; part[t][3] = 0.0; }
         }
@@ -418,9 +526,9 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
                 for (int q = 0; q < 4; ++q) s_part[t][wave][q] = part[t][q];
             }
         }
-        if (gave_up && lane == 0) s_flag = 1;  // (any wave; read after the barrier below)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's p, its canaries of step k + 1: out before the record
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the canaries of step k + 1 are out before the record of step k
         __syncthreads();
+        SOLVE_STAMP(3)
         if (tid < 4) {
             double grp = 0.0;
 #pragma unroll
@@ -433,12 +541,20 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
             s_bcast[4 + tid] = grp;
         }
         __syncthreads();
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(make_double2(s_bcast[4 + 2 * tid], s_bcast[5 + 2 * tid])), pbuf[kb], wg * 32 + tid * 16, 0, 16);
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(make_double2(s_bcast[4 + 2 * tid], s_bcast[5 + 2 * tid])), pbuf, wg * 32 + tid * 16, p_so, 0);
+        SOLVE_STAMP(4)
         if (lead) {
-            pre = minres_pre(s);  // the slot-only half of step k + 1, while the other groups arrive
+            bool ok = s_flag == 0;
+            if (band_leader && ok) {  // the band's sums: its groups' records, one per lane; published write-through
+                double bs[4];
+                ok = poll_band_groups(pbuf, p_so, band_first, band_size, lane, spin_limit, sc, bs);
+                if (lane < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(lane == 0 ? make_double2(bs[0], bs[1]) : make_double2(bs[2], bs[3])), bbuf, (int)my_xcc * 32 + lane * 16, b_so, 16);
+            }
+            SOLVE_STAMP(5)
+            pre = minres_pre(s);  // the slot-only half of step k + 1, while the bands arrive
             double acc[4];
-            bool ok = poll_group_records<8>(pbuf[kb], G, lane, spin_limit, sc, acc);
-            if (s_flag) ok = false;
+            if (ok) ok = poll_bands(bbuf, b_so, (G + B - 1) / B, lane, spin_limit, sc, acc);
+            SOLVE_STAMP(6)
             Slot t_ = slot_load(&s);
             if (ok) st = minres_post(t_, pre, k + 1, acc[0], acc[1], acc[2], acc[3], a.maxiter);
             slot_store(&s, t_);
@@ -448,17 +564,23 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
                 s_bcast[8] = st.oldeps; s_bcast[9] = st.delta; s_bcast[10] = st.denom; s_bcast[11] = st.phi;
                 s_claim = (st.rotate ? 1 : 0) | (st.stop ? 2 : 0);
             }
+            SOLVE_STAMP(7)
         }
         __syncthreads();
+        SOLVE_STAMP(8)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the poll
-        if (s_flag) { failed = true; ++k; break; }
+        if (__builtin_amdgcn_readfirstlane(s_flag)) { failed = true; ++k; break; }
         st.ca = s_bcast[0]; st.cb = s_bcast[1]; st.cc = s_bcast[2]; st.sj = s_bcast[3];
         st.oldeps = s_bcast[8]; st.delta = s_bcast[9]; st.denom = s_bcast[10]; st.phi = s_bcast[11];
-        st.rotate = (s_claim & 1) != 0; st.stop = (s_claim & 2) != 0;
+        {
+            const int ctl_ = __builtin_amdgcn_readfirstlane(s_claim);
+            st.rotate = (ctl_ & 1) != 0;
+            st.stop = (ctl_ & 2) != 0;
+        }
     }
     if (writer) {
         if (failed) { s.done = 1; s.istop = 6; s.itn = k; }
-        slot_store(&a.slots[(size_t)chain * NSLOT], s);
+        slot_store(&a.slots[chain64 * NSLOT], s);
         sc.minres_itn_last = s.itn;
         sc.krylov_total += (unsigned long long)s.itn;
         sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
@@ -467,6 +589,7 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
     }
 
     // ---- phase C: sum-to-zero projection, eta, partial sums of beta's system --------------------------------------
+    PHASE_STAMP(STAMP_STEPS - 1, 0)
     if (failed) {
         if (writer) chain_fail(sc);
         return;  // (the host re-runs the call on the launch-per-step path and re-establishes the canaries before coming back)
@@ -475,7 +598,7 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
         // projection partials per tile (block_partials<2>), one TAGGED record per tile: {sum x, tag | sum z, tag}
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const double2 x = st_vec(t, TV_X);
+            const double2 x = xr[t];
             const double r0 = wave_sum(act[t] ? x.x : 0.0), r1 = wave_sum(act[t] ? x.y : 0.0);
             if (lane == 0) { s_part[t][wave][0] = r0; s_part[t][wave][1] = r1; }
         }
@@ -501,17 +624,16 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
         __syncthreads();
         if (s_flag) return;
         proj_a = s_bcast[0];
+        PHASE_STAMP(STAMP_STEPS - 1, 1)
         // every workgroup of the chain has stored its projection record, i.e. has left the solve: nobody polls the
         // step buffers any more -- the invariant between launches (k_tiles_reset) is restored here
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf[1], wg * 32 + tid * 16, 0, 16);
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_stride, 0);
+        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_stride, 16);
         const int P = ia.p;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = (wg * T + t) * TILE + tid;
-            const int myoff = act[t] ? i * 16 : n * 16;
-            if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), ebuf[1], myoff, 0, 16);
-            else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), ebuf[1], myoff, 0, 0);
-            const double2 x = st_vec(t, TV_X);
+            const double2 x = xr[t];
             double eta = 0.0;
             if (act[t]) {
                 eta = eta_project(x, proj_a);
@@ -520,16 +642,18 @@ __global__ void __launch_bounds__(TILE, T == 1 ? 4 : 3) k_tiles(const IterArgs i
             }
             // the site's terms of beta's system (beta_site_terms), block partials per tile (block_partials<nacc(P)>)
             int nq = 0;
-            OCC_SWITCH_DIM(P, { nq = nacc(D); tile_beta_terms<D>(ia.Xt, n, i, act[t], om[t], eta, zv[t], s_part[t][wave], lane); });
+            double *bpart = reinterpret_cast<double *>(s_state) + (size_t)t * 4 * NACC_MAX;  // [4 waves][NACC_MAX]: the solve's vectors are dead
+            OCC_SWITCH_DIM(P, { nq = nacc(D); tile_beta_terms<D>(ia.Xt, n, i, act[t], om[t], eta, zv[t], bpart + wave * NACC_MAX, lane); });
             __syncthreads();
             if (tid < nq && wg * T + t < nt) {
                 double tv = 0.0;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) tv += s_part[t][w][tid];
-                ia.part_beta[((size_t)chain * nq + tid) * nt + (wg * T + t)] = tv;
+                for (int w = 0; w < 4; ++w) tv += bpart[w * NACC_MAX + tid];
+                ia.part_beta[(chain64 * nq + tid) * nt + (wg * T + t)] = tv;
             }
         }
     }
+    PHASE_STAMP(STAMP_STEPS - 1, 2)
     if (writer) {
         Ctl m = ctl;
         m.koff = 0u;
