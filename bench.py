@@ -372,7 +372,7 @@ def main():
             # constant-rate device wall clock), and its MINRES iterations are counted on the device
             d_solves = max(1, stats['solves'] - stats_warm['solves'])
             steps = (stats['krylov_total'] - stats_warm['krylov_total']) / d_solves + 3.0
-            kname = 'k_iter'
+            kname = 'k_tiles' if stats['persistent_solve'] == 3 else 'k_iter'   # (k_tiles: the tile-looping form for large lattices, occ_tiles.hpp)
             ka = {'avg_us': stats['iter_kernel_mean_us'], 'launches': stats['iter_kernel_launches']}
             bytes_launch = iter_bytes_per_launch(prob, C, sell, steps)
             per_iter = {'iter': 1, 'z_ob': 1}
@@ -454,7 +454,8 @@ def main():
                 'communicator': comm_note, 'problem_transport': transport,
                 'krylov_iterations_mean': round(stats['krylov_mean'], 2),
                 'krylov_cap': stats['krylov_cap'], 'stalls': stats['stalls'],
-                'fused_iteration_kernel': bool(stats['persistent_solve']), 'main_stream_cus': stats['main_stream_cus'],
+                'fused_iteration_kernel': bool(stats['persistent_solve']), 'solve_form': {0: 'one launch per MINRES step', 1: 'k_iter, any placement', 2: 'k_iter, one XCD per chain', 3: 'k_tiles'}[stats['persistent_solve']],
+                'solve_workgroups_per_chain': stats['solve_workgroups'], 'main_stream_cus': stats['main_stream_cus'],
                 'fused_fallbacks': stats['fused_fallbacks'],
                 'threads_per_block': stats['threads_per_block'],
                 'device_ms_last_run': round(stats['last_run_ms'], 3),

@@ -375,21 +375,26 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
-            hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
+            if (s->rsr.m > RSR_MAX_DIM && !std::getenv("OCC_NO_GRAM32")) {  // large bases: 32 x 32 blocks of G, then the K'u workgroups alone
+                hipLaunchKernelGGL(k_rsr_gram32, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
+                hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)((s->rsr.m + 15) / 16), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, (s->launch_sync ? 1 : 0) | 2);
+            } else {
+                hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
+            }
             break;
         case K_RSR_SOLVE:
             if (s->rsr.m <= RSR_MAX_DIM) {
                 hipLaunchKernelGGL(pick_rsr_solve(s->rsr.m), dim3(1, (unsigned)c.C), dim3(256), sizeof(double) * rsr_solve_lds_doubles(s->rsr.m), st, s->rsr, e);
             } else {  // the m x m system in global memory, factorised panel by panel (occ_rsr.hpp, k_rsrb_*)
                 const int m = s->rsr.m;
-                hipLaunchKernelGGL(k_rsrb_tau, dim3(1, (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
+                hipLaunchKernelGGL(k_rsrb_tau, dim3((unsigned)((m + RSRB_QROWS - 1) / RSRB_QROWS), (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
                 hipLaunchKernelGGL(k_rsrb_assemble, dim3((unsigned)m, (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
                 for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
                     const int kb = std::min(RSR_PANEL, m - k0), cols = m - k0 - kb;
-                    hipLaunchKernelGGL(k_rsrb_panel, dim3((unsigned)std::max(1, (cols + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
-                    if (cols > 0) {
-                        const unsigned tt = (unsigned)((cols + 15) / 16);
-                        hipLaunchKernelGGL(k_rsrb_update, dim3(tt, tt, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
+                    hipLaunchKernelGGL(k_rsrb_panel, dim3((unsigned)std::max(1, (cols + 255) / 256) + 1u, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
+                    if (cols > 0) {  // 2 x 2 tiles of 16 x 16 per workgroup; one more workgroup row for the right-hand side
+                        const unsigned tt = (unsigned)((cols + 31) / 32);
+                        hipLaunchKernelGGL(k_rsrb_update, dim3(tt, tt + 1, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
                     }
                 }
                 hipLaunchKernelGGL(k_rsrb_solve, dim3(1, (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
@@ -1317,7 +1322,10 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 if ((long long)C * g <= (long long)tiles_wg_per_cu(t) * main_t && g <= 512) T = t;
             }
             if (ft && std::atoi(ft) >= 1 && std::atoi(ft) <= 4) T = std::atoi(ft);
-            const bool big = n > XL_MAX_WG * ITER_WG_XL && (long long)nbg * C > 2LL * prop.multiProcessorCount;
+            // (beyond 64 workgroups of 512 sites per chain k_iter only has its any-placement form, every exchange a round trip to
+            // the memory side: 250x250 x 1 chain 186 us per iteration against 123 with tiles, x 2 chains 322 / 161, 350x350
+            // 299 / 152; at 150x150 x 2 chains k_iter still wins, 117 / 136)
+            const bool big = n > XL_MAX_WG * ITER_WG_XL && ((long long)nbg * C > 2LL * prop.multiProcessorCount || (long long)n * C >= 50000);
             s->tiles_layout = fused_shape && wmax <= 8 && T > 0 && !std::getenv("OCC_NO_TILES") && (big || ft != nullptr);
             if (s->tiles_layout) {
                 s->tiles_T = T;
@@ -1657,7 +1665,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
             for (int a = 0; a < m; ++a) Kth[(size_t)a * n + i] = Kh[(size_t)i * m + a];
         RsrArgs &r = s->rsr;
         r.n = n; r.m = m; r.p = p; r.C = C;
-        r.ldk = 16 * ((m + 15) / 16);
+        r.ldk = m > RSR_MAX_DIM ? 32 * ((m + 31) / 32) : 16 * ((m + 15) / 16);  // (large bases: k_rsr_gram32 reads 32 columns per block)
         std::vector<double> Kp((size_t)n * r.ldk, 0.0);  // rows padded to whole 128-byte lines
         for (int i = 0; i < n; ++i) std::copy(Kh.begin() + (size_t)i * m, Kh.begin() + (size_t)(i + 1) * m, Kp.begin() + (size_t)i * r.ldk);
         if ((rc = upload(s, &r.K, Kp, "rsr_K"))) return rc;
@@ -1678,14 +1686,16 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         r.scs = c.sc;
         r.sync = c.sync;
         s->rsr_K_host = Kh;
-        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr; r.big_dfac = nullptr;
+        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr; r.big_dfac = nullptr; r.big_quad = nullptr;
         if (m <= RSR_MAX_DIM) {
             HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
         } else {  // the global-memory solve (k_rsrb_*)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
             if ((rc = upload(s, &r.E, Eh, "rsr_E"))) return rc;
             if ((rc = dev_alloc(s, &r.big_eps, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_scal, (size_t)C * 2))) return rc;
+            if ((rc = dev_alloc(s, &r.big_quad, (size_t)C * ((m + RSRB_QROWS - 1) / RSRB_QROWS)))) return rc;
             if ((rc = dev_alloc(s, &r.big_rhs, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_dfac, (size_t)C * ((m + RSR_PANEL - 1) / RSR_PANEL) * RSR_PANEL * RSR_PANEL))) return rc;
         }

@@ -43,7 +43,8 @@ struct RsrArgs {
     // m > RSR_MAX_DIM only (k_rsrb_*): E row-major, the noise of the prior term, {tau, sqrt(tau)}, the finished right-hand side
     const double *E;    // [m][m]
     double *big_eps;    // [C][m]
-    double *big_scal;   // [C][2]
+    double *big_scal;   // [C][2] (unused since round 3)
+    double *big_quad;   // [C][ceil(m / 64)] theta' Qr theta by slices of 64 rows (k_rsrb_tau -> k_rsrb_assemble)
     double *big_rhs;    // [C][m]
     double *big_dfac;   // [C][ceil(m / RSR_PANEL)][RSR_PANEL][RSR_PANEL] the factored diagonal blocks (k_rsrb_panel -> k_rsrb_solve)
     double tau_rate, tau_shape;
@@ -93,8 +94,11 @@ __device__ __forceinline__ void rsr_gram_load(const RsrArgs &a, const double *om
     }
 }
 
-__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, int e, int sync_on)
+// sync_on bit 0: hand-overs by device counters; bit 1: ONLY the K'u workgroups (grid = T per chain): the Gram matrix itself
+// comes from k_rsr_gram32 (large bases)
+__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, int e, int sync_flags)
 {
+    const int sync_on = sync_flags & 1, u_only = sync_flags & 2;
     __shared__ double s_part[GRAM_WAVES - 1][64][4];  // the partial tiles of waves 1..15
     __shared__ double s_u[GRAM_UCHUNK];
     __shared__ int s_noise_ok;
@@ -102,24 +106,25 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
     // first kernel of the main stream's sequence (as k_iter in the ICAR model): k_z_ob of the previous sequence is
     // complete, the side stream may start this sequence.  Said before anything can return or wait.
     const bool synced = sync_on && a.sync != nullptr;
-    if (synced && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync_set(a.sync + SYNC_MAIN, a.sync[SYNC_MAIN_SEQ + e]);
+    if (synced && !u_only && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync_set(a.sync + SYNC_MAIN, a.sync[SYNC_MAIN_SEQ + e]);
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const int T = (a.m + 15) / 16, ntile = T * (T + 1) / 2;
+    const int bx = (int)blockIdx.x + (u_only ? ntile : 0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
     const size_t co = (size_t)chain * a.n;
     const double *om = a.omega_b[ctl.it & 1] + co;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     int ta, tc;
-    const bool utile = (int)blockIdx.x >= ntile;
+    const bool utile = bx >= ntile;
     GRAM_STAMP(0)
 #ifdef OCC_SOLVE_STAMPS
     if (chain == 0 && blockIdx.x == 0 && lane == 0) g_solve_stamps[40 + wave] = wall_clock64();
 #endif
     if (!utile) {
         ta = 0;
-        int rem = (int)blockIdx.x;  // upper triangle of tiles, enumerated row by row
+        int rem = bx;  // upper triangle of tiles, enumerated row by row
         while (rem >= T - ta) { rem -= T - ta; ++ta; }
         tc = ta + rem;
         const int ca = ta * 16 + lc, cc = tc * 16 + lc;
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
             }
         }
     } else {
-        ta = (int)blockIdx.x - ntile;
+        ta = bx - ntile;
         tc = -1;
         const int ca = ta * 16 + lc;
         const double *en = a.enorm[ctl.it & 1] + co;
@@ -208,6 +213,90 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
     }
     GRAM_STAMP(3)
 }
+
+// ---- the Gram matrix for LARGE bases (m > RSR_MAX_DIM): 32 x 32 output blocks ---------------------------------------------
+// k_rsr_gram above reads 2 x 16 columns of K per v_mfma_f64_16x16x4_f64: 2 flop per byte from the L2, exactly the ratio of a
+// CU's L2 path (64 B/clk) to its f64 matrix rate (128 flop/clk) -- at m = 1 280 it ran at 36 % of the matrix peak with the
+// miss path saturated (3 240 workgroups per chain, each pulling 2 x 1.25 MB of K).  Here a workgroup owns a 32 x 32 block
+// of G's upper triangle: per four sites a wave loads 2 x 2 x 16 columns and issues FOUR MFMAs (three on a diagonal block,
+// whose lower-left tile is the transpose of its upper-right one) -- twice the flop per byte, a quarter of the workgroups.
+// Same operands, same instruction order per output element, the 16 partial tiles of a tile added in wave order: the bits of
+// k_rsr_gram.  K's rows are padded to a multiple of 32 columns (zeros).  Dynamic LDS: [4 tiles][16 waves][64 lanes][4] doubles.
+__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram32(const RsrArgs a, int e, int sync_on)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_g32[];
+    const int chain = blockIdx.y;
+    const bool synced = sync_on && a.sync != nullptr;
+    // first kernel of the main stream's sequence: k_z_ob of the previous sequence is complete, the side stream may start
+    if (synced && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync_set(a.sync + SYNC_MAIN, a.sync[SYNC_MAIN_SEQ + e]);
+    const ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    const int T2 = (a.m + 31) / 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
+    const double *om = a.omega_b[ctl.it & 1] + (size_t)chain * a.n;
+    int ba = 0, rem = (int)blockIdx.x;  // upper triangle of 32 x 32 blocks, row by row
+    while (rem >= T2 - ba) { rem -= T2 - ba; ++ba; }
+    const int bc = ba + rem;
+    const bool diag = ba == bc;
+    const int ca = ba * 32 + lc, cc = bc * 32 + lc;
+    v4d acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    constexpr int NB = 4;  // four-site groups per batch (16 sites): two batches in flight
+    double a0[NB], a1[NB], b0[NB], b1[NB], na0[NB], na1[NB], nb0[NB], nb1[NB];
+    auto load = [&](int i0, double (&x0)[NB], double (&x1)[NB], double (&y0)[NB], double (&y1)[NB]) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int i = i0 + 4 * t + lk;
+            const bool vi = i < a.n;
+            const int ii = vi ? i : 0;
+            const double w = vi ? om[ii] : 0.0;
+            const double *row = a.K + (size_t)ii * a.ldk;
+            x0[t] = row[ca];
+            x1[t] = row[ca + 16];
+            y0[t] = row[cc] * w;
+            y1[t] = row[cc + 16] * w;
+        }
+    };
+    int i0 = wave * 16;
+    if (i0 < a.n) load(i0, a0, a1, b0, b1);
+    for (; i0 < a.n; i0 += 16 * GRAM_WAVES) {
+        const int i1 = i0 + 16 * GRAM_WAVES;
+        if (i1 < a.n) load(i1, na0, na1, nb0, nb1);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1[t], acc01, 0, 0, 0);
+            if (!diag) acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b0[t], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) { a0[t] = na0[t]; a1[t] = na1[t]; b0[t] = nb0[t]; b1[t] = nb1[t]; }
+    }
+    // the 16 partial tiles of each of the four tiles, added in wave order (wave q < 4 adds up tile q)
+    auto put = [&](int tile, const v4d &acc) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s_g32[(((size_t)tile * GRAM_WAVES + wave) * 64 + lane) * 4 + v] = acc[v];
+    };
+    put(0, acc00); put(1, acc01); put(2, acc10); put(3, acc11);
+    __syncthreads();
+    if (wave >= 4 || (diag && wave == 2)) return;
+    const int ra = ba * 32 + (wave >> 1) * 16, rc = bc * 32 + (wave & 1) * 16;  // tile `wave`: rows ra.., columns rc..
+    double *G = a.gram + (size_t)chain * a.m * a.m;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        double t = s_g32[(((size_t)wave * GRAM_WAVES + 0) * 64 + lane) * 4 + v];
+#pragma unroll
+        for (int w = 1; w < GRAM_WAVES; ++w) t += s_g32[(((size_t)wave * GRAM_WAVES + w) * 64 + lane) * 4 + v];  // fixed order
+        const int r = ra + 4 * v + lk, c = rc + lc;
+        if (r < a.m && c < a.m) G[(size_t)r * a.m + c] = t;
+    }
+}
+__host__ __device__ inline int rsr_gram32_blocks(int m)
+{
+    const int T2 = (m + 31) / 32;
+    return T2 * (T2 + 1) / 2;
+}
+constexpr size_t RSR_GRAM32_LDS = (size_t)4 * GRAM_WAVES * 64 * 4 * sizeof(double);
 
 // Row stride of the Cholesky factor in LDS: odd, so that a column walk (one row per lane) touches every bank once.
 __host__ __device__ inline int rsr_ld(int m) { return 16 * ((m + 15) / 16) + 1; }
@@ -559,22 +648,24 @@ __global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS
 // is not the small path's (the two agree to rounding, like the oracle).  Plain kernels: at m = 1 280 the conditional is
 // ~10^9 flops of Cholesky per chain and iteration beside a 2 10^10-flop Gram matrix -- milliseconds where the
 // reference's host code takes seconds -- and not the path BASELINE's metric is quoted on.
+// theta' Qr theta in slices of 64 rows (a workgroup of 16 waves, four rows per wave, columns over the lanes), one partial
+// per workgroup; the noise of the prior term for those rows.  (Round 2: one workgroup per chain read all of Qr, 13 MB at
+// m = 1 280: 0.56 ms.)
+constexpr int RSRB_QROWS = 64;
 __global__ void __launch_bounds__(1024) k_rsrb_tau(const RsrArgs a, int e)
 {
     __shared__ double s_th[RSR_BIG_MAX];
     __shared__ double s_part[16];
-    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    ChainScalars &sc = a.scs[chain];
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = (int)blockIdx.x * RSRB_QROWS;
+    const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
     const uint32_t it = ctl.it;
-    for (int t = tid; t < m; t += 1024) {
-        s_th[t] = a.theta[(size_t)chain * m + t];
-        a.big_eps[(size_t)chain * m + t] = block_normal(sc.key, (uint32_t)t, 0, it, STREAM_RSR);
-    }
+    for (int t = tid; t < m; t += 1024) s_th[t] = a.theta[(size_t)chain * m + t];
+    if (tid < RSRB_QROWS && r0 + tid < m) a.big_eps[(size_t)chain * m + r0 + tid] = block_normal(sc.key, (uint32_t)(r0 + tid), 0, it, STREAM_RSR);
     __syncthreads();
-    double part = 0.0;  // this wave's rows r = wave, wave + 16, ...: theta_r (Qr theta)_r, columns over the lanes
-    for (int r = wave; r < m; r += 16) {
+    double part = 0.0;  // this wave's rows r0 + wave, + 16, + 32, + 48: theta_r (Qr theta)_r
+    for (int r = r0 + wave; r < min(m, r0 + RSRB_QROWS); r += 16) {
         double acc = 0.0;
         for (int c = lane; c < m; c += 64) acc = fma(a.Qr[(size_t)r * m + c], s_th[c], acc);
         part = fma(s_th[r], wave_sum(acc), part);
@@ -584,22 +675,26 @@ __global__ void __launch_bounds__(1024) k_rsrb_tau(const RsrArgs a, int e)
     if (tid == 0) {
         double quad = 0.0;
         for (int w = 0; w < 16; ++w) quad += s_part[w];
-        const double rate = 0.5 * quad + a.tau_rate;
-        const double tau = (1.0 / rate) * load_agent(&sc.tau_gamma[it & 1]);  // the variate was drawn ahead by k_noise
-        sc.tau = tau;
-        a.big_scal[chain * 2] = tau;
-        a.big_scal[chain * 2 + 1] = sqrt(tau);
+        a.big_quad[(size_t)chain * gridDim.x + blockIdx.x] = quad;
     }
 }
 
+// prec = G + tau Qr (upper triangle, in place), rhs = K'u + sqrt(tau) E eps2: one workgroup per row; tau from the slices'
+// partial sums of theta' Qr theta, added in slice order by every workgroup (the same bits everywhere)
 __global__ void __launch_bounds__(256) k_rsrb_assemble(const RsrArgs a, int e)
 {
     __shared__ double s_part[4];
     const int chain = blockIdx.y, r = blockIdx.x, m = a.m, tid = threadIdx.x;
-    const ChainScalars &sc = a.scs[chain];
+    ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop) return;
-    const double tau = a.big_scal[chain * 2], st = a.big_scal[chain * 2 + 1];
+    const int nq = (m + RSRB_QROWS - 1) / RSRB_QROWS;
+    double quad = 0.0;
+    for (int b = 0; b < nq; ++b) quad += a.big_quad[(size_t)chain * nq + b];
+    const double rate = 0.5 * quad + a.tau_rate;
+    const double tau = (1.0 / rate) * load_agent(&sc.tau_gamma[ctl.it & 1]);  // the variate was drawn ahead by k_noise
+    const double st = sqrt(tau);
+    if (r == 0 && tid == 0) sc.tau = tau;
     double *P = a.gram + (size_t)chain * m * m;
     for (int c = r + tid; c < m; c += 256) P[(size_t)r * m + c] = fma(tau, a.Qr[(size_t)r * m + c], P[(size_t)r * m + c]);
     double es = 0.0;
@@ -614,6 +709,33 @@ __global__ void __launch_bounds__(256) k_rsrb_assemble(const RsrArgs a, int e)
     }
 }
 
+// Upper Cholesky factor of one RSR_PANEL x RSR_PANEL block by ONE WAVE, the block in registers: lane c < kb owns column c
+// (u[r] = entry (r, c)).  Row i: the pivot comes by v_readlane from lane i, the row is divided by its root, and every later
+// row r takes its update with U_ir read from lane r -- no LDS, no barrier (round 2: the block in LDS, three workgroup
+// barriers per row, every workgroup of the launch for itself: 30 of the panel kernel's 38 us).  The operations are those of
+// the row-by-row loop it replaces (sqrt, division, fma in the same order): the same bits.  Returns false on a pivot <= 0.
+__device__ __forceinline__ bool rsrb_diag_factor(double (&u)[RSR_PANEL], int kb, int lane)
+{
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < RSR_PANEL; ++i) {
+        const double piv = readlane_f64(u[i], i);
+        if (i < kb && !(piv > 0.0)) ok = false;
+        const double d = sqrt(piv);
+        u[i] = (lane == i) ? d : ((lane > i) ? u[i] / d : u[i]);
+#pragma unroll
+        for (int r = i + 1; r < RSR_PANEL; ++r) {
+            const double uir = readlane_f64(u[i], r);  // U_ir (lane r's entry of row i)
+            if (lane >= r) u[r] = fma(-uir, u[i], u[r]);
+        }
+    }
+    return ok;
+}
+
+// Panel step k0: the diagonal block's factor (wave 0 of every workgroup, for itself: 5 us, cheaper than a launch of its
+// own), then U_kk' X = P_k,rest for this workgroup's 256 columns of the block row, one column per thread.  The last
+// workgroup of the grid takes the right-hand side along -- U_kk' y_k = rhs_k: the forward substitution is finished with
+// the factor, as in the small path; workgroup 0 stores the factored block (big_dfac: see below).
 __global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int k0)
 {
     __shared__ double D[RSR_PANEL][RSR_PANEL + 1];
@@ -624,46 +746,44 @@ __global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int 
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const int kb = min(RSR_PANEL, m - k0);
     double *P = a.gram + (size_t)chain * m * m;
-    for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
-        const int i = t / RSR_PANEL, j = t % RSR_PANEL;
-        D[i][j] = (i < kb && j < kb && j >= i) ? P[(size_t)(k0 + i) * m + k0 + j] : 0.0;
+    if (tid < 64) {
+        double u[RSR_PANEL];
+#pragma unroll
+        for (int r = 0; r < RSR_PANEL; ++r) {
+            const bool in = tid < kb && r < kb && tid >= r;
+            const double v = P[(size_t)(k0 + (in ? r : 0)) * m + k0 + (in ? tid : 0)];
+            u[r] = in ? v : ((r == tid) ? 1.0 : 0.0);  // (identity outside the block: nothing divides by zero)
+        }
+        const bool ok = rsrb_diag_factor(u, kb, tid);
+        if (tid == 0) s_bad = ok ? 0 : 1;
+        if (tid < RSR_PANEL) {
+#pragma unroll
+            for (int r = 0; r < RSR_PANEL; ++r) D[r][tid] = (r <= tid && tid < kb && r < kb) ? u[r] : 0.0;
+        }
     }
-    if (tid == 0) s_bad = 0;
     __syncthreads();
-    for (int i = 0; i < kb; ++i) {  // upper Cholesky of the diagonal block, row by row
-        if (tid == 0) {
-            const double piv = D[i][i];
-            if (!(piv > 0.0)) s_bad = 1;
-            D[i][i] = sqrt(piv);
-        }
-        __syncthreads();
-        const double d = D[i][i];
-        if (tid > i && tid < kb) D[i][tid] = D[i][tid] / d;
-        __syncthreads();
-        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) {
-            const int r = t / RSR_PANEL, c = t % RSR_PANEL;
-            if (r > i && c >= r && c < kb) D[r][c] = fma(-D[i][r], D[i][c], D[r][c]);
-        }
-        __syncthreads();
-    }
     if (s_bad) {
         if (blockIdx.x == 0 && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
         return;
     }
     // The factored diagonal block goes to a buffer of its own, NOT back into P: every workgroup of this launch loads the
-    // unfactored block from P above, and nothing orders those loads before a write-back by workgroup 0 -- a workgroup that
-    // starts late would factor an already factored (or half-written) block and solve its block row with the wrong U_kk
-    // (ADVICE r2).  P's diagonal block is never read again; k_rsrb_solve takes the factor from big_dfac.
+    // unfactored block from P above, and nothing orders those loads before a write-back by workgroup 0.  P's
+    // diagonal block is never read again; k_rsrb_solve takes the factor from big_dfac.
     if (blockIdx.x == 0) {
         double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
         for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) F[t] = D[t / RSR_PANEL][t % RSR_PANEL];
     }
-    // the block row right of the diagonal block: U_kk' x = p, one column per thread
-    const int j = k0 + kb + (int)blockIdx.x * 256 + tid;
-    if (j < m) {
+    // the block row right of the diagonal block: U_kk' x = p, one column per thread; the last thread of workgroup 0: the
+    // right-hand side's entries of this panel
+    // (the LAST workgroup of the grid is the right-hand side's: its thread 0)
+    const bool rhs_wg = blockIdx.x == gridDim.x - 1;
+    const int j = rhs_wg ? m : k0 + kb + (int)blockIdx.x * 256 + tid;
+    const bool is_rhs = rhs_wg && tid == 0;
+    double *rhs = a.big_rhs + (size_t)chain * m;
+    if (j < m || is_rhs) {
         double x[RSR_PANEL];
 #pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb) ? P[(size_t)(k0 + t) * m + j] : 0.0;
+        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb) ? (is_rhs ? rhs[k0 + t] : P[(size_t)(k0 + t) * m + j]) : 0.0;
 #pragma unroll
         for (int t = 0; t < RSR_PANEL; ++t) {
             if (t < kb) {
@@ -676,26 +796,68 @@ __global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int 
         }
 #pragma unroll
         for (int t = 0; t < RSR_PANEL; ++t)
-            if (t < kb) P[(size_t)(k0 + t) * m + j] = x[t];
+            if (t < kb) {
+                if (is_rhs) rhs[k0 + t] = x[t];
+                else P[(size_t)(k0 + t) * m + j] = x[t];
+            }
     }
 }
 
+// Trailing update of panel step k0 on the matrix cores: P_ij -= sum_t U_ti U_tj over the panel's rows t, one WAVE per
+// 16 x 16 tile of the trailing upper triangle (four tiles per workgroup): v_mfma_f64_16x16x4_f64 with A = -U[:, i-block]'
+// and B = U[:, j-block], four panel rows per instruction, the tile as the accumulator (lane l: rows 4 v + l / 16, column
+// l % 16; operands: 4 x 128-byte row segments per load).  (Round 2: one thread per entry, 64 scalar loads and 32 FMAs:
+// 10-134 us per launch, 2.1 ms per iteration at m = 1 280.)  The last workgroup row of the grid updates the right-hand
+// side: rhs_j -= sum_t U_tj y_t.
 __global__ void __launch_bounds__(256) k_rsrb_update(const RsrArgs a, int e, int k0)
 {
-    const int chain = blockIdx.z, m = a.m, ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int chain = blockIdx.z, m = a.m, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    if (blockIdx.x < blockIdx.y) return;  // upper triangle of tiles: tile column >= tile row
     const int kb = min(RSR_PANEL, m - k0), base = k0 + kb;
-    const int i = base + 16 * (int)blockIdx.y + ty, j = base + 16 * (int)blockIdx.x + tx;
-    if (i >= m || j >= m || j < i) return;
     double *P = a.gram + (size_t)chain * m * m;
-    double acc = P[(size_t)i * m + j];
-    for (int t = 0; t < kb; ++t) acc = fma(-P[(size_t)(k0 + t) * m + i], P[(size_t)(k0 + t) * m + j], acc);
-    P[(size_t)i * m + j] = acc;
+    if (blockIdx.y == gridDim.y - 1) {  // the right-hand side: one thread per trailing entry
+        double *rhs = a.big_rhs + (size_t)chain * m;
+        const int j = base + (int)blockIdx.x * 256 + (int)threadIdx.x;
+        if (j < m) {
+            double v = rhs[j];
+            for (int t = 0; t < kb; ++t) v = fma(-P[(size_t)(k0 + t) * m + j], rhs[k0 + t], v);
+            rhs[j] = v;
+        }
+        return;
+    }
+    // tile (ti, tj) of the trailing block, ti <= tj: workgroup (bx, by) holds tiles (2 by + wave / 2, 2 bx + wave % 2)
+    const int ti = 2 * (int)blockIdx.y + (wave >> 1), tj = 2 * (int)blockIdx.x + (wave & 1);
+    const int i0 = base + 16 * ti, j0 = base + 16 * tj;
+    if (tj < ti || i0 >= m || j0 >= m) return;
+    v4d acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = i0 + 4 * v + lk, c = j0 + lc;
+        acc[v] = (r < m && c < m) ? P[(size_t)r * m + c] : 0.0;
+    }
+    double av[RSR_PANEL / 4], bv[RSR_PANEL / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) {
+        const int t = 4 * s4 + lk;
+        const bool in = t < kb;
+        const double *row = P + (size_t)(k0 + (in ? t : 0)) * m;
+        const double ua = (in && i0 + lc < m) ? row[min(i0 + lc, m - 1)] : 0.0, ub = (in && j0 + lc < m) ? row[min(j0 + lc, m - 1)] : 0.0;
+        av[s4] = -ua;
+        bv[s4] = ub;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = i0 + 4 * v + lk, c = j0 + lc;
+        if (r < m && c < m && c >= r) P[(size_t)r * m + c] = acc[v];
+    }
 }
 
+// U theta = y (backward), blocked by panels, one workgroup per chain; y = the right-hand side as the panel steps left it
+// (the forward substitution travels with the factorisation).
 __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
 {
     __shared__ double y[RSR_BIG_MAX];
@@ -707,28 +869,6 @@ __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
     const double *F = a.big_dfac + (size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);  // the diagonal blocks' factors
     for (int t = tid; t < m; t += 1024) y[t] = a.big_rhs[(size_t)chain * m + t];
     __syncthreads();
-    // U'y = rhs, forward: the panel's own rows by one wave (lane t owns entry k0 + t), then everything right of it
-    for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
-        const int kb = min(RSR_PANEL, m - k0);
-        if (tid < 64) {
-            double v = (tid < kb) ? y[k0 + tid] : 0.0;
-            for (int s2 = 0; s2 < kb; ++s2) {
-                const double us = (tid >= s2 && tid < kb) ? F[(size_t)(k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL) + s2 * RSR_PANEL + tid] : 1.0;  // row s2 of the block
-                const double ys = readlane_f64(v, s2) / readlane_f64(us, s2);
-                if (tid == s2) v = ys;
-                else if (tid > s2 && tid < kb) v = fma(-us, ys, v);
-            }
-            if (tid < kb) y[k0 + tid] = v;
-        }
-        __syncthreads();
-        for (int j = k0 + kb + tid; j < m; j += 1024) {
-            double v = y[j];
-            for (int s2 = 0; s2 < kb; ++s2) v = fma(-U[(size_t)(k0 + s2) * m + j], y[k0 + s2], v);
-            y[j] = v;
-        }
-        __syncthreads();
-    }
-    // U theta = y, backward: the last panel first
     const int last = ((m - 1) / RSR_PANEL) * RSR_PANEL;
     for (int k0 = last; k0 >= 0; k0 -= RSR_PANEL) {
         const int kb = min(RSR_PANEL, m - k0);

@@ -204,14 +204,15 @@ def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, latti
 
 
 @pytest.mark.parametrize('lattice, chains, tiles, iters', [((250, 250), 1, '1', 30), ((250, 250), 1, '2', 30), ((130, 170), 3, '2', 24),
-                                                           ((61, 67), 2, '1', 24), ((500, 500), 1, None, 12)])
+                                                           ((61, 67), 2, '1', 24), ((180, 200), 2, '4', 20), ((90, 110), 1, '3', 20),
+                                                           ((250, 250), 1, None, 20), ((500, 500), 1, None, 12)])
 def test_tile_looping_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, tiles, iters):
     """k_tiles (occ_tiles.hpp, BASELINE config 4's path): tiles of 256 sites with their vectors in LDS, one or two tiles per
     workgroup, p exchanged through a canary-polled buffer (plain stores inside an XCD's band, write-through at the band
     edges), one record per workgroup and step.  A stale, torn or early-read value anywhere would change the bits of eta.
     Against the launch-per-step kernels in the same layout (256-thread blocks, sums grouped by T): every record, eta, xz,
-    z and every solve's iteration count agree exactly -- forced on mid-size lattices (one and two tiles, several chains, a
-    ragged last tile), and at 500x500 where it is what the engine takes by itself."""
+    z and every solve's iteration count agree exactly -- forced on mid-size lattices (one to four tiles per workgroup, several
+    chains, a ragged last tile), and at 250x250 and 500x500 where it is what the engine takes by itself."""
     from occuspytial_amd._engine import Engine
     from occuspytial_amd._problem import FlatProblem
     from occuspytial_amd.utils import make_lattice_problem

@@ -9,7 +9,8 @@ import sys
 import numpy as np
 
 path, warmup, steps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-rows = [r for r in csv.DictReader(open(path)) if 'k_iter' in r['Kernel_Name']]
+kern = sys.argv[5] if len(sys.argv) > 5 else 'k_iter'
+rows = [r for r in csv.DictReader(open(path)) if ('occ::' + kern + '<') in r['Kernel_Name']]
 d = np.array([int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]) / 1e3
 probes = int(np.sum(d[:12] < 10.0))                       # the residency probes return within microseconds
 lo, hi = probes + warmup, probes + warmup + steps
