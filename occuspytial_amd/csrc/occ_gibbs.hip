@@ -152,6 +152,15 @@ struct occ_sampler {
     bool demoted = false;             // running without device-side waits after one of them gave up
     int promote_wait = 0, promote_backoff = 1;  // calls until the next attempt to come back; doubled after a failed one
     std::string pair_note;            // why the engine did not get the masked pair it wanted (empty: it did, or wanted none)
+    // A call of a dozen iterations is mostly host round trips and small stream operations around the kernels (round 2: ~170 us
+    // per occ_run beyond its iterations, 12 % of the driver's 20-step bench call).  Round 3: the chains' scalars as the last
+    // successful occ_run read them stay on the host (sc_host; dropped by anything else that touches the device state), so the
+    // next call neither waits for the device nor reads; counters are re-zeroed only after a call that did not end cleanly;
+    // the records and the final scalars come back behind ONE synchronisation.
+    std::vector<ChainScalars> sc_host;
+    bool sc_host_valid = false, clean_exit = false;
+    std::vector<double> rec_host;  // the recorded rows of the running call
+    bool marks_done = false;       // ev1 and the copy of the records are enqueued behind the call's last batch
     std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
     bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
     int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
@@ -422,11 +431,13 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                         const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
                         if (s->xl_wide == 1) hipExtLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         else if (s->xl_wide == 2) hipExtLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
+                        else if (s->iter_window == 16) hipExtLaunchKernelGGL((k_iter<16, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         else hipExtLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         continue;
                     }
                     if (s->xl_wide == 1) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else if (s->xl_wide == 2) hipLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    else if (s->iter_window == 16) hipLaunchKernelGGL((k_iter<16, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                 }
             }
@@ -487,6 +498,7 @@ int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
 }
 int write_scalars(occ_sampler *s, const std::vector<ChainScalars> &h)
 {
+    s->sc_host_valid = false;  // (whoever writes them has changed what the host's copy stood for)
     HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return OCC_OK;
@@ -777,10 +789,13 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
     if (s->snap_fresh) {
         h = s->snap_sc;
         s->snap_fresh = false;
+    } else if (s->sc_host_valid) {  // (what the last call read at its end)
+        h = s->sc_host;
     } else {
         int rc = read_scalars(s, h);
         if (rc) return rc;
     }
+    s->sc_host_valid = false;
     for (auto &sc : h) {
         Ctl &ctl = sc.ctl[s->parity];
         sc.it_base = ctl.it;
@@ -791,8 +806,11 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
     }
     // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
     // error may have left them anywhere)
-    if (s->ctx.claim) HIP_TRY(hipMemsetAsync(s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16, s->stream));
-    if (s->ctx.sync) HIP_TRY(hipMemsetAsync(s->ctx.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
+    if (!s->clean_exit) {  // (the last call through here did not end cleanly, or there was none)
+        if (s->ctx.claim) HIP_TRY(hipMemsetAsync(s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16, s->stream));
+        if (s->ctx.sync) HIP_TRY(hipMemsetAsync(s->ctx.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
+    }
+    s->clean_exit = false;  // until the call says otherwise
     HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
     return OCC_OK;
 }
@@ -1350,7 +1368,10 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
             const int base = (ncu * 5 / 64) * 8;  // 160 of 256
             // (more than eight chains: launches of eight, one behind the other -- 16 chains at 100x100 then run 2 x 60 us where
             // the launch-per-step path took 374)
-            const bool xl_ok = fused_ok && s->iter_window == 8 && C <= 8 * XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
+            // (rows of 9-16 off-diagonals -- the irregular graph of BASELINE config 5 -- take the one-XCD form too, in its
+            // 256-thread, one-workgroup-per-CU shape (round 3): every step's exchange through one L2 instead of the memory side)
+            const bool xl_any = fused_ok && C <= 8 * XL_SLOTS && !std::getenv("OCC_NO_XCD_LOCAL");
+            const bool xl_ok = xl_any && s->iter_window == 8;
             auto part = [&](int per_xcd) { return std::max(32 * ((per_xcd + 3) / 4), base); };
             s->xl_candidate = false;
             for (int x = 0; x < XL_SLOTS; ++x) s->xl_per_xcd[x] = 0;
@@ -1366,7 +1387,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                 }
                 for (int x = 0; x < XL_SLOTS; ++x) { wide_xcd[x] = x < hot ? need : rest; wide_main += wide_xcd[x]; }
             }
-            if (xl_ok && nbg <= base / XL_SLOTS) {
+            if (xl_any && nbg <= base / XL_SLOTS) {
                 s->xl_candidate = true; s->xl_wide = 0; s->xl_nbg = nbg; s->xl_per_cu = 1; s->xl_main = base;
             } else if (xl_ok && nbg512 <= 64 && wide_main > 0 && wide_main <= ncu - 96 && hot <= 5 && !std::getenv("OCC_NO_SCALAR_WAVE")) {
                 // (the scalar wave's seventh of the sites costs CUs: taken while the side stream keeps its 96 and most of them on
@@ -2222,7 +2243,24 @@ static int step_impl(occ_sampler *s)
     if ((rc = read_scalars(s, h))) return rc;
     s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
-    return check_device_errors(s, h);
+    if ((rc = check_device_errors(s, h))) return rc;
+    s->sc_host = h;
+    s->sc_host_valid = true;
+    s->clean_exit = true;
+    return OCC_OK;
+}
+
+// Behind the batch that is expected to finish the call: the end-of-run event and the copy of the recorded rows, so that the
+// one synchronisation of the scalars' read covers them (a batch that turns out NOT to be the last -- a carried solve on the
+// launch-per-step path -- simply gets them again behind the next one).
+static int finish_marks(occ_sampler *s, bool last, size_t n_rec)
+{
+    if (!last) return OCC_OK;
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    s->rec_host.resize(n_rec);
+    if (n_rec) HIP_TRY(hipMemcpyAsync(s->rec_host.data(), s->rec_buf, sizeof(double) * n_rec, hipMemcpyDeviceToHost, s->stream));
+    s->marks_done = true;
+    return OCC_OK;
 }
 
 static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
@@ -2253,6 +2291,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     }
     std::vector<ChainScalars> h;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    s->marks_done = false;
 
     // calibration (no graph yet): a few eager sequences measure the Krylov launches a solve needs;
     // the count of the last, warm-started solve sizes the captured graph
@@ -2307,6 +2346,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
             if ((rc = enqueue_sequence(s))) return rc;
         const auto hl1 = std::chrono::steady_clock::now();
         s->graph_launches += batch;
+        if ((rc = finish_marks(s, done_min + batch >= n_iter, (size_t)C * keep * rw))) return rc;
         if ((rc = read_scalars(s, h))) return rc;
         if (std::getenv("OCC_VERBOSE")) {
             const auto hl2 = std::chrono::steady_clock::now();
@@ -2338,18 +2378,22 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
             if ((want > s->krylov_cap || want < s->krylov_cap - 1) && (rc = build_graph(s, want))) return rc;
         }
     }
-    HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (!s->marks_done) {  // (every iteration was stepped eagerly: nothing was enqueued above)
+        if ((rc = finish_marks(s, true, (size_t)C * keep * rw))) return rc;
+        if ((rc = read_scalars(s, h))) return rc;
+        if ((rc = check_device_errors(s, h))) return rc;
+    }
+    // (ev1 and the records were enqueued behind the last batch; the read of the scalars that followed waited for both)
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     s->last_run_ms = ms;
-    if ((rc = read_scalars(s, h))) return rc;
-    if ((rc = check_device_errors(s, h))) return rc;
     s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
+    s->sc_host = h;  // the chains' scalars as this call leaves them: the next call does not ask the device again
+    s->sc_host_valid = true;
+    s->clean_exit = true;
 
-    std::vector<double> host((size_t)C * keep * rw);
-    HIP_TRY(copy_on(s, host.data(), s->rec_buf, sizeof(double) * host.size(), hipMemcpyDeviceToHost));
+    const std::vector<double> &host = s->rec_host;
     for (int ch = 0; ch < C; ++ch)
         for (int64_t t = 0; t < keep; ++t) {
             const double *row = host.data() + ((size_t)ch * keep + t) * rw;
@@ -2380,13 +2424,15 @@ static int snapshot_take(occ_sampler *s)
         if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
         if (s->rsr.m > 0 && (rc = dev_alloc(s, &s->snap_theta, (size_t)c.C * s->rsr.m, false))) return rc;
     }
-    if ((rc = read_scalars(s, s->snap_sc))) return rc;
+    if (s->sc_host_valid) s->snap_sc = s->sc_host;  // (what the last occ_run read at its end; nothing has touched the device since)
+    else if ((rc = read_scalars(s, s->snap_sc))) return rc;
+    s->sc_host_valid = false;
     s->snap_fresh = true;  // set_window, next, takes these
     s->snap_parity = s->parity;
-    HIP_TRY(hipMemcpyAsync(s->snap_eta, c.eta, sizeof(double) * Cn, hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->snap_z, c.z, Cn, hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->snap_x, c.Xv, sizeof(double2) * Cn, hipMemcpyDeviceToDevice, s->stream));
-    if (s->rsr.m > 0) HIP_TRY(hipMemcpyAsync(s->snap_theta, s->rsr.theta, sizeof(double) * (size_t)c.C * s->rsr.m, hipMemcpyDeviceToDevice, s->stream));
+    // one launch for the three copies (three stream copies: three launch gaps in front of the call's first kernel)
+    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)std::min<size_t>((Cn + 255) / 256, 2048)), dim3(256), 0, s->stream, c.eta, s->snap_eta, c.z, s->snap_z, c.Xv, s->snap_x,
+                       (unsigned long long)Cn, s->rsr.m > 0 ? s->rsr.theta : nullptr, s->snap_theta, (unsigned long long)c.C * (unsigned long long)std::max(s->rsr.m, 0));
+    if (hipGetLastError() != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_snapshot failed");
     return OCC_OK;
 }
 
@@ -2770,6 +2816,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     if (!s || reps < 1 || !counts || !total_us) return OCC_E_BADARG;
     DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
+    s->sc_host_valid = false;
     int rc = set_window(s, 1 << 30, 0, 0);  // no chain reaches its stop during the timing loops
     if (rc) return rc;
     // The fused iteration kernel first, IN SITU: `reps` real iterations continue the chains from where they are

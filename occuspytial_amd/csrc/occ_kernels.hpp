@@ -737,6 +737,20 @@ __global__ void __launch_bounds__(256) k_checksum(const unsigned char *__restric
     atomicAdd(out, acc);
 }
 
+// The state a call is re-run from after a device-side wait gave up (occ_gibbs.hip, snapshot_take): eta, z, the warm start
+// (and theta of the reduced-rank model) of every chain, in ONE launch.
+__global__ void __launch_bounds__(256) k_snapshot(const double *__restrict__ eta, double *__restrict__ s_eta, const uint8_t *__restrict__ z, uint8_t *__restrict__ s_z,
+                                                  const double2 *__restrict__ x, double2 *__restrict__ s_x, unsigned long long count,
+                                                  const double *__restrict__ theta, double *__restrict__ s_theta, unsigned long long count_theta)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        s_eta[i] = eta[i];
+        s_z[i] = z[i];
+        s_x[i] = x[i];
+    }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count_theta; i += (unsigned long long)gridDim.x * blockDim.x) s_theta[i] = theta[i];
+}
+
 // First kernel of a side-stream sequence: one lane announces that the previous k_noise is complete, then waits
 // until the main stream has finished the previous sequence.
 __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs)
