@@ -494,27 +494,40 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no gather moves above the flags
         SOLVE_STAMP(2)
-        // -- g_k = A p_{k-1} from the neighbours' p_{k-1}; p_{k-1} takes p_{k-3}'s place
+        // -- g_k = A p_{k-1} from the neighbours' p_{k-1}; p_{k-1} takes p_{k-3}'s place.  The gathers of several tiles go out
+        // before the first is used (a round trip per batch where a tile-by-tile loop made T)
+        // (TG tiles' gathers in flight together.  More than one was tried -- a round trip per batch where the tile-by-tile loop
+        // makes T -- and lost: 32 more registers per tile in flight, and at T = 4 / 2 the spills they caused sit between the
+        // gathers with a wait each: 500x500 200 -> 237 us per iteration.)
+        constexpr int TG = 1;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            double2 pj[NW];
-            const int i = (wg * T + t) * TILE + tid;
-            const int myoff = (act[t] ? i : n - 1) * 16;
+        for (int t0 = 0; t0 < T; t0 += TG) {
+            double2 pj[TG][NW];
 #pragma unroll
-            for (int kk = 0; kk < NW; ++kk) pj[kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_so, 16));
-            const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);
-            const double2 p = kry_form_p(st, g, p3, p2);  // (re-formed: the same bits as the stored one, no LDS round trip)
-            double gx = dg[t] * p.x, gy = dg[t] * p.y;
+            for (int u = 0; u < TG; ++u) {
+                const int t = t0 + u;
+                const int i = (wg * T + t) * TILE + tid;
+                const int myoff = (act[t] ? i : n - 1) * 16;
 #pragma unroll
-            for (int kk = 0; kk < NW; ++kk) {
-                const double c = nb_av(t, kk);
-                gx = fma(c, pj[kk].x, gx);
-                gy = fma(c, pj[kk].y, gy);
+                for (int kk = 0; kk < NW; ++kk) pj[u][kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_so, 16));
             }
-            st_vec(t, pb) = p;
-            gr[t] = make_double2(gx, gy);
-            part[t][1] = fma(p.y, gy, p.x * gx);
-            if (!act[t]) { part[t][0] = 0.0; part[t][1] = 0.0; part[t][2] = 0.0; part[t][3] = 0.0; }
+#pragma unroll
+            for (int u = 0; u < TG; ++u) {
+                const int t = t0 + u;
+                const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);
+                const double2 p = kry_form_p(st, g, p3, p2);  // (re-formed: the same bits as the stored one, no LDS round trip)
+                double gx = dg[t] * p.x, gy = dg[t] * p.y;
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) {
+                    const double c = nb_av(t, kk);
+                    gx = fma(c, pj[u][kk].x, gx);
+                    gy = fma(c, pj[u][kk].y, gy);
+                }
+                st_vec(t, pb) = p;
+                gr[t] = make_double2(gx, gy);
+                part[t][1] = fma(p.y, gy, p.x * gx);
+                if (!act[t]) { part[t][0] = 0.0; part[t][1] = 0.0; part[t][2] = 0.0; part[t][3] = 0.0; }
+            }
         }
         // -- the sums: block partials per tile (block_partials<4>: wave sums, waves added in wave order), the group's tiles in
         // tile order, one record
