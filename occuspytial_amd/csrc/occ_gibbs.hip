@@ -1602,7 +1602,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
         if ((rc = dev_alloc(s, &c.claim, (size_t)C * 16))) return rc;
         s->iter.claim = c.claim;
-        if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * 3 * c.nb_n * 4))) return rc;
+        if ((rc = dev_alloc(s, &s->iter.part, (size_t)C * ITER_PART_DOUBLES * c.nb_n))) return rc;
         s->iter.bar = c.bar;
     }
 

@@ -58,7 +58,7 @@ constexpr int XL_SLOTS = 8;                     // chains of an XCD-local launch
 // Developer builds (-DOCC_SOLVE_STAMPS, `make stamps`) record s_memtime at a few points of every MINRES step of
 // chain 0 / workgroup 0; the product build compiles the hooks away.
 #ifdef OCC_SOLVE_STAMPS
-constexpr int STAMP_STEPS = 48, STAMP_POINTS = 12;
+constexpr int STAMP_STEPS = 48, STAMP_POINTS = 16;
 __device__ unsigned long long g_solve_stamps[STAMP_STEPS * STAMP_POINTS];
 #define SOLVE_STAMP(pt)                                                                                  \
     if (chain == 0 && wg == 0 && threadIdx.x == 0 && k < STAMP_STEPS) g_solve_stamps[k * STAMP_POINTS + (pt)] = __builtin_readcyclecounter();
@@ -86,7 +86,8 @@ struct IterArgs {
     unsigned *claim;      // [C][16] one XCD per chain: the next free workgroup slot of the chain
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
-    double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
+    double *part;         // [C][ITER_PART_DOUBLES nb_n]: [3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in
+                          // rotation), then (scalar-wave form) [4][nb_n][2] records of ||x||^2, four in rotation
     // k_tiles (occ_tiles.hpp): exchange buffers of p (three in rotation, [C][tiles_npad]), tagged records [C][nb_n][4],
     // tiles per workgroup, workgroups per chain, workgroups per XCD band
     double2 *tex[3];
@@ -98,6 +99,8 @@ struct IterArgs {
     int chain_base;       // one XCD per chain: first chain of this launch (more than eight chains run as several launches of eight)
     int C, p, q;
 };
+
+constexpr int ITER_PART_DOUBLES = 3 * 4 + 4 * 2;  // per slice and chain (IterArgs::part)
 
 __device__ __forceinline__ v4u pack_d2(double2 v)
 {
@@ -334,6 +337,32 @@ __device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, i
     return true;
 }
 
+// The same poll over the slices' one-half records of ||x||^2 (scalar-wave form): the canonical order of the fourth sum.
+__device__ __forceinline__ bool poll_slice_x(__amdgpu_buffer_rsrc_t buf, int nslices, int lane, unsigned spin_limit, const ChainScalars &sc, double &tot)
+{
+    unsigned spins = 0;
+    for (;;) {
+        bool pend = false;
+        tot = 0.0;
+        for (int base = 0; base < nslices; base += 256) {
+            double2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = load_sc1(buf, (base + 64 * r + lane) * 16);  // (past the last slice: zeros)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pend = pend || rec_pending(v[r]);
+                tot += v[r].x;
+            }
+        }
+        if (!__any(pend)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit) return false;
+        if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;  // another workgroup gave up
+    }
+    tot = wave_sum(tot);
+    return true;
+}
+
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
 //
@@ -445,11 +474,18 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[1] + co), 0, n * 16, 0x00020000)};
     // per-slice records of the running solve {S0, S1 | S2, S3}: two buffers by step parity (any placement), three in
     // rotation when the records double as arrival flags (XL, see "step exchange" above)
-    double *part_base = ia.part + (size_t)chain * 3 * a.nb_n * 4;
+    double *part_base = ia.part + (size_t)chain * ITER_PART_DOUBLES * a.nb_n;
     const __amdgpu_buffer_rsrc_t pbuf[3] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 8), 0, a.nb_n * 32, 0x00020000)};
+    // scalar-wave form: the slices' records of ||x||^2 (one 16-byte half each), four buffers in rotation (see the solve)
+    const __amdgpu_buffer_rsrc_t xbuf[4] = {
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 12), 0, a.nb_n * 16, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 14), 0, a.nb_n * 16, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 16), 0, a.nb_n * 16, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 18), 0, a.nb_n * 16, 0x00020000)};
+    (void)xbuf;
     if (probe) {  // residency / placement probe: one barrier, nothing else
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -468,7 +504,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     int off[NW];      // byte offset of neighbour kk in a [n] double2 array
     double av[NW];    // Q_ij, then tau * Q_ij
     unsigned hasmask = 0u;
-    double2 nm1[NW], nm2[NW], ng[NW];
+    double2 ng[NW];
     const int ic = act ? i : n - 1;             // clamped row for plain loads
     const int myoff = act ? i * 16 : n * 16;    // byte offset of this site in the exchange buffers
     int width, base;
@@ -483,7 +519,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     double2 x = zero2;
     double2 xn[NW];
 #pragma unroll
-    for (int kk = 0; kk < NW; ++kk) { off[kk] = myoff; av[kk] = 0.0; xn[kk] = zero2; nm1[kk] = zero2; nm2[kk] = zero2; }
+    for (int kk = 0; kk < NW; ++kk) { off[kk] = myoff; av[kk] = 0.0; xn[kk] = zero2; }
     // (the scalar wave owns no site: nothing stands between it and tau.)  The site waves issue their first level of loads,
     // pass the noise hand-over's barrier at once -- the scalar wave is waiting there to start on tau -- and only then
     // take the neighbour gathers, whose addresses are loaded values
@@ -589,7 +625,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     // ---- phase B: MINRES.  The coefficients of step k come from the sums of step k - 1 (minres_post).
     Slot s_reg = {};
     int k = 1;
-    double2 g = p0, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
+    double2 g = p0, gm2 = zero2, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
     if constexpr (SW) {
         // ======== scalar wave + seven site waves.  Workgroup barriers of step k, in order:
         //   B1  stop / coefficients of p_{k-1} are in s_bcast            (scalar wave: after minres_post_ab)
@@ -602,34 +638,47 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             Slot &s = s_reg;
             KryMid mid;
             KryPre pre = minres_pre(s);
-            KryStep st = minres_post_ab(s, pre, 1, 0.0, 0.0, 0.0, 0.0, a.maxiter, mid);
-            if (threadIdx.x == 0) { s_bcast[0] = 1.0; s_bcast[1] = 0.0; s_bcast[2] = 0.0; s_bcast[3] = 0.0; }
+            KryStep st = minres_post_b(s, pre, 1, 0.0, 0.0, 0.0, mid);
+            double xn2 = 0.0;
+            if (threadIdx.x == 0) { s_bcast[0] = 1.0; s_bcast[1] = 0.0; s_bcast[2] = 0.0; s_rot[5] = 0.0; }
             __syncthreads();  // B1 of step 1
             for (; !failed; ++k) {
                 SOLVE_STAMP(0)
-                if (st.stop) break;
-                minres_post_c(s, pre, k, st, mid);
-                if (threadIdx.x == 0) {
-                    s_rot[0] = st.sj; s_rot[1] = st.oldeps; s_rot[2] = st.delta; s_rot[3] = st.denom; s_rot[4] = st.phi;
-                    s_rot[5] = st.rotate ? 1.0 : 0.0;
-                }
+                // the site waves are on step k; here: (a) the stopping test of iteration k - 3 -- they hear of it at the step's
+                // last barrier (what they did in the step is then dropped).  (Uniform by value; said so to the compiler, or k --
+                // and with it every buffer descriptor chosen by k -- counts as divergent and each buffer access becomes a
+                // waterfall loop.)
+                const bool stop = __builtin_amdgcn_readfirstlane((int)(st.stop || minres_post_a(s, pre, k, xn2, a.maxiter))) != 0;
                 SOLVE_STAMP(1)
-                __syncthreads();  // B2
-                SOLVE_STAMP(2)
-                pre = minres_pre(s);  // the slot-only half of step k + 1, while the site waves finish step k
-                double acc[4];
-                const bool ok = poll_slice_records<true>(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc);
+                bool ok = true;
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                if (!stop) {
+                    minres_post_c(s, pre, k, st, mid);  // (c) in full: the slot after step k
+                    SOLVE_STAMP(12)
+                    pre = minres_pre(s);  // the slot-only half of step k + 1, while the site waves finish step k
+                    SOLVE_STAMP(13)
+                    ok = __builtin_amdgcn_readfirstlane((int)poll_slice_records<true>(pbuf[k % 3], a.nb_n, lane, spin_limit, sc, acc)) != 0;
+                }
                 SOLVE_STAMP(3)
                 if (threadIdx.x == 0) {
-                    s_flag = ok ? 0 : 1;
+                    s_flag = ok ? (stop ? 2 : 0) : 1;
                     if (!ok) chain_fail(sc);
                 }
                 __syncthreads();  // B0
                 SOLVE_STAMP(4)
                 if (!ok) { failed = true; break; }
-                st = minres_post_ab(s, pre, k + 1, acc[0], acc[1], acc[2], acc[3], a.maxiter, mid);
+                if (stop) break;
+                // (b): the coefficients of p_k, and the part of (c) of step k + 1 the site waves need after them -- the rotation's
+                // coefficients -- while their gathers of g_k are on the way
+                st = minres_post_b(s, pre, k + 1, acc[0], acc[1], acc[2], mid);
+                xn2 = acc[3];
+                if (!st.stop) minres_rotation(s, pre, k + 1, st, mid);
                 SOLVE_STAMP(5)
-                if (threadIdx.x == 0) { s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.stop ? 1.0 : 0.0; }
+                if (threadIdx.x == 0) {
+                    s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc;
+                    s_rot[0] = st.sj; s_rot[1] = st.oldeps; s_rot[2] = st.delta; s_rot[3] = st.denom; s_rot[4] = st.phi;
+                    s_rot[5] = st.rotate ? 1.0 : 0.0;
+                }
                 __syncthreads();  // B1 of step k + 1
             }
             if (writer) {
@@ -648,7 +697,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             // the older one's registers; the loop below calls it with the roles swapped every other step.  (With one set of
             // names and "older = newer; newer = new" at the end of the body the compiler moved 76 registers per step, a
             // third of what a site wave issued.)  Returns false when the solve is over (stop or failure).
-            auto site_step = [&](double2 (&h1)[NW], double2 (&h2)[NW], double2 &q1, double2 &q2, double2 &u1, double2 &u2) -> bool {
+            auto site_step = [&](double2 &g1, double2 &g2, double2 &q1, double2 &q2, double2 &u1, double2 &u2) -> bool {
                 // g_{k-1} at the neighbours (step 1: p_0), complete since the poll of step k - 1 (the chain barrier of phase A):
                 // the only place that loads it, so the loads land in the registers the step reads them from
                 double2 ng[NW];
@@ -658,33 +707,26 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 __syncthreads();  // B1
                 SITE_STAMP(6)
                 st.ca = s_bcast[0]; st.cb = s_bcast[1]; st.cc = s_bcast[2];
-                if (s_bcast[3] != 0.0) return false;
+                st.sj = s_rot[0]; st.oldeps = s_rot[1]; st.delta = s_rot[2]; st.denom = s_rot[3]; st.phi = s_rot[4];
+                const bool rotate = __builtin_amdgcn_readfirstlane((int)(s_rot[5] != 0.0)) != 0;
                 double part[4] = {0.0, 0.0, 0.0, 0.0};
-                const double2 p = kry_form_p(st, g, q2, q1);  // p_{k-1}
-                double gx = d * p.x, gy = d * p.y;
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const double2 pj = kry_form_p(st, ng[kk], h2[kk], h1[kk]);
-                    gx = fma(av[kk], pj.x, gx);
-                    gy = fma(av[kk], pj.y, gy);
-                    h2[kk] = pj;
-                }
-                g = make_double2(gx, gy);
-                store_x<1>(gbuf[k & 1], myoff, g);
+                const double2 h = kry_apply<NW>(d, av, g1, ng);  // A g_{k-1}
+                const double2 p = kry_form_p(st, g1, q2, q1);    // p_{k-1}
+                const double2 gn = kry_form_p(st, h, g2, g1);    // g_k = A p_{k-1}, by the same three-term recurrence
+                g2 = gn;
+                store_x<1>(gbuf[k & 1], myoff, gn);
                 if (lane < 2) store_x<1>(pbuf[(k + 1) % 3], slice * 32 + lane * 16, rec_canary());  // this slice's record of step k + 1
                 part[0] = dot2(p, p);
-                part[1] = fma(p.y, gy, p.x * gx);
+                part[1] = fma(p.y, gn.y, p.x * gn.x);
                 if (k >= 2) part[2] = dot2(p, q1);
                 SITE_STAMP(7)
-                __syncthreads();  // B2 (p_{k-3} = q2 is the rotation's operand: p takes its place after it)
-                SITE_STAMP(8)
-                if (s_rot[5] != 0.0) {  // w_{k-2}, x_{k-2}  (before the first rotation both w's are zeros: the roles may swap)
-                    st.sj = s_rot[0]; st.oldeps = s_rot[1]; st.delta = s_rot[2]; st.denom = s_rot[3]; st.phi = s_rot[4];
+                double2 xk = x;  // x_{k-2}: takes x's place at the end of the step unless the solve turns out to have ended before it
+                if (rotate) {  // w_{k-2}, x_{k-2}  (before the first rotation both w's are zeros: the roles may swap)
                     const double2 w = kry_form_w(st, q2, u2, u1);
-                    x.x = fma(st.phi, w.x, x.x);
-                    x.y = fma(st.phi, w.y, x.y);
+                    xk.x = fma(st.phi, w.x, x.x);
+                    xk.y = fma(st.phi, w.y, x.y);
                     u2 = w;
-                    part[3] = dot2(x, x);
+                    part[3] = dot2(xk, xk);
                 }
                 q2 = p;
                 if (!act) { part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0; }
@@ -693,16 +735,19 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g and its canaries of step k + 1 are in the XCD's L2
                 if (lane < 2) store_x<1>(pbuf[k % 3], slice * 32 + lane * 16, lane == 0 ? make_double2(part[0], part[1]) : make_double2(part[2], part[3]));
                 SITE_STAMP(10)
-                __syncthreads();  // B0
+                __syncthreads();  // B0: every record of the step has arrived (0), or the poll gave up (1), or the solve ended before this step (2)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the poll
-                if (s_flag) { failed = true; return false; }
+                const int how = __builtin_amdgcn_readfirstlane(s_flag);  // (uniform: see the scalar wave)
+                if (how == 1) failed = true;
+                if (how != 0) return false;
+                x = xk;
                 ++k;
                 return true;
             };
             if (failed) __syncthreads();  // (phase A gave up: the scalar wave's B1 of step 1 still stands)
             while (!failed) {
-                if (!site_step(nm1, nm2, pm1, pm2, wm1, wm2)) break;
-                if (!site_step(nm2, nm1, pm2, pm1, wm2, wm1)) break;
+                if (!site_step(g, gm2, pm1, pm2, wm1, wm2)) break;
+                if (!site_step(gm2, g, pm2, pm1, wm2, wm1)) break;
             }
         }
     } else {
@@ -760,19 +805,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             part[3] = dot2(x, x);
         }
         {
-            const double2 p = kry_form_p(st, g, pm2, pm1);  // p_{k-1}
-            double gx = d * p.x, gy = d * p.y;
-#pragma unroll
-            for (int kk = 0; kk < NW; ++kk) {
-                const double2 pj = kry_form_p(st, ng[kk], nm2[kk], nm1[kk]);
-                gx = fma(av[kk], pj.x, gx);
-                gy = fma(av[kk], pj.y, gy);
-                nm2[kk] = nm1[kk];
-                nm1[kk] = pj;
-            }
-            g = make_double2(gx, gy);
+            const double2 p = kry_form_p(st, g, pm2, pm1);     // p_{k-1}
+            const double2 h = kry_apply<NW>(d, av, g, ng);     // A g_{k-1}
+            const double2 gn = kry_form_p(st, h, gm2, g);      // g_k = A p_{k-1}, by the same three-term recurrence
+            gm2 = g;
+            g = gn;
             part[0] = dot2(p, p);
-            part[1] = fma(p.y, gy, p.x * gx);
+            part[1] = fma(p.y, gn.y, p.x * gn.x);
             if (k >= 2) part[2] = dot2(p, pm1);
             pm2 = pm1;
             pm1 = p;
@@ -864,12 +903,15 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 
     // ---- phase C: sum-to-zero projection, eta, partial sums of beta's system.  The solve stopped at the top
     // of step k, uniformly over the chain: buffers of parity k are free (everybody has passed barrier k-1).
+    // (scalar-wave form: the step that learnt `stop` has already stored its records in buffer k % 3 -- the sums go to the
+    // buffer of step k - 1, which every workgroup has finished reading)
     double proj_a = 0.0;
+    const int PROJ_BUF = XL ? (SW ? (k + 2) % 3 : k % 3) : (k & 1);
     PHASE_STAMP(STAMP_STEPS - 1, 0)
     if (!failed) {
         if (slice_act) {
             const double t0 = wave_sum(act ? x.x : 0.0), t1 = wave_sum(act ? x.y : 0.0);
-            if (lane == 0) store_x<XL>(pbuf[XL ? k % 3 : (k & 1)], slice * 32, make_double2(t0, t1));
+            if (lane == 0) store_x<XL>(pbuf[PROJ_BUF], slice * 32, make_double2(t0, t1));
         }
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -881,7 +923,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
                 double2 v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[XL ? k % 3 : (k & 1)], (b0 + 64 * r) * 32);
+                for (int r = 0; r < 4; ++r) v[r] = load_sc1(pbuf[PROJ_BUF], (b0 + 64 * r) * 32);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sx += v[r].x; sz += v[r].y; }
             }

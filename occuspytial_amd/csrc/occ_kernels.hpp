@@ -1208,6 +1208,23 @@ __device__ __forceinline__ KryStep minres_post_ab(Slot &s, const KryPre &q, int 
     }
     return minres_post_b(s, q, k, S0, S1, S2, mid);
 }
+// The part of (c) the vectors wait for -- the rotation's coefficients -- ahead of the rest: the same operations on the same
+// operands as minres_post_c below (which forms them again, bit for bit), nothing written to the slot.
+__device__ __forceinline__ void minres_rotation(const Slot &s, const KryPre &q, int k, KryStep &st, const KryMid &mid)
+{
+    if (k < 3) return;
+    const double eps = DBL_EPSILON;
+    const double beta_n = mid.beta_km1;
+    st.oldeps = s.epsln;
+    st.delta = q.delta;
+    const double g2 = fma(beta_n, beta_n, q.gbar2);
+    const bool g_ok = g2 >= eps * eps;
+    const double ig = rsqrt_nr(g_ok ? g2 : 1.0);
+    st.denom = g_ok ? ig : 1.0 / eps;
+    st.phi = (q.gbar * st.denom) * s.phibar;
+    st.sj = q.sj;
+    st.rotate = true;
+}
 // (c): the rotation of iteration k - 2 (k >= 3) and the slot after step k
 __device__ __forceinline__ void minres_post_c(Slot &s, const KryPre &q, int k, KryStep &st, const KryMid &mid)
 {
@@ -1370,6 +1387,18 @@ __device__ __forceinline__ double2 kry_form_w(const KryStep &st, double2 p3, dou
     return w;
 }
 __device__ __forceinline__ double dot2(double2 a, double2 b) { return fma(a.y, b.y, a.x * b.x); }
+// h = A v at one site: d v_i + sum over the NW neighbour slots, in slot order (unused slots carry the coefficient 0)
+template <int NW>
+__device__ __forceinline__ double2 kry_apply(double d, const double (&av)[NW], double2 v, const double2 (&nv)[NW])
+{
+    double hx = d * v.x, hy = d * v.y;
+#pragma unroll
+    for (int kk = 0; kk < NW; ++kk) {
+        hx = fma(av[kk], nv[kk].x, hx);
+        hy = fma(av[kk], nv[kk].y, hy);
+    }
+    return make_double2(hx, hy);
+}
 
 constexpr int NPRE = 8;  // neighbour slots fetched before the scalars are known (queen lattice: all)
 
@@ -1536,14 +1565,14 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     double2 *Pw = a.Pv[(kl + 2) % 3] + co, *Gw = a.Gv[kl & 1] + co;   // p_{k-1}, g_k
     double2 *Ww = a.Wv[kl & 1] + co;                              // holds w_{k-4}, receives w_{k-2}
     const double2 *Wr = a.Wv[(kl - 1) & 1] + co;                  // w_{k-3}
-    double2 g1_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
-    double2 ng[NPRE], n2[NPRE], n3[NPRE];
+    double2 g1_i = zero2, g2_i = zero2, p2_i = zero2, p3_i = zero2, w1 = zero2, w2 = zero2, x = zero2;
+    double2 ng[NPRE];
     if (act) {
-        g1_i = G1[i]; p2_i = P2[i]; p3_i = P3[i]; x = a.Xv[co + i]; w1 = Ww[i]; w2 = Wr[i];
+        g1_i = G1[i]; g2_i = Gw[i]; p2_i = P2[i]; p3_i = P3[i]; x = a.Xv[co + i]; w1 = Ww[i]; w2 = Wr[i];
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk) {
-            ng[kk] = zero2; n2[kk] = zero2; n3[kk] = zero2;
-            if (kk < width) { ng[kk] = G1[col[kk]]; n2[kk] = P2[col[kk]]; n3[kk] = P3[col[kk]]; }
+            ng[kk] = zero2;
+            if (kk < width) ng[kk] = G1[col[kk]];
         }
     }
     if (ctl.it >= it_stop || chain_error != 0) return;
@@ -1555,19 +1584,17 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     const int k = kl + (int)ctl.koff;  // step within THIS solve (continues across launch sequences)
     const double om = (ctl.it & 1) ? om1 : om0;
     // speculative loads of vectors that do not exist yet at the first steps are discarded
-    // (k = 1: p_0, stored by k_eta_init in Pv[0] = this launch's p_{k-1} slot, plays p_{k-1})
+    // (k = 1: p_0, stored by k_eta_init in Pv[0] = this launch's p_{k-1} slot, plays p_{k-1} and -- the operand of the
+    // matrix product -- g_{k-1})
     if (k < 5) w1 = zero2;
     if (k < 4) w2 = zero2;
-    if (k < 3) {
-        p3_i = zero2;
-#pragma unroll
-        for (int kk = 0; kk < NPRE; ++kk) n3[kk] = zero2;
-    }
+    if (k < 3) { p3_i = zero2; g2_i = zero2; }
     if (k == 1 && act) {
         p2_i = Pw[i];
+        g1_i = p2_i;
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk)
-            if (kk < width) n2[kk] = Pw[col[kk]];
+            if (kk < width) ng[kk] = Pw[col[kk]];
     }
     OCC_STAMP(1)
     double S0 = 0.0, S1 = 0.0, S2 = 0.0, xn2 = 0.0;
@@ -1603,40 +1630,35 @@ __global__ void __launch_bounds__(256) k_minres(const KryArgs a, int chain_base,
     }
     OCC_STAMP(3)
     if (act) {
-        double2 p;  // p_{k-1} at this site
-        if (k == 1) {
-            p = p2_i;  // p_0, already in its place
-        } else {
-            p = kry_form_p(st, g1_i, p3_i, p2_i);
-            Pw[i] = p;
-        }
+        // h = A g_{k-1} (step 1: A p_0), the diagonal first, then the slots in order
         const double d = tau * qd + om;
-        double gx = d * p.x, gy = d * p.y;
+        double hx = d * g1_i.x, hy = d * g1_i.y;
 #pragma unroll
         for (int kk = 0; kk < NPRE; ++kk)
             if (kk < width) {
                 const double av = tau * val[kk];
-                const double2 pj = (k == 1) ? n2[kk] : kry_form_p(st, ng[kk], n3[kk], n2[kk]);
-                gx = fma(av, pj.x, gx);
-                gy = fma(av, pj.y, gy);
+                hx = fma(av, ng[kk].x, hx);
+                hy = fma(av, ng[kk].y, hy);
             }
         for (int kk = NPRE; kk < width; ++kk) {  // rows longer than the prefetch window
             const int jn = a.sell_col[base + kk * 64 + lane];
             const double av = tau * a.sell_val[base + kk * 64 + lane];
-            double2 pj;
-            if (k == 1) {
-                pj = Pw[jn];
-            } else {
-                const double2 gj = G1[jn], q2 = P2[jn];
-                const double2 q3 = (k >= 3) ? P3[jn] : zero2;
-                pj = kry_form_p(st, gj, q3, q2);
-            }
-            gx = fma(av, pj.x, gx);
-            gy = fma(av, pj.y, gy);
+            const double2 gj = (k == 1) ? Pw[jn] : G1[jn];
+            hx = fma(av, gj.x, hx);
+            hy = fma(av, gj.y, hy);
         }
-        Gw[i] = make_double2(gx, gy);
+        double2 p, gn;  // p_{k-1} and g_k = A p_{k-1} at this site
+        if (k == 1) {
+            p = p2_i;  // p_0, already in its place
+            gn = make_double2(hx, hy);
+        } else {
+            p = kry_form_p(st, g1_i, p3_i, p2_i);
+            gn = kry_form_p(st, make_double2(hx, hy), g2_i, g1_i);  // the same three-term recurrence, applied to A's images
+            Pw[i] = p;
+        }
+        Gw[i] = gn;
         part[0] = dot2(p, p);
-        part[1] = fma(p.y, gy, p.x * gx);
+        part[1] = fma(p.y, gn.y, p.x * gn.x);
         if (k >= 2) part[2] = dot2(p, p2_i);
     }
     OCC_STAMP(4)
@@ -1719,15 +1741,17 @@ __global__ void __launch_bounds__(256) k_beta_partial(OCC_KARGS, int k_last_laun
     const int n = c.n, i = blk * blockDim.x + threadIdx.x;
     if (carry) {
         // Re-align the unfinished solve to launch number 1 of the next sequence: k_minres indexes its
-        // buffers by launch number, so after L launches the live vectors g_k (Gv[L&1]), p_{k-1}, p_{k-2}
+        // buffers by launch number, so after L launches the live vectors g_k, g_{k-1} (Gv[L&1], Gv[(L-1)&1]), p_{k-1}, p_{k-2}
         // (Pv[(L+2)%3], Pv[(L+1)%3]), w_{k-2}, w_{k-3} (Wv[L&1], Wv[(L-1)&1]) and the partial sums
-        // (parity (L+1)&1) move to where launch 1 looks for them: Gv[0], Pv[2], Pv[1], Wv[0], Wv[1], parity 1.
+        // (parity (L+1)&1) move to where launch 1 looks for them: Gv[0], Gv[1], Pv[2], Pv[1], Wv[0], Wv[1], parity 1.
         const int L = k_last_launch;
         const size_t co = (size_t)chain * n;
         if (i < n && (L % 6) != 0) {
-            const double2 g = c.Gv[L & 1][co + i], pa = c.Pv[(L + 2) % 3][co + i], pb = c.Pv[(L + 1) % 3][co + i];
+            const double2 g = c.Gv[L & 1][co + i], gb = c.Gv[(L - 1) & 1][co + i];
+            const double2 pa = c.Pv[(L + 2) % 3][co + i], pb = c.Pv[(L + 1) % 3][co + i];
             const double2 wa = c.Wv[L & 1][co + i], wb = c.Wv[(L - 1) & 1][co + i];
             c.Gv[0][co + i] = g;
+            c.Gv[1][co + i] = gb;
             c.Pv[2][co + i] = pa;
             c.Pv[1][co + i] = pb;
             c.Wv[0][co + i] = wa;

@@ -7,19 +7,19 @@
 // 500x500), the number of launches guessed when the graph is captured.  k_tiles is the same phases A / B / C
 // (tau, right-hand side, p_0 | joint MINRES | projection, eta, beta sums -- logit.py:206-217, 75-92, distributions.pyx:24-39,
 // logit.py:226-231, scipy minres.py) with
-//   * TILES of 256 sites, T consecutive tiles per 256-thread workgroup, the tile's own vectors (g, p_{k-2}, p_{k-3},
-//     w_{k-3}, w_{k-4}, x: 96 bytes per site) in LDS for the whole solve -- 24 KB per tile, six tiles per CU;
-//   * p EXCHANGED instead of re-formed at the neighbours: a step stores p_{k-1} (16 B per site) and gathers it at the
-//     eight neighbours -- no neighbour histories, three workgroups per CU.  A workgroup's p is ready when its FLAG of the step
-//     says so (every storing wave drained, workgroup barrier, one lane stores the flag): a workgroup waits for the flags of
-//     the few workgroups that hold its neighbours -- on a lattice the one before and the one after -- not for the chain;
-//     the rotation (w, x) of the step runs between "store p" and "look at the flags";
+//   * TILES of 256 sites, T consecutive tiles per 256-thread workgroup, the tile's own histories (p_{k-2}, p_{k-3}, w_{k-3},
+//     w_{k-4}: 64 bytes per site) in LDS for the whole solve -- 16 KB per tile -- and g_{k-1}, g_{k-2}, x in registers;
+//   * g EXCHANGED: a step stores g_k = A p_{k-1} (16 B per site) and the next one gathers it at the eight neighbours for
+//     h = A g_k, from which p_k and g_{k+1} follow by the three-term recurrence (occ_kernels.hpp, k_minres) -- no neighbour
+//     histories, and no exchange of its own: a workgroup stores g_k, drains, and only then publishes its sums of step k, so
+//     whoever holds the chain's sums of step k (which every workgroup waits for anyway) may gather g_k.  (Round 3 first
+//     exchanged p_{k-1} within the step, with a flag per workgroup that its neighbours waited for: a second hand-over per
+//     step, 3 of its 10.5 us at 500x500.)  "Step 0" publishes p_0 with a record of zeros;
 //   * ONE XCD PER BAND of consecutive workgroups: a workgroup works for the band of the XCD it runs on (HW_REG_XCC_ID) and
 //     claims its place in it, as k_iter's one-XCD forms do for a chain.  Neighbours inside a band are read through that
 //     XCD's L2 (plain stores, L1-bypassing loads); only the 128-byte lines of the exchange buffer that hold a site with
-//     a neighbour in ANOTHER band are stored write-through (sc1) -- two lattice rows per band edge -- and a workgroup keeps
-//     two flags, a plain one for its band and a write-through one for the others.  Every line is written whole by one
-//     store instruction of one wave in one of the two forms (MI355X_MICROARCH.md, Valid forms);
+//     a neighbour in ANOTHER band are stored write-through (sc1) -- two lattice rows per band edge.  Every line is written
+//     whole by one store instruction of one wave in one of the two forms (MI355X_MICROARCH.md, Valid forms);
 //   * the four sums of a step in TWO LEVELS: every workgroup (its T tiles added in tile order) stores one 32-byte record
 //     that is its own arrival flag (canary halves, three buffers in rotation -- occ_iter.hpp "XL step exchange") with
 //     plain stores; the first workgroup of a band adds up its band's records (one per lane, through the band's L2) and
@@ -42,15 +42,15 @@ __host__ __device__ constexpr size_t tiles_lds_bytes(int T) { return (size_t)T *
 // of four waves) and LDS (16 KB per tile of the CU's 160 KB).  Tiles per CU: 4, 6, 9, 8.
 __host__ __device__ constexpr int tiles_wg_per_cu(int T) { return T == 1 ? 4 : (T == 4 ? 2 : 3); }
 
-// The invariant between launches: every group record and every band record of record buffer 1 holds the canary (step 1
+// The invariant between launches: every group record and every band record of record buffer 0 holds the canary (step 0
 // of the next solve polls them).  k_tiles restores it at its end; this kernel establishes it at creation and after
 // anything that may have left the buffers in another state (residency probes, a failed launch).
 __global__ void __launch_bounds__(256) k_tiles_reset(const IterArgs ia)
 {
     const int chain = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2LL * ia.tiles_G) reinterpret_cast<double2 *>(ia.part + ((size_t)chain * 3 + 1) * ia.a.nb_n * 4)[i] = rec_canary();
-    if (i < 2LL * XL_SLOTS) reinterpret_cast<double2 *>(ia.tband + ((size_t)chain * 3 + 1) * XL_SLOTS * 4)[i] = rec_canary();
+    if (i < 2LL * ia.tiles_G) reinterpret_cast<double2 *>(ia.part + (size_t)chain * ITER_PART_DOUBLES * ia.a.nb_n)[i] = rec_canary();
+    if (i < 2LL * XL_SLOTS) reinterpret_cast<double2 *>(ia.tband + (size_t)chain * 3 * XL_SLOTS * 4)[i] = rec_canary();
 }
 
 // Broadcast of one lane's double; the lane index is wave-uniform.
@@ -176,7 +176,7 @@ template <int NW, int T, int DIA>
 __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterArgs ia, int e, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_state[];  // [T][TILE_VECS][TILE]; phase C: the block partials of beta's system
-    __shared__ int s_flag, s_noise_ok, s_claim, s_wlo[4], s_whi[4];
+    __shared__ int s_flag, s_noise_ok, s_claim;
     __shared__ double s_bcast[12];
     __shared__ double s_part[T][4][4];  // per tile and wave: the block partials of a step's sums (wave order)
     __shared__ Slot s_slot;
@@ -230,11 +230,9 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     // buffers, so nothing is clipped at a buffer's end: lanes without a site store nothing and gather their own row n - 1.
     const int e_stride = ia.C * ia.tiles_npad * 16, p_stride = nt * 32, b_stride = XL_SLOTS * 32;  // bytes between the rotating buffers
     const __amdgpu_buffer_rsrc_t ebuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tex[0] + chain64 * ia.tiles_npad), 0, 2 * e_stride + n * 16, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.part + chain64 * 3 * nt * 4), 0, 3 * p_stride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.part + chain64 * ITER_PART_DOUBLES * nt), 0, 3 * p_stride, 0x00020000);
     const __amdgpu_buffer_rsrc_t tbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.trec + chain64 * nt * 4), 0, nt * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t bbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tband + chain64 * 3 * XL_SLOTS * 4), 0, 3 * b_stride, 0x00020000);
-    // "my p of step k is out": two words per workgroup -- [0][wg] plain (readers of this band), [1][wg] write-through (others)
-    const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tflag + chain64 * 2 * G), 0, 2 * G * 8, 0x00020000);
     const bool band_leader = place == 0;
     const unsigned bar_base = sc.bar_base;
     auto st_vec = [&](int t, int v) -> double2 & { return s_state[((size_t)t * TILE_VECS + v) * TILE + tid]; };
@@ -277,7 +275,6 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     bool act[T];
     double om[T], zv[T];
     double2 gr[T], xr[T];  // g_{k-1} and x of this lane's sites (registers: with them in LDS a CU held six tiles, now eight)
-    int wlo = wg, whi = wg;  // the workgroups that hold this workgroup's neighbours (a superset: the range between the extremes)
     {
         double xb[T], qd[T], en[T], up[T], xav[T][NW];
         double2 x0[T], xn[T][NW];
@@ -319,22 +316,12 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
                 xn[t][kk] = a.Xv[co + j];
                 const int jw = j / (T * TILE);  // the workgroup that holds the neighbour
                 remote = remote || (has && jw / B != (int)my_xcc);
-                wlo = min(wlo, has ? jw : wg);
-                whi = max(whi, has ? jw : wg);
             }
             // (the 8 lanes of a 128-byte line decide together: a line is stored whole in ONE of the two forms)
             const unsigned long long m = __ballot(remote);
             if ((m >> (lane & 56)) & 0xffull) sc1mask |= 1u << t;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            wlo = min(wlo, __shfl_xor(wlo, o));
-            whi = max(whi, __shfl_xor(whi, o));
-        }
-        if (lane == 0) { s_wlo[wave] = wlo; s_whi[wave] = whi; }
-        __syncthreads();  // (also: thread 0's wait for the side stream's noise is over)
-        wlo = min(min(s_wlo[0], s_wlo[1]), min(s_wlo[2], s_wlo[3]));
-        whi = max(max(s_whi[0], s_whi[1]), max(s_whi[2], s_whi[3]));
+        __syncthreads();  // (thread 0's wait for the side stream's noise is over)
         if (synced && !s_noise_ok && writer) sc.err = -2;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -403,21 +390,20 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     }
 
     PHASE_STAMP(0, 3)
-    // ---- phase B: MINRES.  Step k: p_{k-1} formed and published, the rotation of iteration k - 2, g_k = A p_{k-1} from the
-    // neighbours' p_{k-1}, the four sums; the coefficients of step k + 1 come from the sums of step k.
+    // ---- phase B: MINRES.  Step k: g_{k-1} gathered at the neighbours, h = A g_{k-1}, p_{k-1} and g_k = A p_{k-1} by the same
+    // three-term recurrence (occ_kernels.hpp, k_minres), g_k published, the rotation of iteration k - 2, the four sums; the
+    // coefficients of step k + 1 come from the sums of step k.  "Step 0" publishes p_0 (which plays g_0) with a record of
+    // zeros: whoever has the sums of step k has every workgroup's g_k -- each stored it, drained, before its record.
     Slot &s = s_slot;
     KryPre pre = {};
     KryStep st = {};
     bool failed = false;
-    if (lead) {
-        pre = minres_pre(s);
-        Slot t_ = slot_load(&s);
-        st = minres_post(t_, pre, 1, 0.0, 0.0, 0.0, 0.0, a.maxiter);
-        slot_store(&s, t_);
-    }
+    if (lead) pre = minres_pre(s);
     st.ca = 1.0; st.cb = 0.0; st.cc = 0.0; st.rotate = false; st.stop = false;
-    int k = 1;
-    const unsigned long long flag_hi = (unsigned long long)bar_base << 32;  // flags of this launch: (launch counter, step)
+    double2 g2r[T];  // g_{k-2} of this lane's sites
+#pragma unroll
+    for (int t = 0; t < T; ++t) g2r[t] = zero2;
+    int k = 0;
     for (;; ++k) {
         SOLVE_STAMP(0)
         if (st.stop) break;
@@ -425,110 +411,58 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         // derived from k for lane-dependent: a buffer descriptor picked by k % 3 became a waterfall loop around EVERY gather,
         // each with its own s_waitcnt -- 9.7 us per step.  Scalar registers by force.)
         k = __builtin_amdgcn_readfirstlane(k);
-        const int kb = __builtin_amdgcn_readfirstlane(k % 3), kn = __builtin_amdgcn_readfirstlane((k + 1) % 3);
+        const int kb = __builtin_amdgcn_readfirstlane(k % 3), kn = __builtin_amdgcn_readfirstlane((k + 1) % 3), kp = __builtin_amdgcn_readfirstlane((k + 2) % 3);
         const int pa = TV_P + (k & 1), pb = TV_P + ((k + 1) & 1), wa = TV_W + (k & 1), wb = TV_W + ((k + 1) & 1);
-        const int e_so = kb * e_stride, p_so = kb * p_stride, p_sn = kn * p_stride, b_so = kb * b_stride, b_sn = kn * b_stride;  // scalar offsets
+        const int e_so = kb * e_stride, e_sp = kp * e_stride, p_so = kb * p_stride, p_sn = kn * p_stride, b_so = kb * b_stride, b_sn = kn * b_stride;  // scalar offsets
         double part[T][4];
-        // -- p_{k-1} at the site, published
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = (wg * T + t) * TILE + tid;
-            const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
-            const double2 p = kry_form_p(st, g, p3, p2);
-            // (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
-            if (act[t]) {
-                if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf, i * 16, e_so, 16);
-                else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(p), ebuf, i * 16, e_so, 0);
-            }
-            part[t][0] = dot2(p, p);
-            part[t][2] = (k >= 2) ? dot2(p, p2) : 0.0;
-            part[t][3] = 0.0;
-        }
-        // this group's record of step k + 1 (and, band leader, the band's) shows the canary before the one of step k is out
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_sn, 0);
-        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_sn, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's p is out (L2, or memory for the write-through lines)
-        __syncthreads();
-        if (tid < 2) {  // ... the workgroup's: say so
-            const unsigned long long v = flag_hi | (unsigned)k;
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            v2u w2;
-            w2.x = (unsigned)v; w2.y = (unsigned)(v >> 32);
-            if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, wg * 8, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, (G + wg) * 8, 0, 16);
-        }
-        SOLVE_STAMP(1)
-        // -- while the flags travel: w_{k-2}, x_{k-2} (the rotation of iteration k - 2)
+            const int myoff = (act[t] ? i : n - 1) * 16;
+            double2 gn = gr[t];  // step 0: p_0
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const double2 p3 = st_vec(t, pb);
-            if (st.rotate) {
-                const double2 w = kry_form_w(st, p3, st_vec(t, wa), st_vec(t, wb));  // (p_{k-3}, w_{k-4}, w_{k-3})
-                xr[t].x = fma(st.phi, w.x, xr[t].x);
-                xr[t].y = fma(st.phi, w.y, xr[t].y);
-                st_vec(t, wa) = w;
-                part[t][3] = dot2(xr[t], xr[t]);
-            }
-        }
-        // -- the neighbours' workgroups have published p_{k-1}?  One wave looks at their flags (lane l: workgroup wlo + l).
-        if (lead) {
-            const unsigned long long want = flag_hi | (unsigned)k;
-            unsigned spins = 0;
-            bool ok = true;
-            for (int w0 = wlo; w0 <= whi && ok; w0 += 64) {
-                for (;;) {
-                    const int w = w0 + lane;
-                    const bool in = w <= whi && w != wg;
-                    const int wc = in ? w : wg;
-                    const bool local = wc / B == (int)my_xcc;
-                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                    const v2u f0 = __builtin_amdgcn_raw_buffer_load_b64(fbuf, (local ? wc : G + wc) * 8, 0, 16);
-                    const unsigned long long f = ((unsigned long long)f0.y << 32) | f0.x;
-                    if (!__any(in && f != want)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > spin_limit || ((spins & 1023u) == 0u && chain_err(sc) != 0)) { ok = false; break; }
+            for (int q = 0; q < 4; ++q) part[t][q] = 0.0;
+            if (k > 0) {
+                // g_{k-1} at the neighbours (complete since the sums of step k - 1 arrived)
+                double2 gj[NW];
+#pragma unroll
+                for (int kk = 0; kk < NW; ++kk) gj[kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_sp, 16));
+                const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
+                // while the gathers travel: w_{k-2}, x_{k-2} (the rotation of iteration k - 2)
+                if (st.rotate) {
+                    const double2 w = kry_form_w(st, p3, st_vec(t, wa), st_vec(t, wb));  // (p_{k-3}, w_{k-4}, w_{k-3})
+                    xr[t].x = fma(st.phi, w.x, xr[t].x);
+                    xr[t].y = fma(st.phi, w.y, xr[t].y);
+                    st_vec(t, wa) = w;
+                    part[t][3] = dot2(xr[t], xr[t]);
                 }
-            }
-            if (!ok && lane == 0) s_flag = 1;
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no gather moves above the flags
-        SOLVE_STAMP(2)
-        // -- g_k = A p_{k-1} from the neighbours' p_{k-1}; p_{k-1} takes p_{k-3}'s place.  The gathers of several tiles go out
-        // before the first is used (a round trip per batch where a tile-by-tile loop made T)
-        // (TG tiles' gathers in flight together.  More than one was tried -- a round trip per batch where the tile-by-tile loop
-        // makes T -- and lost: 32 more registers per tile in flight, and at T = 4 / 2 the spills they caused sit between the
-        // gathers with a wait each: 500x500 200 -> 237 us per iteration.)
-        constexpr int TG = 1;
-#pragma unroll
-        for (int t0 = 0; t0 < T; t0 += TG) {
-            double2 pj[TG][NW];
-#pragma unroll
-            for (int u = 0; u < TG; ++u) {
-                const int t = t0 + u;
-                const int i = (wg * T + t) * TILE + tid;
-                const int myoff = (act[t] ? i : n - 1) * 16;
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) pj[u][kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_so, 16));
-            }
-#pragma unroll
-            for (int u = 0; u < TG; ++u) {
-                const int t = t0 + u;
-                const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);
-                const double2 p = kry_form_p(st, g, p3, p2);  // (re-formed: the same bits as the stored one, no LDS round trip)
-                double gx = dg[t] * p.x, gy = dg[t] * p.y;
+                const double2 p = kry_form_p(st, g, p3, p2);  // p_{k-1}
+                double hx = dg[t] * g.x, hy = dg[t] * g.y;    // h = A g_{k-1}: the diagonal, then the slots in order
 #pragma unroll
                 for (int kk = 0; kk < NW; ++kk) {
                     const double c = nb_av(t, kk);
-                    gx = fma(c, pj[u][kk].x, gx);
-                    gy = fma(c, pj[u][kk].y, gy);
+                    hx = fma(c, gj[kk].x, hx);
+                    hy = fma(c, gj[kk].y, hy);
                 }
+                gn = kry_form_p(st, make_double2(hx, hy), g2r[t], g);  // g_k
                 st_vec(t, pb) = p;
-                gr[t] = make_double2(gx, gy);
-                part[t][1] = fma(p.y, gy, p.x * gx);
+                g2r[t] = g;
+                gr[t] = gn;
+                part[t][0] = dot2(p, p);
+                part[t][1] = fma(p.y, gn.y, p.x * gn.x);
+                part[t][2] = (k >= 2) ? dot2(p, p2) : 0.0;
                 if (!act[t]) { part[t][0] = 0.0; part[t][1] = 0.0; part[t][2] = 0.0; part[t][3] = 0.0; }
             }
+            // g_k published (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
+            if (act[t]) {
+                if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 0);
+            }
         }
+        SOLVE_STAMP(1)
+        // this group's record of step k + 1 (and, band leader, the band's) shows the canary before the one of step k is out
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_sn, 0);
+        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_sn, 16);
         // -- the sums: block partials per tile (block_partials<4>: wave sums, waves added in wave order), the group's tiles in
         // tile order, one record
 #pragma unroll
@@ -539,7 +473,7 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
                 for (int q = 0; q < 4; ++q) s_part[t][wave][q] = part[t][q];
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the canaries of step k + 1 are out before the record of step k
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g_k (L2, or memory for the write-through lines) and the canaries of step k + 1 are out
         __syncthreads();
         SOLVE_STAMP(3)
         if (tid < 4) {
@@ -557,20 +491,21 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(make_double2(s_bcast[4 + 2 * tid], s_bcast[5 + 2 * tid])), pbuf, wg * 32 + tid * 16, p_so, 0);
         SOLVE_STAMP(4)
         if (lead) {
-            bool ok = s_flag == 0;
-            if (band_leader && ok) {  // the band's sums: its groups' records, one per lane; published write-through
+            bool ok = true;
+            if (band_leader) {  // the band's sums: its groups' records, one per lane; published write-through
                 double bs[4];
                 ok = poll_band_groups(pbuf, p_so, band_first, band_size, lane, spin_limit, sc, bs);
                 if (lane < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(lane == 0 ? make_double2(bs[0], bs[1]) : make_double2(bs[2], bs[3])), bbuf, (int)my_xcc * 32 + lane * 16, b_so, 16);
             }
             SOLVE_STAMP(5)
-            pre = minres_pre(s);  // the slot-only half of step k + 1, while the bands arrive
+            if (k > 0) pre = minres_pre(s);  // the slot-only half of step k + 1, while the bands arrive
             double acc[4];
             if (ok) ok = poll_bands(bbuf, b_so, (G + B - 1) / B, lane, spin_limit, sc, acc);
             SOLVE_STAMP(6)
             Slot t_ = slot_load(&s);
             if (ok) st = minres_post(t_, pre, k + 1, acc[0], acc[1], acc[2], acc[3], a.maxiter);
             slot_store(&s, t_);
+            if (k == 0) st.ca = 1.0;  // step 1: kry_form_p returns its first argument (p_0, A p_0) exactly
             if (tid == 0) {
                 if (!ok) { s_flag = 1; chain_fail(sc); }
                 s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.sj;
@@ -640,8 +575,8 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         PHASE_STAMP(STAMP_STEPS - 1, 1)
         // every workgroup of the chain has stored its projection record, i.e. has left the solve: nobody polls the
         // step buffers any more -- the invariant between launches (k_tiles_reset) is restored here
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_stride, 0);
-        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_stride, 16);
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, 0, 0);
+        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, 0, 16);
         const int P = ia.p;
 #pragma unroll
         for (int t = 0; t < T; ++t) {

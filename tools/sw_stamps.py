@@ -20,7 +20,7 @@ for i, g in enumerate(gens):
     eng.set_start(i, st['alpha'], st['beta'], st['tau'], st['eta'])
 eng.run(300, 299)
 lib = C.CDLL(L.LIB_PATH)
-STEPS, PTS = 48, 12
+STEPS, PTS = 48, 16
 buf = (C.c_ulonglong * (STEPS * PTS))()
 assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
 t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
@@ -30,6 +30,7 @@ print('scalar wave: top->post_c+rot | ->B2 | pre+poll | ->B0 | post_ab | ->next 
 for k in range(2, min(itn + 2, STEPS - 1)):
     sc = [t[k, 1] - t[k, 0], t[k, 2] - t[k, 1], t[k, 3] - t[k, 2], t[k, 4] - t[k, 3], t[k, 5] - t[k, 4], t[k + 1, 0] - t[k, 5]]
     si = [t[k, 7] - t[k, 6], t[k, 8] - t[k, 7], t[k, 9] - t[k, 8], t[k, 10] - t[k, 9], t[k, 11] - t[k, 10], t[k + 1, 6] - t[k, 11]]
+    print('     B2->post_c %d, pre %d, poll %d' % (t[k,12]-t[k,2], t[k,13]-t[k,12], t[k,3]-t[k,13]))
     print('%3d  ' % k + ' '.join('%6d' % v for v in sc) + '     |   ' + ' '.join('%6d' % v for v in si) + '   %6d   site top - scalar top %d' % (t[k + 1, 0] - t[k, 0], t[k, 6] - t[k, 0]))
 L_ = STEPS - 1
 print('phase A: tau %d, rhs+p0 %d, barrier %d, to first step %d' % (t[0,1]-t[0,0], t[0,2]-t[0,1], t[0,3]-t[0,2], t[1,0]-t[0,3]))
