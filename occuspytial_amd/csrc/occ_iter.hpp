@@ -86,8 +86,7 @@ struct IterArgs {
     unsigned *claim;      // [C][16] one XCD per chain: the next free workgroup slot of the chain
     unsigned long long *clock;  // Ctx::iter_clock
     unsigned *sync;       // Ctx::sync (stream hand-overs by device counters) or null
-    double *part;         // [C][ITER_PART_DOUBLES nb_n]: [3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in
-                          // rotation), then (scalar-wave form) [4][nb_n][2] records of ||x||^2, four in rotation
+    double *part;         // [C][3][nb_n][4] per-slice records of the running solve (two by step parity; XL: three in rotation)
     // k_tiles (occ_tiles.hpp): exchange buffers of p (three in rotation, [C][tiles_npad]), tagged records [C][nb_n][4],
     // tiles per workgroup, workgroups per chain, workgroups per XCD band
     double2 *tex[3];
@@ -100,7 +99,7 @@ struct IterArgs {
     int C, p, q;
 };
 
-constexpr int ITER_PART_DOUBLES = 3 * 4 + 4 * 2;  // per slice and chain (IterArgs::part)
+constexpr int ITER_PART_DOUBLES = 3 * 4;  // per slice and chain (IterArgs::part)
 
 __device__ __forceinline__ v4u pack_d2(double2 v)
 {
@@ -337,32 +336,6 @@ __device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, i
     return true;
 }
 
-// The same poll over the slices' one-half records of ||x||^2 (scalar-wave form): the canonical order of the fourth sum.
-__device__ __forceinline__ bool poll_slice_x(__amdgpu_buffer_rsrc_t buf, int nslices, int lane, unsigned spin_limit, const ChainScalars &sc, double &tot)
-{
-    unsigned spins = 0;
-    for (;;) {
-        bool pend = false;
-        tot = 0.0;
-        for (int base = 0; base < nslices; base += 256) {
-            double2 v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = load_sc1(buf, (base + 64 * r + lane) * 16);  // (past the last slice: zeros)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pend = pend || rec_pending(v[r]);
-                tot += v[r].x;
-            }
-        }
-        if (!__any(pend)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > spin_limit) return false;
-        if ((spins & 1023u) == 0u && chain_err(sc) != 0) return false;  // another workgroup gave up
-    }
-    tot = wave_sum(tot);
-    return true;
-}
-
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
 //
@@ -417,16 +390,24 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     if (XL) {
         if ((int)my_xcc >= min(ia.C - ia.chain_base, XL_SLOTS)) return;
         chain = ia.chain_base + (int)my_xcc;
-        if (threadIdx.x == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + (size_t)chain * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         chain = (int)blockIdx.y;
         wg = (int)blockIdx.x;
+    }
+    // (a scalar register by force, HERE: left to itself the compiler may sink the chain number's 64-bit extension into the
+    // one-lane branch below and merge it back as a VECTOR register -- every buffer descriptor derived from it is then
+    // lane-dependent in its eyes and each of the kernel's buffer accesses becomes a waterfall loop: k_iter 40 -> 54 us when a
+    // change elsewhere in the kernel tipped that decision, as in k_tiles before it)
+    size_t chain64 = (size_t)chain;
+    asm volatile("" : "+s"(chain64));
+    if (XL) {
+        if (threadIdx.x == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + chain64 * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // what needs neither the slot nor the noise is on its way while the claim's atomic returns: the chain's control words,
     // and one lane's wait for the noise of this iteration (from the side stream's previous sequence; normally it has been
     // there for a whole iteration -- the workgroup looks at the result before phase A's loads of the noise)
-    ChainScalars &sc = a.scs[chain];
+    ChainScalars &sc = a.scs[chain64];
     const Ctl ctl = sc.ctl[e];
     const uint32_t it_stop = sc.it_stop;
     const int err0 = sc.err;
@@ -462,9 +443,9 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const bool act = i < n;
     const int lane = threadIdx.x & 63, slice = scalar_wave ? a.nb_n : (i >> 6);
     const bool slice_act = slice < a.nb_n;  // a slice with at least one site owns a partial sum
-    const size_t co = (size_t)chain * n;
+    const size_t co = chain64 * n;
     const double2 zero2 = make_double2(0.0, 0.0);
-    unsigned *cnt = ia.bar + (size_t)chain * BAR_STRIDE;
+    unsigned *cnt = ia.bar + chain64 * BAR_STRIDE;
     const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)cnt, 0, ia.nbg * 4, 0x00020000);  // XL: the chain's flags
     (void)fbuf; (void)my_xcc;
     const unsigned bar_base = sc.bar_base;
@@ -474,18 +455,11 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.Gv[1] + co), 0, n * 16, 0x00020000)};
     // per-slice records of the running solve {S0, S1 | S2, S3}: two buffers by step parity (any placement), three in
     // rotation when the records double as arrival flags (XL, see "step exchange" above)
-    double *part_base = ia.part + (size_t)chain * ITER_PART_DOUBLES * a.nb_n;
+    double *part_base = ia.part + chain64 * ITER_PART_DOUBLES * a.nb_n;
     const __amdgpu_buffer_rsrc_t pbuf[3] = {
         __builtin_amdgcn_make_buffer_rsrc((void *)part_base, 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 4), 0, a.nb_n * 32, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 8), 0, a.nb_n * 32, 0x00020000)};
-    // scalar-wave form: the slices' records of ||x||^2 (one 16-byte half each), four buffers in rotation (see the solve)
-    const __amdgpu_buffer_rsrc_t xbuf[4] = {
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 12), 0, a.nb_n * 16, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 14), 0, a.nb_n * 16, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 16), 0, a.nb_n * 16, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(part_base + (size_t)a.nb_n * 18), 0, a.nb_n * 16, 0x00020000)};
-    (void)xbuf;
     if (probe) {  // residency / placement probe: one barrier, nothing else
         ++nbar;
         OCC_CHAIN_BARRIER(s_flag);
@@ -571,7 +545,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     double tau = 0.0;
     if (lead) {
         double q = 0.0;
-        const double *pq = ia.part_quad + (size_t)chain * a.nb_n;
+        const double *pq = ia.part_quad + chain64 * a.nb_n;
         for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
             double v[4];
 #pragma unroll
@@ -683,7 +657,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
             }
             if (writer) {
                 if (failed) { s.done = 1; s.istop = 6; s.itn = k; }
-                slot_store(&a.slots[(size_t)chain * NSLOT], s);
+                slot_store(&a.slots[chain64 * NSLOT], s);
                 sc.minres_itn_last = s.itn;
                 sc.krylov_total += (unsigned long long)s.itn;
                 sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;
@@ -892,7 +866,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
 #define BAR_STAMP(pt)
     if (writer) {
         if (failed) { s.done = 1; s.istop = 6; s.itn = k; }
-        slot_store(&a.slots[(size_t)chain * NSLOT], s);
+        slot_store(&a.slots[chain64 * NSLOT], s);
         sc.minres_itn_last = s.itn;
         sc.krylov_total += (unsigned long long)s.itn;
         sc.krylov_sq_total += (unsigned long long)s.itn * (unsigned long long)s.itn;

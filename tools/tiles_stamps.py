@@ -26,17 +26,18 @@ for i, g in enumerate(gens):
 eng.run(100, 99)
 print(eng.stats())
 lib = C.CDLL(L.LIB_PATH)
-STEPS, PTS = 48, 12
+STEPS, PTS = 48, 16
 buf = (C.c_ulonglong * (STEPS * PTS))()
 assert lib.occ_debug_solve_stamps(buf, STEPS * PTS) == STEPS * PTS
 t = np.array(buf, dtype=np.int64).reshape(STEPS, PTS)
 itn = int(eng.get('minres_itn', 0))
-names = ['p+flag', 'rotation+flagwait', 'gather+g+sums+sync', 'group sum+record', 'band poll(leader)', 'pre+bands poll', 'post+bcast', 'sync', 'to next']
+names = ['gather+vectors+store', 'sums+drain+sync', 'group sum+record', 'band poll(leader)', 'pre+bands poll', 'post+bcast', 'sync', 'to next']
+pts = [0, 1, 3, 4, 5, 6, 7, 8]
 print('last solve of chain 0: %d iterations; shader-clock ticks per segment (workgroup 0, thread 0)' % itn)
 print('step ' + ' '.join('%15s' % n for n in names) + '   step total')
 tot = np.zeros(len(names)); cnt = 0
-for k in range(1, min(itn + 3, STEPS - 1)):
-    d = [t[k, j + 1] - t[k, j] for j in range(8)] + [t[k + 1, 0] - t[k, 8]]
+for k in range(0, min(itn + 3, STEPS - 1)):
+    d = [t[k, pts[j + 1]] - t[k, pts[j]] for j in range(7)] + [t[k + 1, 0] - t[k, 8]]
     print('%4d ' % k + ' '.join('%15d' % v for v in d) + '   %d' % (t[k + 1, 0] - t[k, 0]))
     if k >= 2:
         tot += np.array(d, dtype=float); cnt += 1
