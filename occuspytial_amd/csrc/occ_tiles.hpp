@@ -14,7 +14,7 @@
 //     histories, and no exchange of its own: a workgroup stores g_k, drains, and only then publishes its sums of step k, so
 //     whoever holds the chain's sums of step k (which every workgroup waits for anyway) may gather g_k.  (Round 3 first
 //     exchanged p_{k-1} within the step, with a flag per workgroup that its neighbours waited for: a second hand-over per
-//     step, 3 of its 10.5 us at 500x500.)  "Step 0" publishes p_0 with a record of zeros;
+//     step.)  Only p_0 still goes out behind such flags (phase B's head);
 //   * ONE XCD PER BAND of consecutive workgroups: a workgroup works for the band of the XCD it runs on (HW_REG_XCC_ID) and
 //     claims its place in it, as k_iter's one-XCD forms do for a chain.  Neighbours inside a band are read through that
 //     XCD's L2 (plain stores, L1-bypassing loads); only the 128-byte lines of the exchange buffer that hold a site with
@@ -42,15 +42,15 @@ __host__ __device__ constexpr size_t tiles_lds_bytes(int T) { return (size_t)T *
 // of four waves) and LDS (16 KB per tile of the CU's 160 KB).  Tiles per CU: 4, 6, 9, 8.
 __host__ __device__ constexpr int tiles_wg_per_cu(int T) { return T == 1 ? 4 : (T == 4 ? 2 : 3); }
 
-// The invariant between launches: every group record and every band record of record buffer 0 holds the canary (step 0
+// The invariant between launches: every group record and every band record of record buffer 1 holds the canary (step 1
 // of the next solve polls them).  k_tiles restores it at its end; this kernel establishes it at creation and after
 // anything that may have left the buffers in another state (residency probes, a failed launch).
 __global__ void __launch_bounds__(256) k_tiles_reset(const IterArgs ia)
 {
     const int chain = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2LL * ia.tiles_G) reinterpret_cast<double2 *>(ia.part + (size_t)chain * ITER_PART_DOUBLES * ia.a.nb_n)[i] = rec_canary();
-    if (i < 2LL * XL_SLOTS) reinterpret_cast<double2 *>(ia.tband + (size_t)chain * 3 * XL_SLOTS * 4)[i] = rec_canary();
+    if (i < 2LL * ia.tiles_G) reinterpret_cast<double2 *>(ia.part + ((size_t)chain * 3 + 1) * ia.a.nb_n * 4)[i] = rec_canary();
+    if (i < 2LL * XL_SLOTS) reinterpret_cast<double2 *>(ia.tband + ((size_t)chain * 3 + 1) * XL_SLOTS * 4)[i] = rec_canary();
 }
 
 // Broadcast of one lane's double; the lane index is wave-uniform.
@@ -176,7 +176,7 @@ template <int NW, int T, int DIA>
 __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterArgs ia, int e, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_state[];  // [T][TILE_VECS][TILE]; phase C: the block partials of beta's system
-    __shared__ int s_flag, s_noise_ok, s_claim;
+    __shared__ int s_flag, s_noise_ok, s_claim, s_wlo[4], s_whi[4];
     __shared__ double s_bcast[12];
     __shared__ double s_part[T][4][4];  // per tile and wave: the block partials of a step's sums (wave order)
     __shared__ Slot s_slot;
@@ -233,6 +233,8 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     const __amdgpu_buffer_rsrc_t pbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.part + chain64 * ITER_PART_DOUBLES * nt), 0, 3 * p_stride, 0x00020000);
     const __amdgpu_buffer_rsrc_t tbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.trec + chain64 * nt * 4), 0, nt * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t bbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tband + chain64 * 3 * XL_SLOTS * 4), 0, 3 * b_stride, 0x00020000);
+    // "my p_0 is out": two words per workgroup -- [0][wg] plain (readers of this band), [1][wg] write-through (others)
+    const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc((void *)(ia.tflag + chain64 * 2 * G), 0, 2 * G * 8, 0x00020000);
     const bool band_leader = place == 0;
     const unsigned bar_base = sc.bar_base;
     auto st_vec = [&](int t, int v) -> double2 & { return s_state[((size_t)t * TILE_VECS + v) * TILE + tid]; };
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         else return av[t][kk];
     };
     unsigned sc1mask = 0u;  // bit t: this lane's 128-byte line of tile t holds a site with a neighbour in another band
+    int wlo = wg, whi = wg;  // the workgroups that hold this workgroup's neighbours (a superset: the range between the extremes)
     bool act[T];
     double om[T], zv[T];
     double2 gr[T], xr[T];  // g_{k-1} and x of this lane's sites (registers: with them in LDS a CU held six tiles, now eight)
@@ -316,12 +319,22 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
                 xn[t][kk] = a.Xv[co + j];
                 const int jw = j / (T * TILE);  // the workgroup that holds the neighbour
                 remote = remote || (has && jw / B != (int)my_xcc);
+                wlo = min(wlo, has ? jw : wg);
+                whi = max(whi, has ? jw : wg);
             }
             // (the 8 lanes of a 128-byte line decide together: a line is stored whole in ONE of the two forms)
             const unsigned long long m = __ballot(remote);
             if ((m >> (lane & 56)) & 0xffull) sc1mask |= 1u << t;
         }
-        __syncthreads();  // (thread 0's wait for the side stream's noise is over)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wlo = min(wlo, __shfl_xor(wlo, o));
+            whi = max(whi, __shfl_xor(whi, o));
+        }
+        if (lane == 0) { s_wlo[wave] = wlo; s_whi[wave] = whi; }
+        __syncthreads();  // (also: thread 0's wait for the side stream's noise is over)
+        wlo = min(min(s_wlo[0], s_wlo[1]), min(s_wlo[2], s_wlo[3]));
+        whi = max(max(s_whi[0], s_whi[1]), max(s_whi[2], s_whi[3]));
         if (synced && !s_noise_ok && writer) sc.err = -2;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -392,21 +405,69 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     PHASE_STAMP(0, 3)
     // ---- phase B: MINRES.  Step k: g_{k-1} gathered at the neighbours, h = A g_{k-1}, p_{k-1} and g_k = A p_{k-1} by the same
     // three-term recurrence (occ_kernels.hpp, k_minres), g_k published, the rotation of iteration k - 2, the four sums; the
-    // coefficients of step k + 1 come from the sums of step k.  "Step 0" publishes p_0 (which plays g_0) with a record of
-    // zeros: whoever has the sums of step k has every workgroup's g_k -- each stored it, drained, before its record.
+    // coefficients of step k + 1 come from the sums of step k.  Whoever has the sums of step k has every workgroup's g_k --
+    // each stored it, drained, before its record.  p_0 (which plays g_0) has no sums to travel with: it goes out behind a
+    // FLAG per workgroup, (launch counter, 0), that the workgroups holding its neighbours wait for -- on a lattice the one
+    // before and the one after (a plain word for readers in the band, a write-through copy for the others; 3 us where a
+    // record of zeros through the two-level reduction -- a "step 0" -- took 7.4).
     Slot &s = s_slot;
     KryPre pre = {};
     KryStep st = {};
     bool failed = false;
-    if (lead) pre = minres_pre(s);
+    if (lead) {
+        pre = minres_pre(s);
+        Slot t_ = slot_load(&s);
+        st = minres_post(t_, pre, 1, 0.0, 0.0, 0.0, 0.0, a.maxiter);
+        slot_store(&s, t_);
+    }
     st.ca = 1.0; st.cb = 0.0; st.cc = 0.0; st.rotate = false; st.stop = false;
     double2 g2r[T];  // g_{k-2} of this lane's sites
+    {
+        const unsigned long long fv = (unsigned long long)bar_base << 32;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int t = 0; t < T; ++t) g2r[t] = zero2;
-    int k = 0;
+        for (int t = 0; t < T; ++t) {
+            g2r[t] = zero2;
+            const int i = (wg * T + t) * TILE + tid;
+            if (act[t]) {  // (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
+                if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gr[t]), ebuf, i * 16, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gr[t]), ebuf, i * 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's p_0 is out (L2, or memory for the write-through lines)
+        __syncthreads();
+        if (tid < 2) {
+            v2u w2;
+            w2.x = (unsigned)fv; w2.y = (unsigned)(fv >> 32);
+            if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, wg * 8, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(w2, fbuf, (G + wg) * 8, 0, 16);
+        }
+        if (lead) {  // one wave looks at the neighbours' flags (lane l: workgroup wlo + l)
+            unsigned spins = 0;
+            bool ok = true;
+            for (int w0 = wlo; w0 <= whi && ok; w0 += 64) {
+                for (;;) {
+                    const int w = w0 + lane;
+                    const bool in = w <= whi && w != wg;
+                    const int wc = in ? w : wg;
+                    const bool local = wc / B == (int)my_xcc;
+                    const v2u f0 = __builtin_amdgcn_raw_buffer_load_b64(fbuf, (local ? wc : G + wc) * 8, 0, 16);
+                    const unsigned long long f = ((unsigned long long)f0.y << 32) | f0.x;
+                    if (!__any(in && f != fv)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit || ((spins & 1023u) == 0u && chain_err(sc) != 0)) { ok = false; break; }
+                }
+            }
+            if (!ok && lane == 0) { s_flag = 1; chain_fail(sc); }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no gather moves above the flags
+        failed = __builtin_amdgcn_readfirstlane(s_flag) != 0;
+    }
+    int k = 1;
     for (;; ++k) {
         SOLVE_STAMP(0)
-        if (st.stop) break;
+        if (st.stop || failed) break;
         // (the step number is wave-uniform, but the loop leaves on values read from LDS and the compiler then takes everything
         // derived from k for lane-dependent: a buffer descriptor picked by k % 3 became a waterfall loop around EVERY gather,
         // each with its own s_waitcnt -- 9.7 us per step.  Scalar registers by force.)
@@ -419,10 +480,10 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         for (int t = 0; t < T; ++t) {
             const int i = (wg * T + t) * TILE + tid;
             const int myoff = (act[t] ? i : n - 1) * 16;
-            double2 gn = gr[t];  // step 0: p_0
+            double2 gn;
 #pragma unroll
             for (int q = 0; q < 4; ++q) part[t][q] = 0.0;
-            if (k > 0) {
+            {
                 // g_{k-1} at the neighbours (complete since the sums of step k - 1 arrived)
                 double2 gj[NW];
 #pragma unroll
@@ -498,14 +559,13 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
                 if (lane < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(lane == 0 ? make_double2(bs[0], bs[1]) : make_double2(bs[2], bs[3])), bbuf, (int)my_xcc * 32 + lane * 16, b_so, 16);
             }
             SOLVE_STAMP(5)
-            if (k > 0) pre = minres_pre(s);  // the slot-only half of step k + 1, while the bands arrive
+            pre = minres_pre(s);  // the slot-only half of step k + 1, while the bands arrive
             double acc[4];
             if (ok) ok = poll_bands(bbuf, b_so, (G + B - 1) / B, lane, spin_limit, sc, acc);
             SOLVE_STAMP(6)
             Slot t_ = slot_load(&s);
             if (ok) st = minres_post(t_, pre, k + 1, acc[0], acc[1], acc[2], acc[3], a.maxiter);
             slot_store(&s, t_);
-            if (k == 0) st.ca = 1.0;  // step 1: kry_form_p returns its first argument (p_0, A p_0) exactly
             if (tid == 0) {
                 if (!ok) { s_flag = 1; chain_fail(sc); }
                 s_bcast[0] = st.ca; s_bcast[1] = st.cb; s_bcast[2] = st.cc; s_bcast[3] = st.sj;
@@ -575,8 +635,8 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         PHASE_STAMP(STAMP_STEPS - 1, 1)
         // every workgroup of the chain has stored its projection record, i.e. has left the solve: nobody polls the
         // step buffers any more -- the invariant between launches (k_tiles_reset) is restored here
-        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, 0, 0);
-        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, 0, 16);
+        if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_stride, 0);
+        if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_stride, 16);
         const int P = ia.p;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
