@@ -159,7 +159,12 @@ struct occ_sampler {
     // the records and the final scalars come back behind ONE synchronisation.
     std::vector<ChainScalars> sc_host;
     bool sc_host_valid = false, clean_exit = false;
-    std::vector<double> rec_host;  // the recorded rows of the running call
+    // Page-locked staging for what crosses PCIe on every call (an asynchronous copy to or from pageable memory is staged by
+    // the runtime and, device to host, waits for the stream: two serial round trips at the end of every occ_run):
+    // pin_sc = [2][C] ChainScalars (0: set_window's upload, 1: read_scalars' read-back), pin_rec = the recorded rows.
+    ChainScalars *pin_sc = nullptr;
+    double *pin_rec = nullptr;
+    size_t pin_rec_cap = 0;
     bool marks_done = false;       // ev1 and the copy of the records are enqueued behind the call's last batch
     std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
     bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
@@ -173,7 +178,9 @@ struct occ_sampler {
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
-    unsigned long long clock_init[4] = {~0ull, 0ull, 0ull, 0ull};
+    bool clock_fresh = false;  // k_snapshot has just reset k_iter's clock words (run_impl does not do it again)
+    bool window_open = false;  // ... and opened this window of iterations on the device (set_window does not upload it again)
+    int64_t window_n = 0, window_burnin = 0, window_keep = 0;
     int launch_rc = 0;       // first failed kernel launch since the last take_launch_rc()
     std::string launch_err;
     // launch-sequence ("slot") parity: the kernels of the next sequence read ChainScalars::ctl[parity]
@@ -492,8 +499,11 @@ int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
 {
     h.resize(s->ctx.C);
     if (s->flag_sync && s->side) HIP_TRY(hipStreamSynchronize(s->side));  // its last k_noise is not waited for by the main stream
-    HIP_TRY(hipMemcpyAsync(h.data(), s->ctx.sc, sizeof(ChainScalars) * h.size(), hipMemcpyDeviceToHost, s->stream));
+    if (!s->pin_sc) HIP_TRY(hipHostMalloc((void **)&s->pin_sc, 2 * sizeof(ChainScalars) * h.size(), hipHostMallocDefault));
+    ChainScalars *back = s->pin_sc + h.size();
+    HIP_TRY(hipMemcpyAsync(back, s->ctx.sc, sizeof(ChainScalars) * h.size(), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    std::memcpy(h.data(), back, sizeof(ChainScalars) * h.size());
     return OCC_OK;
 }
 int write_scalars(occ_sampler *s, const std::vector<ChainScalars> &h)
@@ -811,7 +821,14 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
         if (s->ctx.sync) HIP_TRY(hipMemsetAsync(s->ctx.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
     }
     s->clean_exit = false;  // until the call says otherwise
-    HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
+    if (s->window_open && s->window_n == n_iter && s->window_burnin == burnin && s->window_keep == keep) {
+        s->window_open = false;  // (k_snapshot has made these edits on the device, in front of this call's kernels)
+        return OCC_OK;
+    }
+    s->window_open = false;
+    if (!s->pin_sc) HIP_TRY(hipHostMalloc((void **)&s->pin_sc, 2 * sizeof(ChainScalars) * h.size(), hipHostMallocDefault));
+    std::memcpy(s->pin_sc, h.data(), sizeof(ChainScalars) * h.size());  // (free again: the last copy from it was followed by a stream synchronisation)
+    HIP_TRY(hipMemcpyAsync(s->ctx.sc, s->pin_sc, sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
     return OCC_OK;
 }
 
@@ -1048,6 +1065,8 @@ int occ_destroy(occ_sampler *s)
         destroy_graph(s);
         for (void *p : s->allocs) (void)hipFree(p);
         if (s->rec_buf) (void)hipFree(s->rec_buf);
+        if (s->pin_sc) (void)hipHostFree(s->pin_sc);
+        if (s->pin_rec) (void)hipHostFree(s->pin_rec);
         for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
             if (ev) (void)hipEventDestroy(ev);
         drop_pair(s);  // the streams go with the last engine that shares them
@@ -2257,8 +2276,15 @@ static int finish_marks(occ_sampler *s, bool last, size_t n_rec)
 {
     if (!last) return OCC_OK;
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    s->rec_host.resize(n_rec);
-    if (n_rec) HIP_TRY(hipMemcpyAsync(s->rec_host.data(), s->rec_buf, sizeof(double) * n_rec, hipMemcpyDeviceToHost, s->stream));
+    if (n_rec > s->pin_rec_cap) {  // (grown between calls only: nothing is in flight to the old one)
+        if (s->pin_rec) HIP_TRY(hipHostFree(s->pin_rec));
+        s->pin_rec = nullptr;
+        s->pin_rec_cap = 0;
+        const size_t cap = std::max<size_t>(n_rec, 4096);
+        HIP_TRY(hipHostMalloc((void **)&s->pin_rec, sizeof(double) * cap, hipHostMallocDefault));
+        s->pin_rec_cap = cap;
+    }
+    if (n_rec) HIP_TRY(hipMemcpyAsync(s->pin_rec, s->rec_buf, sizeof(double) * n_rec, hipMemcpyDeviceToHost, s->stream));
     s->marks_done = true;
     return OCC_OK;
 }
@@ -2286,8 +2312,11 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     if (rc) return rc;
     if (c.iter_clock) {  // k_iter's clock counts this run only
         // (a member, not a stack array: the copy is asynchronous and the source must outlive it)
-        s->clock_init[0] = ~0ull; s->clock_init[1] = s->clock_init[2] = s->clock_init[3] = 0ull;
-        HIP_TRY(hipMemcpyAsync(c.iter_clock, s->clock_init, sizeof(s->clock_init), hipMemcpyHostToDevice, s->stream));
+        if (!s->clock_fresh) {
+            HIP_TRY(hipMemsetAsync(c.iter_clock, 0xff, sizeof(unsigned long long), s->stream));       // [0] = ~0: the earliest start so far
+            HIP_TRY(hipMemsetAsync(c.iter_clock + 1, 0, 3 * sizeof(unsigned long long), s->stream));  // [1] latest end, [2] sum, [3] launches
+        }
+        s->clock_fresh = false;
     }
     std::vector<ChainScalars> h;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -2393,10 +2422,10 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     s->sc_host_valid = true;
     s->clean_exit = true;
 
-    const std::vector<double> &host = s->rec_host;
+    const double *host = s->pin_rec;
     for (int ch = 0; ch < C; ++ch)
         for (int64_t t = 0; t < keep; ++t) {
-            const double *row = host.data() + ((size_t)ch * keep + t) * rw;
+            const double *row = host + ((size_t)ch * keep + t) * rw;
             std::copy(row, row + q, out_alpha + ((size_t)ch * keep + t) * q);
             std::copy(row + q, row + q + p, out_beta + ((size_t)ch * keep + t) * p);
             out_tau[(size_t)ch * keep + t] = row[q + p];
@@ -2413,7 +2442,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
 // variates are functions of (key, iteration, index) and both paths return the same bits, so the caller gets exactly
 // what the fused path would have returned.  The engine stays on the launch-per-step path afterwards
 // (occ_stats::persistent_solve = 0, ::fused_fallbacks counts).
-static int snapshot_take(occ_sampler *s)
+static int snapshot_take(occ_sampler *s, int64_t n_iter = 0, int64_t burnin = 0, int64_t keep = 0)
 {
     const Ctx &c = s->ctx;
     const size_t Cn = (size_t)c.C * c.n;
@@ -2431,7 +2460,11 @@ static int snapshot_take(occ_sampler *s)
     s->snap_parity = s->parity;
     // one launch for the three copies (three stream copies: three launch gaps in front of the call's first kernel)
     hipLaunchKernelGGL(k_snapshot, dim3((unsigned)std::min<size_t>((Cn + 255) / 256, 2048)), dim3(256), 0, s->stream, c.eta, s->snap_eta, c.z, s->snap_z, c.Xv, s->snap_x,
-                       (unsigned long long)Cn, s->rsr.m > 0 ? s->rsr.theta : nullptr, s->snap_theta, (unsigned long long)c.C * (unsigned long long)std::max(s->rsr.m, 0));
+                       (unsigned long long)Cn, s->rsr.m > 0 ? s->rsr.theta : nullptr, s->snap_theta, (unsigned long long)c.C * (unsigned long long)std::max(s->rsr.m, 0),
+                       c.iter_clock, (n_iter > 0 && c.C <= 256) ? c.sc : nullptr, c.C, s->parity, (uint32_t)n_iter, (uint32_t)burnin, (uint32_t)keep);
+    s->clock_fresh = c.iter_clock != nullptr;
+    s->window_open = n_iter > 0 && c.C <= 256;
+    s->window_n = n_iter; s->window_burnin = burnin; s->window_keep = keep;
     if (hipGetLastError() != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_snapshot failed");
     return OCC_OK;
 }
@@ -2599,7 +2632,7 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     int rc;
     if ((rc = refresh_paths(s))) return rc;
     const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;
-    if (fused && (rc = snapshot_take(s))) return rc;
+    if (fused && (rc = snapshot_take(s, n_iter, burnin, n_iter - burnin))) return rc;
     s->device_timeout = false;
     rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
     if (rc == OCC_E_HIP && fused && s->device_timeout) {

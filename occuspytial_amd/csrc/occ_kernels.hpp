@@ -738,11 +738,25 @@ __global__ void __launch_bounds__(256) k_checksum(const unsigned char *__restric
 }
 
 // The state a call is re-run from after a device-side wait gave up (occ_gibbs.hip, snapshot_take): eta, z, the warm start
-// (and theta of the reduced-rank model) of every chain, in ONE launch.
+// (and theta of the reduced-rank model) of every chain, in ONE launch -- which also resets the fused kernel's clock words
+// and opens the call's window: no copy engine between the call's entry and its first kernel.
 __global__ void __launch_bounds__(256) k_snapshot(const double *__restrict__ eta, double *__restrict__ s_eta, const uint8_t *__restrict__ z, uint8_t *__restrict__ s_z,
                                                   const double2 *__restrict__ x, double2 *__restrict__ s_x, unsigned long long count,
-                                                  const double *__restrict__ theta, double *__restrict__ s_theta, unsigned long long count_theta)
+                                                  const double *__restrict__ theta, double *__restrict__ s_theta, unsigned long long count_theta,
+                                                  unsigned long long *__restrict__ clock,  // k_iter's clock words of the call that follows (or null)
+                                                  ChainScalars *__restrict__ scs, int n_chains, int parity, uint32_t n_iter, uint32_t burnin, uint32_t keep)
 {
+    if (clock != nullptr && blockIdx.x == 0 && threadIdx.x < 4) clock[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;
+    // ... and opens the call's window of iterations in the chains' scalars (what set_window would upload: occ_gibbs.hip)
+    if (scs != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_chains) {
+        ChainScalars &sc = scs[threadIdx.x];
+        Ctl &ctl = sc.ctl[parity];
+        sc.it_base = ctl.it;
+        sc.it_stop = ctl.it + n_iter;
+        sc.burnin = burnin;
+        sc.keep = keep;
+        ctl.koff = 0;
+    }
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
         s_eta[i] = eta[i];
         s_z[i] = z[i];
