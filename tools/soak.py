@@ -8,7 +8,7 @@ from occuspytial_amd._problem import FlatProblem, chain_generators, default_star
 from occuspytial_amd.utils import make_lattice_problem
 import os
 cases = [(100, 100, 4, 300000, {}), (100, 100, 2, 100000, {}), (100, 100, 8, 60000, {}), (60, 60, 8, 150000, {}), (20, 20, 3, 150000, {}),
-         (100, 100, 4, 60000, {'OCC_NO_XCD_LOCAL': '1'})]
+         (100, 100, 4, 60000, {'OCC_NO_XCD_LOCAL': '1'}), (250, 250, 2, 30000, {}), (500, 500, 1, 8000, {})]
 for rows, cols, chains, iters, env in cases:
     for k in ('OCC_NO_XCD_LOCAL',):
         os.environ.pop(k, None)
