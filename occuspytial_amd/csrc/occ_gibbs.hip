@@ -334,7 +334,7 @@ KernelRsr pick_rsr_solve(int m)
     }
 }
 KernelEI pick_z_ob(int p) { return OCC_PICK_P(k_z_ob, p); }
-KernelE pick_omega_a(int q)
+KernelEI pick_omega_a(int q)
 {
     switch (q) {
         case 0: return k_omega_a<0>;  // generic path (run-time q)
@@ -387,7 +387,7 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_ETA_INIT: hipLaunchKernelGGL(k_eta_init<0>, gs, blk, 0, st, OCC_ARGS); break;
         case K_MINRES: hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, st, s->kry, 0, e, extra); break;
         case K_BETA_PARTIAL: hipLaunchKernelGGL(pick_beta_partial(tp), gs, blk, lds_p, st, OCC_ARGS, extra); break;
-        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), shared_grid(c, 1, c.nb_r), blk, lds_q, st, OCC_ARGS); break;
+        case K_OMEGA_A: hipLaunchKernelGGL(pick_omega_a(tq), shared_grid(c, 1, c.nb_r), blk, lds_q, st, OCC_ARGS, extra); break;  // extra = 1: k_gate's work first
         case K_ALPHA_DRAW: hipLaunchKernelGGL(k_alpha_draw<0>, dim3((unsigned)c.C), dim3(512), 0, st, OCC_ARGS, s->launch_sync ? 1 : 0); break;
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
@@ -694,8 +694,12 @@ int build_graph(occ_sampler *s, int cap)
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
         HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
         for (int t = 0; t < GRAPH_SEQ; ++t) {
-            LAUNCH(s, s->side, K_GATE, 0);
-            LAUNCH(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
+            if (std::getenv("OCC_GATE_KERNEL")) {  // diagnostic: the gate as a kernel of its own, as until round 3
+                LAUNCH(s, s->side, K_GATE, 0);
+                LAUNCH(s, s->side, K_OMEGA_A, s->parity ^ (t & 1));
+            } else {
+                LAUNCH(s, s->side, K_OMEGA_A, s->parity ^ (t & 1), 1);
+            }
             LAUNCH(s, s->side, K_NOISE, s->parity ^ (t & 1), 1);
         }
         HIP_TRY(hipStreamEndCapture(s->side, &s->tail_graph[0]));
@@ -3144,8 +3148,8 @@ int occ_cond_alpha(occ_sampler *s, int32_t chain, const double *omega_a, const d
     const int e = s->parity;
     const dim3 blk((unsigned)s->tpb), gr((unsigned)c.nb_r, 1u);
 #define OCC_OMEGA_A_INJ(q) ((q) == 1 ? k_omega_a<1, 1> : (q) == 2 ? k_omega_a<2, 1> : (q) == 3 ? k_omega_a<3, 1> : (q) == 4 ? k_omega_a<4, 1> : (q) == 5 ? k_omega_a<5, 1> : (q) == 6 ? k_omega_a<6, 1> : (q) == 7 ? k_omega_a<7, 1> : k_omega_a<8, 1>)
-    if (s->generic) hipLaunchKernelGGL((k_omega_a<0, 1>), gr, blk, generic_lds_bytes(nacc(c.q), s->tpb), s->stream, OCC_CARGS);
-    else hipLaunchKernelGGL(OCC_OMEGA_A_INJ(c.q), gr, blk, 0, s->stream, OCC_CARGS);
+    if (s->generic) hipLaunchKernelGGL((k_omega_a<0, 1>), gr, blk, generic_lds_bytes(nacc(c.q), s->tpb), s->stream, OCC_CARGS, 0);
+    else hipLaunchKernelGGL(OCC_OMEGA_A_INJ(c.q), gr, blk, 0, s->stream, OCC_CARGS, 0);
     hipLaunchKernelGGL(k_alpha_draw<1>, dim3(1), dim3(512), 0, s->stream, OCC_CARGS, 0);
     ChainScalars sc;
     if ((rc = cond_end(s, chain, &sc))) return rc;

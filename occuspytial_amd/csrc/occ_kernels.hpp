@@ -1901,10 +1901,28 @@ __device__ __forceinline__ void omega_a_row_g(const Ctx &c, const ChainScalars &
     em.finish();
 }
 
+// `gate` (head of a side-stream sequence that hands over through the device counters): the kernel does k_gate's work first --
+// its first workgroup announces that the previous k_noise is complete (stream order), and every workgroup that can be among
+// the first on the device waits for the main stream to have finished the previous sequence before it reads z.  A kernel of
+// its own for that (k_gate) cost the side stream a launch boundary per iteration, and the side stream is what bounds a
+// long run (K ~ 5: main stream 44 us, side 50).  Workgroups past GATE_FIRST are dispatched only after an earlier one has
+// finished, i.e. passed the wait: they need not look.
+constexpr unsigned GATE_FIRST = 4096;
 template <int Q, int INJ = 0>
-__global__ void __launch_bounds__(256, 3) k_omega_a(OCC_KARGS)
+__global__ void __launch_bounds__(256, 3) k_omega_a(OCC_KARGS, int gate)
 {
     const Ctx &c = *cp;
+    if (gate && c.sync != nullptr) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < GATE_FIRST) {
+            if (threadIdx.x == 0 && c.sync[SYNC_DEBUG] == 0u) {  // (test knob OCC_DEBUG_BREAK_HANDOVER: a side stream that never announces its noise)
+                const unsigned j = c.sync[SYNC_SIDE_SEQ];
+                if (lin == 0) sync_set(c.sync + SYNC_NOISE, j);
+                if (!sync_wait(c.sync, SYNC_MAIN, j)) scs[0].err = -2;
+            }
+            __syncthreads();
+        }
+    }
     const Tile tile = tile_of_block_shared(c, 1, c.nb_r, chain_base);
     const int chain = tile.chain, blk = tile.blk;
     if (chain < 0) return;
