@@ -343,12 +343,13 @@ __device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, i
 // workgroup, two waves per SIMD, as ONE SCALAR WAVE AND SEVEN SITE WAVES (448 sites).  A MINRES step is a chain of
 // dependent events -- sums of step k - 1 -> scalar recurrence (~100 dependent f64 instructions) -> coefficients ->
 // vectors -> sums -- and with the recurrence on a wave that also owns sites (round 2: wave 0 of eight site waves) every
-// wave of the chain waits for it: 45 % of a step.  Here the scalar wave owns no sites.  It polls the records, forms
-// `stop` and the three coefficients of p_{k-1} (minres_post_ab: the short half) and hands them over in LDS; while the
-// site waves form p and g = A p with them it runs the rotation of iteration k - 2 and the slot's update (minres_post_c),
-// hands over the rotation's coefficients for the w / x update that ends the site waves' step, prepares the next step
-// (minres_pre) and is polling again before the first record of the step arrives.  Per step: three workgroup barriers
-// (coefficients, rotation, poll done), no reduction through LDS (every site wave publishes its own record).
+// wave of the chain waits for it: 45 % of a step.  Here the scalar wave owns no sites.  It polls the records and forms
+// what the site waves need next and nothing else -- the three coefficients of p_{k-1} (minres_post_b) and the five of the
+// rotation of iteration k - 2 (minres_rotation) -- one hand-over in LDS; while the site waves run the whole step with them
+// (h = A g_{k-1} from the gathers, p, g, w, x, the four sums, the record) it evaluates the stopping test of iteration k - 3
+// (minres_post_a: the verdict travels with the step's last barrier), updates the slot (minres_post_c), prepares the next
+// step (minres_pre) and is polling again before the first record of the step arrives.  Per step: two workgroup barriers
+// (hand-over, poll done), no reduction through LDS (every site wave publishes its own record).
 //
 // flags: bit 0 = hand over to / from the side stream through the device counters; bit 1 = RESIDENCY PROBE: the launch
 // does nothing but one barrier among the workgroups of every chain, with a short time limit -- the same kernel, grid,
@@ -602,12 +603,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     double2 g = p0, gm2 = zero2, pm1 = zero2, pm2 = zero2, wm1 = zero2, wm2 = zero2;
     if constexpr (SW) {
         // ======== scalar wave + seven site waves.  Workgroup barriers of step k, in order:
-        //   B1  stop / coefficients of p_{k-1} are in s_bcast            (scalar wave: after minres_post_ab)
-        //   B2  the rotation's coefficients are in s_rot                 (scalar wave: after minres_post_c; site waves: after g)
-        //   B0  every record of step k has arrived (or the poll gave up: s_flag)
-        // Both roles leave the loop at the same place: after B1 (stop) or after B0 (failure).
-        // At step 1 the coefficients are ca = 1, cb = cc = 0: kry_form_p then returns its first argument -- p_0 at the
-        // site (g starts as p_0) and at its neighbours (ng holds p_0) -- exactly: the histories are zeros.
+        //   B1  the coefficients of p_{k-1} (s_bcast) and of the rotation of iteration k - 2 (s_rot) are there
+        //       (scalar wave: after minres_post_b and minres_rotation, formed while the site waves' gathers of g_{k-1} travel)
+        //   B0  the verdict on step k (s_flag) -- 0: every record has arrived, 1: the poll gave up, 2: the solve ended before
+        //       the step (scipy's test of iteration k - 3, evaluated beside the vectors: what the step did is dropped)
+        // Both roles leave the loop at the same place, after B0.
+        // At step 1 the coefficients are ca = 1, cb = cc = 0: kry_form_p then returns its first argument -- p_0, and
+        // h = A p_0 from the p_0 gathered at the neighbours -- exactly: the histories are zeros.
         if (scalar_wave) {
             Slot &s = s_reg;
             KryMid mid;
