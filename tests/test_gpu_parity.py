@@ -163,6 +163,52 @@ def test_batched_chains_equal_single_chain_runs():
     batch.close()
 
 
+def test_calls_with_different_windows_steps_and_reads_between_them_equal_one_run():
+    """Every occ_run opens its window of iterations (first / last iteration, burn-in, rows to keep) in the chains' scalars: on
+    the device, by the kernel that snapshots the state (round 3: no copy engine between a call's entry and its first kernel),
+    or by an upload when the call cannot take that way (occ_step; a call after something else touched the state).  The
+    recorded rows come back through page-locked staging that grows between calls.  A run cut into calls of different
+    lengths and burn-ins, with single steps and state reads in between, must leave the chains where ONE run leaves them and
+    return the same rows."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(60, 60, visits=3, p=2, q=2, random_state=9)
+    prob = FlatProblem(Q, W, X, y)
+    keys = [KEY + 3 * c for c in range(4)]
+    starts = [_random_start(prob, 21 + c) for c in range(4)]
+    one = Engine(prob, keys)
+    cut = Engine(prob, keys)
+    for c in range(4):
+        one.set_start(c, **starts[c])
+        cut.set_start(c, **starts[c])
+    A, B, T = one.run(61, 0)
+    rows = []
+    plan = [('run', 2, 0), ('run', 7, 3), ('step',), ('run', 1, 0), ('get',), ('run', 30, 29), ('step',), ('step',), ('run', 18, 5)]
+    for item in plan:
+        if item[0] == 'run':
+            a, b, t = cut.run(item[1], item[2])
+            rows.append((item[1], item[2], a, b, t))
+        elif item[0] == 'step':
+            cut.step()
+            rows.append((1, 1, None, None, None))
+        else:
+            assert np.all(np.isfinite(cut.get('eta', 2)))
+    assert sum(r[0] for r in rows) == 61
+    at = 0
+    for n, burn, a, b, t in rows:
+        if a is not None:
+            assert a.shape[1] == n - burn
+            assert np.array_equal(a, A[:, at + burn:at + n]) and np.array_equal(b, B[:, at + burn:at + n]) and np.array_equal(t, T[:, at + burn:at + n])
+        at += n
+    for c in range(4):
+        for name in ('eta', 'xz', 'z'):
+            assert np.array_equal(one.get(name, c), cut.get(name, c))
+    assert one.stats()['fused_fallbacks'] == 0 and cut.stats()['fused_fallbacks'] == 0
+    one.close()
+    cut.close()
+
+
 @pytest.mark.parametrize('lattice, chains, iters', [((20, 20), 3, 30), ((100, 100), 4, 60), ((37, 91), 6, 40), ((60, 60), 8, 30), ((30, 40), 10, 20), ((50, 50), 19, 20)])
 def test_persistent_solve_is_bit_identical_to_launch_per_step(monkeypatch, lattice, chains, iters):
     """k_iter exchanges g between the workgroups of a chain -- one XCD per chain: plain stores, L1-bypassing loads
