@@ -199,8 +199,10 @@ __device__ inline double pg1_draw(Cursor &c, double z)
 {
     const double Z = 0.5 * fabs(z);
     // (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loops below, and a
-    // wave that never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it)
-    if (!(Z < 1.0e300)) return z - z;
+    // wave that never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it.  The
+    // same for a finite argument so large that the series' coefficients overflow to inf x 0 = NaN, past |z| ~ 1e100: every
+    // comparison of the alternating series is then false and its loop never ends)
+    if (!(Z < 1.0e100)) return (z - z) * __longlong_as_double(0x7ff8000000000000LL);
     const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
     const double ptail = pg_mass_texpon(Z);
     for (;;) {
