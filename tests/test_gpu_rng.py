@@ -111,6 +111,21 @@ def test_the_samplers_omega_b_kernel_draws_what_occ_draw_draws():
     eng.close()
 
 
+def test_device_pg1_leaves_its_loops_on_arguments_no_chain_should_produce():
+    """A wave that never finishes hangs the device.  The sampler's rejection loops end with probability one for any sane
+    argument; for NaN, inf and for finite arguments past |z| ~ 1e100 -- where the alternating series' coefficients overflow to
+    inf x 0 = NaN and every comparison is false -- pg1_draw returns NaN at once (occ_rng.hpp), which the Cholesky
+    factorisation downstream reports.  Large sane arguments still draw."""
+    from occuspytial_amd._engine import device_draw
+    z = np.array([np.nan, np.inf, -np.inf, 1e101, -3e250, 1e99, 1e6, -4e3, 50.0, 0.0] * 32)
+    out = device_draw('pg1', z, key=3, it=1)
+    bad = ~np.isfinite(z) | (np.abs(z) >= 2e100)
+    assert np.isnan(out[bad]).all()
+    assert np.isfinite(out[~bad]).all() and (out[~bad] > 0).all()
+    big = (~bad) & (np.abs(z) >= 4e3)
+    assert np.allclose(out[big] * 2 * np.abs(z[big]), 1.0, rtol=0.2)   # PG(1, z) concentrates at 1 / (2 |z|)
+
+
 def test_wave_sum_forms_agree_bit_for_bit():
     """The engine adds four quantities over a wave in one fixed order (wave_sum: DPP levels); the form k_iter and the
     per-slice readers use transposes the quantities over the lanes of a quad and moves one value instead of four.
