@@ -392,7 +392,10 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
             if (s->rsr.m > RSR_MAX_DIM && !std::getenv("OCC_NO_GRAM32")) {  // large bases: 32 x 32 blocks of G, then the K'u workgroups alone
-                hipLaunchKernelGGL(k_rsr_gram32, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
+                if (c.C > 1 && !std::getenv("OCC_GRAM32_ONE_CHAIN"))  // two chains per workgroup: K streamed once for both
+                    hipLaunchKernelGGL(k_rsr_gram32<2>, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)((c.C + 1) / 2)), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(k_rsr_gram32<1>, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
                 hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)((s->rsr.m + 15) / 16), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, (s->launch_sync ? 1 : 0) | 2);
             } else {
                 hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
@@ -1735,7 +1738,8 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
             HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
         } else {  // the global-memory solve (k_rsrb_*)
-            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
             if ((rc = upload(s, &r.E, Eh, "rsr_E"))) return rc;
             if ((rc = dev_alloc(s, &r.big_eps, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_scal, (size_t)C * 2))) return rc;

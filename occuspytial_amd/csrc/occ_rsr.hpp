@@ -222,73 +222,107 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
 // whose lower-left tile is the transpose of its upper-right one) -- twice the flop per byte, a quarter of the workgroups.
 // Same operands, same instruction order per output element, the 16 partial tiles of a tile added in wave order: the bits of
 // k_rsr_gram.  K's rows are padded to a multiple of 32 columns (zeros).  Dynamic LDS: [4 tiles][16 waves][64 lanes][4] doubles.
+// NC chains per workgroup (grid.y = ceil(C / NC)): K's columns are loaded ONCE for the NC chains and weighted by each chain's
+// omega where they are used -- the kernel streams 2 x 32 columns of K (5 MB at n = 10 000) per workgroup through the Infinity
+// Cache, 16.8 GB per iteration at m = 1 280 with four chains: bound by that stream (7.7 TB/s), not by the matrix cores.  The
+// products row[cc] * w are the ones the one-chain form takes, in the same order per output element: the same bits.
+template <int NC>
 __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram32(const RsrArgs a, int e, int sync_on)
 {
     extern __shared__ __attribute__((aligned(16))) double s_g32[];
-    const int chain = blockIdx.y;
+    const int chain0 = (int)blockIdx.y * NC;
     const bool synced = sync_on && a.sync != nullptr;
     // first kernel of the main stream's sequence: k_z_ob of the previous sequence is complete, the side stream may start
     if (synced && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync_set(a.sync + SYNC_MAIN, a.sync[SYNC_MAIN_SEQ + e]);
-    const ChainScalars &sc = a.scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    bool on[NC];
+    const double *om[NC];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int chain = min(chain0 + c, a.C - 1);
+        const ChainScalars &sc = a.scs[chain];
+        const Ctl ctl = sc.ctl[e];
+        on[c] = chain0 + c < a.C && !(ctl.koff || ctl.it >= sc.it_stop);
+        om[c] = a.omega_b[ctl.it & 1] + (size_t)chain * a.n;
+        any = any || on[c];
+    }
+    if (!any) return;
     const int T2 = (a.m + 31) / 32;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
-    const double *om = a.omega_b[ctl.it & 1] + (size_t)chain * a.n;
     int ba = 0, rem = (int)blockIdx.x;  // upper triangle of 32 x 32 blocks, row by row
     while (rem >= T2 - ba) { rem -= T2 - ba; ++ba; }
     const int bc = ba + rem;
     const bool diag = ba == bc;
     const int ca = ba * 32 + lc, cc = bc * 32 + lc;
-    v4d acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
-    constexpr int NB = 4;  // four-site groups per batch (16 sites): two batches in flight
-    double a0[NB], a1[NB], b0[NB], b1[NB], na0[NB], na1[NB], nb0[NB], nb1[NB];
-    auto load = [&](int i0, double (&x0)[NB], double (&x1)[NB], double (&y0)[NB], double (&y1)[NB]) {
+    v4d acc[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[c][q] = v4d{0.0, 0.0, 0.0, 0.0};
+    constexpr int NB = NC == 1 ? 4 : 2;  // four-site groups per batch: two batches in flight
+    double a0[NB], a1[NB], b0[NB], b1[NB], w[NC][NB], na0[NB], na1[NB], nb0[NB], nb1[NB], nw[NC][NB];
+    auto load = [&](int i0, double (&x0)[NB], double (&x1)[NB], double (&y0)[NB], double (&y1)[NB], double (&ww)[NC][NB]) {
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
             const int i = i0 + 4 * t + lk;
             const bool vi = i < a.n;
             const int ii = vi ? i : 0;
-            const double w = vi ? om[ii] : 0.0;
             const double *row = a.K + (size_t)ii * a.ldk;
             x0[t] = row[ca];
             x1[t] = row[ca + 16];
-            y0[t] = row[cc] * w;
-            y1[t] = row[cc + 16] * w;
+            y0[t] = row[cc];
+            y1[t] = row[cc + 16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ww[c][t] = vi ? om[c][ii] : 0.0;
         }
     };
-    int i0 = wave * 16;
-    if (i0 < a.n) load(i0, a0, a1, b0, b1);
-    for (; i0 < a.n; i0 += 16 * GRAM_WAVES) {
-        const int i1 = i0 + 16 * GRAM_WAVES;
-        if (i1 < a.n) load(i1, na0, na1, nb0, nb1);
+    // A wave's sites are the same in both forms -- 16 consecutive ones out of every 16 x GRAM_WAVES, in ascending order (which
+    // is what decides the bits of a partial tile) -- taken in batches of 4 NB: batch b starts at site_of(b).
+    constexpr int SUBS = 4 / NB;
+    auto site_of = [&](int b) { return wave * 16 + (b / SUBS) * 16 * GRAM_WAVES + (b % SUBS) * 4 * NB; };
+    int b = 0;
+    if (site_of(0) < a.n) load(site_of(0), a0, a1, b0, b1, w);
+    for (; site_of(b) < a.n; ++b) {
+        if (site_of(b + 1) < a.n) load(site_of(b + 1), na0, na1, nb0, nb1, nw);
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1[t], acc01, 0, 0, 0);
-            if (!diag) acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b0[t], acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc11, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double y0 = b0[t] * w[c][t], y1 = b1[t] * w[c][t];
+                acc[c][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], y0, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], y1, acc[c][1], 0, 0, 0);
+                if (!diag) acc[c][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], y0, acc[c][2], 0, 0, 0);
+                acc[c][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], y1, acc[c][3], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < NB; ++t) { a0[t] = na0[t]; a1[t] = na1[t]; b0[t] = nb0[t]; b1[t] = nb1[t]; }
+        for (int t = 0; t < NB; ++t) {
+            a0[t] = na0[t]; a1[t] = na1[t]; b0[t] = nb0[t]; b1[t] = nb1[t];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) w[c][t] = nw[c][t];
+        }
     }
-    // the 16 partial tiles of each of the four tiles, added in wave order (wave q < 4 adds up tile q)
-    auto put = [&](int tile, const v4d &acc) {
+    // the 16 partial tiles of each of the four tiles, added in wave order (wave q < 4 adds up tile q), chain after chain
 #pragma unroll
-        for (int v = 0; v < 4; ++v) s_g32[(((size_t)tile * GRAM_WAVES + wave) * 64 + lane) * 4 + v] = acc[v];
-    };
-    put(0, acc00); put(1, acc01); put(2, acc10); put(3, acc11);
-    __syncthreads();
-    if (wave >= 4 || (diag && wave == 2)) return;
-    const int ra = ba * 32 + (wave >> 1) * 16, rc = bc * 32 + (wave & 1) * 16;  // tile `wave`: rows ra.., columns rc..
-    double *G = a.gram + (size_t)chain * a.m * a.m;
+    for (int c = 0; c < NC; ++c) {
+        if (c > 0) __syncthreads();
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        double t = s_g32[(((size_t)wave * GRAM_WAVES + 0) * 64 + lane) * 4 + v];
+        for (int tile = 0; tile < 4; ++tile)
 #pragma unroll
-        for (int w = 1; w < GRAM_WAVES; ++w) t += s_g32[(((size_t)wave * GRAM_WAVES + w) * 64 + lane) * 4 + v];  // fixed order
-        const int r = ra + 4 * v + lk, c = rc + lc;
-        if (r < a.m && c < a.m) G[(size_t)r * a.m + c] = t;
+            for (int v = 0; v < 4; ++v) s_g32[(((size_t)tile * GRAM_WAVES + wave) * 64 + lane) * 4 + v] = acc[c][tile][v];
+        __syncthreads();
+        if (on[c] && wave < 4 && !(diag && wave == 2)) {
+            const int ra = ba * 32 + (wave >> 1) * 16, rc = bc * 32 + (wave & 1) * 16;  // tile `wave`: rows ra.., columns rc..
+            double *G = a.gram + (size_t)(chain0 + c) * a.m * a.m;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double t = s_g32[(((size_t)wave * GRAM_WAVES + 0) * 64 + lane) * 4 + v];
+#pragma unroll
+                for (int ww = 1; ww < GRAM_WAVES; ++ww) t += s_g32[(((size_t)wave * GRAM_WAVES + ww) * 64 + lane) * 4 + v];  // fixed order
+                const int r = ra + 4 * v + lk, cidx = rc + lc;
+                if (r < a.m && cidx < a.m) G[(size_t)r * a.m + cidx] = t;
+            }
+        }
     }
 }
 __host__ __device__ inline int rsr_gram32_blocks(int m)
