@@ -2372,6 +2372,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     if (done_min < n_iter && s->side_enabled && !s->flag_sync && s->rsr.m == 0) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
     const int64_t seq_per_enqueue = (s->flag_sync || s->rsr.m > 0) ? GRAPH_SEQ : 1;
 
+    int64_t stuck = 0;  // sequences enqueued since a chain last advanced
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
         // solve into the next sequence; finished chains idle.  No host work inside a batch.
@@ -2392,11 +2393,23 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
                          std::chrono::duration<double, std::micro>(hl2 - hl0).count() / batch);
         }
         if ((rc = check_device_errors(s, h))) return rc;
+        const int64_t done_before = done_min;
         done_min = n_iter;
         unsigned long long tot = 0, sq = 0, solves = 0;
         for (int ch = 0; ch < C; ++ch) {
             done_min = std::min<int64_t>(done_min, (int64_t)h[ch].ctl[s->parity].it - (int64_t)h[ch].it_base);
             tot += h[ch].krylov_total; sq += h[ch].krylov_sq_total; solves += h[ch].solves;
+        }
+        // (a batch of sequences that advances no chain and reports no error must not be repeated for ever: whatever left the
+        // chains' window in that state, the caller gets an error, not a call that never returns)
+        // (a solve carried over many short sequences -- launch-per-step path with a small cap -- legitimately spends whole
+        // batches inside one iteration: the bound is in sequences, beyond what the longest admissible solve can take)
+        if (done_min <= done_before && done_min < n_iter) {
+            stuck += batch;
+            if (stuck > std::max<int64_t>(8192, 4 * (int64_t)c.maxiter))
+                return set_error(s, OCC_E_HIP, "the chains made no progress over thousands of sequences (window of iterations not open on the device?)");
+        } else {
+            stuck = 0;
         }
         if (std::getenv("OCC_VERBOSE")) {
             unsigned long long car = 0;
