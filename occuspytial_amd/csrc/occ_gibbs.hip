@@ -849,12 +849,33 @@ StreamPair *acquire_pair(int device, const std::vector<uint32_t> &m_main, const 
     std::lock_guard<std::mutex> g(g_pool_mu);
     int masked = 0, cap = MAX_MASKED_PAIRS;
     if (const char *mc = std::getenv("OCC_MAX_MASKED_PAIRS")) cap = std::max(0, std::atoi(mc));  // tests
+    int live_masked = 0;
+    StreamPair *match = nullptr;
     for (StreamPair *p : slot.pairs) {
-        if (p->m_main == m_main && p->m_side == m_side) {
-            p->refs += 1;
-            return p;
-        }
+        if (p->m_main == m_main && p->m_side == m_side) match = p;
         masked += p->m_main.empty() ? 0 : 1;
+        live_masked += (!p->m_main.empty() && p->refs > 0) ? 1 : 0;
+    }
+    // (an idle pair -- refs 0, kept by release_pair -- comes back into use as it is; the cap is on the partitions engines HOLD)
+    if (match && (match->refs > 0 || m_main.empty() || live_masked < cap)) {
+        match->refs += 1;
+        return match;
+    }
+    // at the cap: idle masked pairs (no engine holds them) make room first
+    if (!m_main.empty() && masked >= cap) {
+        for (size_t i = 0; i < slot.pairs.size() && masked >= cap;) {
+            StreamPair *q = slot.pairs[i];
+            if (q->refs == 0 && !q->m_main.empty()) {
+                slot.pairs.erase(slot.pairs.begin() + (long)i);
+                (void)hipStreamDestroy(q->side);
+                (void)hipStreamDestroy(q->main);
+                delete q;
+                g_stream_gen.fetch_add(1);
+                masked -= 1;
+            } else {
+                ++i;
+            }
+        }
     }
     if (!m_main.empty() && masked >= cap) {
         *why = std::to_string(masked) + " CU-masked stream pairs are alive on device " + std::to_string(device) +
@@ -896,14 +917,15 @@ void release_pair(StreamPair *p)
     DeviceSlot &slot = device_slot(p->device);
     std::lock_guard<std::mutex> g(g_pool_mu);
     if (--p->refs > 0) return;
-    slot.pairs.erase(std::remove(slot.pairs.begin(), slot.pairs.end(), p), slot.pairs.end());
+    // The last engine that held the pair is gone: the streams stay, idle, for the next engine that wants this partition (a
+    // process that creates and closes engines one after the other -- a test-suite, a parameter sweep -- then keeps ONE set of
+    // hardware queues instead of creating and destroying CU-masked streams by the dozen; the stops inside occ_create seen
+    // in round 3, DESIGN 6.1, came from runs that did exactly that).  acquire_pair destroys idle pairs when it needs their
+    // place under the cap; the rest go with the process.
     (void)hipSetDevice(p->device);
     (void)hipStreamSynchronize(p->main);
     (void)hipStreamSynchronize(p->side);
-    (void)hipStreamDestroy(p->side);
-    (void)hipStreamDestroy(p->main);
-    delete p;
-    g_stream_gen.fetch_add(1);
+    (void)slot;
 }
 
 // live pairs of a device: {masked, unmasked} (occ_stats, OCC_VERBOSE)
@@ -912,7 +934,8 @@ void count_pairs(int device, int *masked, int *plain)
     DeviceSlot &slot = device_slot(device);
     std::lock_guard<std::mutex> g(g_pool_mu);
     *masked = *plain = 0;
-    for (StreamPair *p : slot.pairs) (p->m_main.empty() ? *plain : *masked) += 1;
+    for (StreamPair *p : slot.pairs)
+        if (p->refs > 0) (p->m_main.empty() ? *plain : *masked) += 1;  // (idle pairs wait for a taker: not live)
 }
 
 void adopt_pair(occ_sampler *s, StreamPair *p)
