@@ -412,6 +412,18 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     const Ctl ctl = sc.ctl[e];
     const uint32_t it_stop = sc.it_stop;
     const int err0 = sc.err;
+    // ... and, on the wave that will draw tau, the first 256 partial sums of eta'Q eta (k_z_ob's, cold): their latency runs
+    // beside the claim's instead of in front of phase A's barrier
+    double quad_pre[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!SHARE || threadIdx.x < 64) {  // (= `lead` below)
+        const double *pq0 = ia.part_quad + chain64 * a.nb_n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bb = (int)(threadIdx.x & 63) + 64 * r;
+            const double t = pq0[min(bb, a.nb_n - 1)];
+            quad_pre[r] = (bb < a.nb_n) ? t : 0.0;
+        }
+    }
     if (XL) {
         if (threadIdx.x == 0) s_claim = ticket;
         __syncthreads();
@@ -502,15 +514,22 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     double vraw[NW];
 #pragma unroll
     for (int kk = 0; kk < NW; ++kk) { jraw[kk] = 0; vraw[kk] = 0.0; }
+    // DIA (KryArgs::dia_*: the off-diagonals lie on at most eight diagonals with one value each -- any unweighted lattice;
+    // the 8-wide window only): a neighbour's index is the site's plus a constant, so the gathers of x_0 go out WITH the first
+    // level of loads (row clamped; the mask byte decides the coefficient afterwards) instead of behind the column indices --
+    // one cold memory latency less in front of p_0.  Same neighbours in the same order as the stored slots (ascending
+    // columns), absent ones with coefficient 0: the same bits (k_minres and k_tiles take the same form).
+    const bool dia = NW == 8 && a.dia_n > 0;
+    unsigned dmask_raw = 0u;
     auto neighbours = [&]() {
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) {
-            const bool has = act && kk < width;
+            const bool has = dia ? (act && kk < a.dia_n && ((dmask_raw >> kk) & 1u)) : (act && kk < width);
             const int j = has ? jraw[kk] : ic;
             off[kk] = has ? j * 16 : myoff;
-            av[kk] = vraw[kk];
+            av[kk] = dia ? (has ? a.dia_val[kk & 7] : 0.0) : vraw[kk];
             hasmask |= has ? (1u << kk) : 0u;
-            xn[kk] = X0[j];
+            if (!dia) xn[kk] = X0[j];
         }
     };
     if (!scalar_wave) {
@@ -519,11 +538,20 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         xb = xdot(ia.Xt, n, ic, sc.beta, ia.p);
         x = X0[ic];
         qd = a.qdiag[ic];
+        if (dia) {
+            dmask_raw = a.dia_mask[ic];
 #pragma unroll
-        for (int kk = 0; kk < NW; ++kk) {
-            const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
-            jraw[kk] = a.sell_col[slot];
-            vraw[kk] = a.sell_val[slot];
+            for (int kk = 0; kk < NW; ++kk) {
+                jraw[kk] = min(max(ic + (kk < a.dia_n ? a.dia_off[kk & 7] : 0), 0), n - 1);
+                xn[kk] = X0[jraw[kk]];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk) {
+                const int slot = base + ((kk < width) ? kk * 64 : 0) + (ic & 63);  // always inside the (padded) slot arrays
+                jraw[kk] = a.sell_col[slot];
+                vraw[kk] = a.sell_val[slot];
+            }
         }
         if (!SW) neighbours();  // (without a scalar wave nobody waits at the barrier below: no reason to hold the indices across it)
     }
@@ -547,7 +575,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     if (lead) {
         double q = 0.0;
         const double *pq = ia.part_quad + chain64 * a.nb_n;
-        for (int b0 = lane; b0 < a.nb_n; b0 += 256) {
+        // tau's standard gamma variate was drawn one iteration ahead by k_noise (side stream), like the rest of the noise:
+        // 4 000 cycles of dependent f64 arithmetic that used to sit here, in front of every load of the phase.  (Loaded first:
+        // its latency runs beside that of the partial sums, not behind their reduction.)
+        const double gvar = synced ? load_agent(&sc.tau_gamma[it & 1]) : sc.tau_gamma[it & 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q += quad_pre[r];  // (the first round: loaded at kernel entry; the same order of additions)
+        for (int b0 = lane + 256; b0 < a.nb_n; b0 += 256) {
             double v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -560,9 +594,6 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         }
         q = wave_sum(q);
         const double rate = 0.5 * q + ia.tau_rate;
-        // tau's standard gamma variate was drawn one iteration ahead by k_noise (side stream), like the rest of the noise:
-        // 4 000 cycles of dependent f64 arithmetic that used to sit here, in front of every load of the phase
-        const double gvar = synced ? load_agent(&sc.tau_gamma[it & 1]) : sc.tau_gamma[it & 1];
         tau = (1.0 / rate) * gvar;
         if (writer) sc.tau = tau;
         if (SHARE && threadIdx.x == 0) s_bcast[0] = tau;
