@@ -843,9 +843,36 @@ int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
 // ---- the pooled stream pairs (see StreamPair above) --------------------------------------------------------------------
 // -> the pair with these masks on `device` (created when no engine holds one yet); nullptr when it cannot be had -- the cap
 // on masked pairs is reached, or the runtime cannot create the streams -- with the reason in *why.  The device is current.
+// At process exit: the idle pairs go before the runtime does (registered at the first acquisition, so it runs ahead of the
+// finalisers of everything loaded before this library; a profiler that walks the live streams at its own finalisation --
+// rocprofv3 7.2 does -- otherwise meets streams nobody will ever destroy: SIGSEGV inside __cxa_finalize).
+static void pool_at_exit()
+{
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (auto &kv : g_slots) {
+        std::vector<StreamPair *> &pairs = kv.second->pairs;
+        for (size_t i = 0; i < pairs.size();) {
+            StreamPair *q = pairs[i];
+            if (q->refs == 0) {
+                (void)hipSetDevice(q->device);
+                (void)hipStreamSynchronize(q->main);
+                (void)hipStreamSynchronize(q->side);
+                (void)hipStreamDestroy(q->side);
+                (void)hipStreamDestroy(q->main);
+                pairs.erase(pairs.begin() + (long)i);
+                delete q;
+            } else {
+                ++i;
+            }
+        }
+    }
+}
+
 StreamPair *acquire_pair(int device, const std::vector<uint32_t> &m_main, const std::vector<uint32_t> &m_side, std::string *why)
 {
     DeviceSlot &slot = device_slot(device);
+    static std::once_flag at_exit_once;
+    std::call_once(at_exit_once, [] { std::atexit(pool_at_exit); });
     std::lock_guard<std::mutex> g(g_pool_mu);
     int masked = 0, cap = MAX_MASKED_PAIRS;
     if (const char *mc = std::getenv("OCC_MAX_MASKED_PAIRS")) cap = std::max(0, std::atoi(mc));  // tests
