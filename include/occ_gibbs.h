@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 5
+#define OCC_ABI_VERSION 6
 #define OCC_MAX_COVARIATES 32 /* p and q limit.  Up to 8 of each: kernels with the p x p / q x q accumulators in registers and the
                                 fused iteration kernel; 9 to 32: generic kernels (run-time p and q, terms reduced one at a time,
                                 Cholesky factor in LDS) on the launch-per-step path */
@@ -159,6 +159,9 @@ typedef struct occ_stats {
                                         events of hipExtLaunchKernel, i.e. the begin / end timestamps of the dispatch's
                                         completion signal -- what rocprofv3 --kernel-trace reports for a kernel (launch ramp
                                         and end-of-kernel release included, which the in-kernel clock cannot see) */
+    /* ABI 6 */
+    int32_t stream_pairs_idle;    /* pairs no engine holds, kept for the next taker of their CU partition (not live) */
+    int32_t stream_pairs_evicted; /* idle CU-masked pairs this process destroyed to make room under the cap of four, all devices */
 } occ_stats;
 int occ_get_stats(occ_sampler *s, occ_stats *out);
 
@@ -205,7 +208,7 @@ const char *occ_comm_last_error(const occ_comm *comm); /* NULL: error of the las
 int occ_create_distributed(const occ_problem *problem /* root only */, occ_comm *comm, int32_t root, int32_t n_chains,
                            const uint64_t *keys, occ_sampler **out);
 const char *occ_group_transport(const occ_sampler *s);
-int occ_synchronize(occ_sampler *s); /* hipDeviceSynchronize on the handle's device */
+int occ_synchronize(occ_sampler *s); /* the handle's streams have drained (deadline poll), then hipDeviceSynchronize on its device */
 
 /* ---- per-conditional entry points with INJECTED variates ---------------------------------------------------
  * One conditional update of ONE chain of the ICAR model, run on the device by the kernels of the launch-per-step path

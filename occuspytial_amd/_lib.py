@@ -42,6 +42,7 @@ class OccStats(C.Structure):
         ('repromotions', C.c_int32), ('stream_probes', C.c_int32), ('handover_mode', C.c_int32),
         ('stream_pairs_masked', C.c_int32), ('stream_pairs_plain', C.c_int32), ('demoted', C.c_int32),
         ('profile_iter_dispatch_us', C.c_double),
+        ('stream_pairs_idle', C.c_int32), ('stream_pairs_evicted', C.c_int32),
     ]
 
 
@@ -91,7 +92,7 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built, or no usable gfx950 device)."""
 
 
-ABI_VERSION = 5  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
+ABI_VERSION = 6  # OCC_ABI_VERSION of include/occ_gibbs.h this binding was written against
 
 
 def load():

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "occ_comm.hpp"
@@ -42,8 +43,9 @@ static_assert(K_ITER + 1 == OCC_N_KERNEL_KINDS, "kernel kinds out of sync with t
 // kept a dozen samplers alive ran every device-side hand-over of a new engine into its time-out -- and the probe at
 // creation could not see it, because a fresh queue starts out mapped and loses its slot later, when other queues
 // get work.  Hence:
-//   * one (main, side) pair per (process, device, CU partition), shared by every engine that wants that partition and
-//     released (streams destroyed) with the last of them;
+//   * one (main, side) pair per (process, device, CU partition), shared by every engine that wants that partition; when
+//     the last of them closes the pair stays, IDLE, for the next taker of the partition (release_pair) -- idle pairs are
+//     destroyed only to make room under the cap (acquire_pair) and at process exit (pool_at_exit);
 //   * at most MAX_MASKED_PAIRS masked pairs alive per device; an engine that would need one more takes the unmasked
 //     pair and hands over through events -- decided by counting, not by probing;
 //   * engines of one device run their calls ONE AFTER THE OTHER (DeviceSlot::busy, taken by every entry point): they
@@ -55,6 +57,7 @@ struct StreamPair {
     std::vector<uint32_t> m_main, m_side;  // empty: the unmasked pair (priority streams)
     hipStream_t main = nullptr, side = nullptr;
     int refs = 0;
+    bool dead = false;  // a host wait on one of its streams ran into its deadline, or the process is exiting: never handed out again
 };
 struct DeviceSlot {
     std::recursive_mutex busy;        // held for the length of every entry point that touches the device through a handle
@@ -64,6 +67,7 @@ constexpr int MAX_MASKED_PAIRS = 4;  // per device: 8 of its 24 hardware queues
 std::mutex g_pool_mu;
 std::map<int, DeviceSlot *> g_slots;  // never freed: a handle's lease may outlive every pair
 std::atomic<unsigned long long> g_stream_gen{1};
+std::atomic<long long> g_pairs_evicted{0};  // idle masked pairs destroyed to make room under the cap (occ_stats)
 
 DeviceSlot &device_slot(int device)
 {
@@ -152,22 +156,24 @@ struct occ_sampler {
     bool demoted = false;             // running without device-side waits after one of them gave up
     int promote_wait = 0, promote_backoff = 1;  // calls until the next attempt to come back; doubled after a failed one
     std::string pair_note;            // why the engine did not get the masked pair it wanted (empty: it did, or wanted none)
-    // A call of a dozen iterations is mostly host round trips and small stream operations around the kernels (round 2: ~170 us
-    // per occ_run beyond its iterations, 12 % of the driver's 20-step bench call).  Round 3: the chains' scalars as the last
-    // successful occ_run read them stay on the host (sc_host; dropped by anything else that touches the device state), so the
-    // next call neither waits for the device nor reads; counters are re-zeroed only after a call that did not end cleanly;
-    // the records and the final scalars come back behind ONE synchronisation.
-    std::vector<ChainScalars> sc_host;
-    bool sc_host_valid = false, clean_exit = false;
+    // The chains' scalars as the last occ_run / occ_step read them at its end (round 3: a call of a dozen iterations was mostly
+    // host round trips -- ~170 us per occ_run beyond its iterations).  ONE flag says whether the device still holds exactly
+    // these: `mirror_ok`, set at the clean end of occ_run / occ_step and dropped by open_window (the next call's kernels
+    // change the scalars) and by every other writer of Ctx::sc (write_scalars, occ_profile).  Round 3 had five flags
+    // (snap_fresh, sc_host_valid, window_open, clock_fresh, clean_exit) for what is now this one and `clean_exit`.
+    std::vector<ChainScalars> mirror;
+    bool mirror_ok = false;
+    bool clean_exit = false;  // the last call through open_window ended cleanly: the claim / abort words are as the kernels leave them
     // Page-locked staging for what crosses PCIe on every call (an asynchronous copy to or from pageable memory is staged by
     // the runtime and, device to host, waits for the stream: two serial round trips at the end of every occ_run):
-    // pin_sc = [2][C] ChainScalars (0: set_window's upload, 1: read_scalars' read-back), pin_rec = the recorded rows.
+    // pin_sc = [2][C] ChainScalars (0: open_window's upload, 1: read_scalars' read-back), pin_rec = the recorded rows.
     ChainScalars *pin_sc = nullptr;
     double *pin_rec = nullptr;
     size_t pin_rec_cap = 0;
     bool marks_done = false;       // ev1 and the copy of the records are enqueued behind the call's last batch
-    std::vector<ChainScalars> win_sc;  // set_window's copy of the chains' scalars (in flight to the device when it returns)
-    bool snap_fresh = false;           // snap_sc was read by the snapshot of THIS call: set_window need not read again
+    bool debug_close_window = false;  // tests (occ_set_state "debug_close_window"): the NEXT call's window is opened with zero iterations on the device
+    bool wedged = false;           // a host wait ran into its deadline: the streams never drained; nothing of this engine is freed or reused
+    int probe_wait = 0, probe_backoff = 1;  // calls until the stream probe is asked again after a negative answer
     int share_cum[2][9] = {};  // cumulative CUs of the main / side stream's mask over the XCDs (Ctx::share_on)
     int main_cus = 0;        // > 0: the main stream is restricted to this many CUs, the side stream to the others
     // stream hand-overs by device-side sequence counters (Ctx::sync) instead of event nodes: only with the CU
@@ -178,9 +184,6 @@ struct occ_sampler {
     int tpb = 256;
     std::vector<void *> allocs;
     std::string err;
-    bool clock_fresh = false;  // k_snapshot has just reset k_iter's clock words (run_impl does not do it again)
-    bool window_open = false;  // ... and opened this window of iterations on the device (set_window does not upload it again)
-    int64_t window_n = 0, window_burnin = 0, window_keep = 0;
     int launch_rc = 0;       // first failed kernel launch since the last take_launch_rc()
     std::string launch_err;
     // launch-sequence ("slot") parity: the kernels of the next sequence read ChainScalars::ctl[parity]
@@ -231,20 +234,99 @@ constexpr int GRAPH_SEQ = 2;  // (16 per graph measured the same: the boundary b
         }                                                                                          \
     } while (0)
 
+// ---- host waits have a deadline and name themselves ------------------------------------------------------------------
+// Every device-side wait of the engine is bounded (SYNC_SPIN_LIMIT, ITER_SPIN_LIMIT), so a host wait on one of its streams
+// that outlasts seconds is not the kernels' doing (round 3 recorded two such stops, one inside occ_create and one inside
+// occ_run, with nothing but Python frames to go by: DESIGN 6.4).  The engine therefore never blocks inside
+// hipStreamSynchronize / hipDeviceSynchronize: it polls hipStreamQuery against a deadline (OCC_HOST_WAIT_S, default 20 s)
+// and a wait that runs into it returns OCC_E_HIP naming the call site and the engine's host-side state; the engine is then
+// `wedged` -- its streams hold work that never completed, so nothing of it is freed, destroyed or handed to another engine.
+static std::string host_state(const occ_sampler *s)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof(buf),
+                  "device %d, %d chains, n %d; path: persistent %d xcd_local %d tiles %d rsr_m %d; hand-overs: flag_sync %d side_enabled %d "
+                  "event_nodes %d demoted %d streams_serialised %d; main_cus %d (%s pair); parity %d graph_parity %d snap_parity %d; "
+                  "mirror_ok %d clean_exit %d need_prologue %d; graph launches %lld, eager iterations %lld, fallbacks %lld",
+                  s->device, s->ctx.C, s->ctx.n, (int)s->persistent, (int)s->xcd_local, (int)s->tiles, s->rsr.m, (int)s->flag_sync, (int)s->side_enabled,
+                  (int)s->event_nodes, (int)s->demoted, (int)s->streams_serialised, s->main_cus, (s->pair && !s->pair->m_main.empty()) ? "CU-masked" : "plain",
+                  s->parity, s->graph_parity, s->snap_parity, (int)s->mirror_ok, (int)s->clean_exit, (int)s->need_prologue,
+                  (long long)s->graph_launches, (long long)s->eager_iterations, (long long)s->fused_fallbacks);
+    return buf;
+}
+static double host_wait_limit_s()
+{
+    const char *e = std::getenv("OCC_HOST_WAIT_S");
+    const double v = e ? std::atof(e) : 20.0;
+    return v > 0.0 ? v : 20.0;
+}
+// hipSuccess when `st` has drained; hipErrorNotReady after the deadline (*late = true); any other error as the runtime gave it
+static hipError_t poll_stream(hipStream_t st, bool *late)
+{
+    *late = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = host_wait_limit_s();
+    for (unsigned polls = 1;; ++polls) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();  // (not ready is not an error to keep)
+        if ((polls & 63u) == 0u) {
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (sec > limit) { *late = true; return hipErrorNotReady; }
+            if (sec > 0.002) std::this_thread::yield();  // (a long wait: the host thread need not own a core)
+        }
+    }
+}
+static int wait_on(occ_sampler *s, hipStream_t st, const char *func, int line)
+{
+    const std::string what = std::string(func) + " (occ_gibbs.hip:" + std::to_string(line) + ")";
+    if (!st) return OCC_OK;
+    bool late = false;
+    const hipError_t e = poll_stream(st, &late);
+    if (e == hipSuccess) return OCC_OK;
+    if (late) {
+        s->wedged = true;
+        if (s->pair) s->pair->dead = true;
+        char lim[64];
+        std::snprintf(lim, sizeof(lim), "%.0f s", host_wait_limit_s());
+        s->err = std::string("host wait `") + what + "`: the " + (st == s->side ? "side" : "main") + " stream did not drain within " + lim +
+                 " (every device-side wait of the engine is bounded far below that: the queue is not being served); " + host_state(s);
+    } else {
+        s->err = std::string("host wait `") + what + "`: " + hipGetErrorString(e);
+    }
+    return OCC_E_HIP;
+}
+#define WAIT_TRY(st)                                           \
+    do {                                                       \
+        const int w_ = wait_on(s, (st), __func__, __LINE__);   \
+        if (w_ != OCC_OK) return w_;                           \
+    } while (0)
+
 // Copies and fills are ordered on the engine's OWN stream, never on the legacy default stream: a default-stream operation
 // synchronises implicitly with every blocking stream of the device (the CU-masked streams are blocking), which
 // invalidates a stream capture that another host thread -- another engine on the same device -- has open at that moment.
+static hipError_t drain_for_copy(occ_sampler *s)
+{
+    bool late = false;
+    const hipError_t e = poll_stream(s->stream, &late);
+    if (late) {  // (HIP_TRY reports the expression; the state goes to stderr once, here)
+        s->wedged = true;
+        if (s->pair) s->pair->dead = true;
+        std::fprintf(stderr, "[occ] a copy or fill on the main stream did not complete within %.0f s: %s\n", host_wait_limit_s(), host_state(s).c_str());
+    }
+    return e;
+}
 static hipError_t copy_on(occ_sampler *s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
     if (!s->stream) return hipMemcpy(dst, src, bytes, kind);
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s->stream);
-    return e != hipSuccess ? e : hipStreamSynchronize(s->stream);
+    return e != hipSuccess ? e : drain_for_copy(s);
 }
 static hipError_t fill_on(occ_sampler *s, void *dst, int value, size_t bytes)
 {
     if (!s->stream) return hipMemset(dst, value, bytes);
     const hipError_t e = hipMemsetAsync(dst, value, bytes, s->stream);
-    return e != hipSuccess ? e : hipStreamSynchronize(s->stream);
+    return e != hipSuccess ? e : drain_for_copy(s);
 }
 
 template <class T>
@@ -501,19 +583,19 @@ int take_launch_rc(occ_sampler *s)
 int read_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
 {
     h.resize(s->ctx.C);
-    if (s->flag_sync && s->side) HIP_TRY(hipStreamSynchronize(s->side));  // its last k_noise is not waited for by the main stream
+    if (s->flag_sync) WAIT_TRY(s->side);  // its last k_noise is not waited for by the main stream
     if (!s->pin_sc) HIP_TRY(hipHostMalloc((void **)&s->pin_sc, 2 * sizeof(ChainScalars) * h.size(), hipHostMallocDefault));
     ChainScalars *back = s->pin_sc + h.size();
     HIP_TRY(hipMemcpyAsync(back, s->ctx.sc, sizeof(ChainScalars) * h.size(), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     std::memcpy(h.data(), back, sizeof(ChainScalars) * h.size());
     return OCC_OK;
 }
 int write_scalars(occ_sampler *s, const std::vector<ChainScalars> &h)
 {
-    s->sc_host_valid = false;  // (whoever writes them has changed what the host's copy stood for)
+    s->mirror_ok = false;  // (whoever writes them has changed what the host's copy stood for)
     HIP_TRY(hipMemcpyAsync(s->ctx.sc, h.data(), sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     return OCC_OK;
 }
 
@@ -551,7 +633,7 @@ int eager_krylov(occ_sampler *s, int k_from, int *k_last)
         LAUNCH(s, s->stream, K_MINRES, s->parity, k);
         if (k < 4) continue;
         HIP_TRY(hipMemcpyAsync(slots.data(), s->ctx.slots, sizeof(Slot) * slots.size(), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        WAIT_TRY(s->stream);
         if (int lrc = take_launch_rc(s)) return lrc;
         bool all = true;
         for (int c = 0; c < s->ctx.C; ++c) all = all && slots[(size_t)c * NSLOT + (k & (NSLOT - 1))].done;
@@ -656,7 +738,7 @@ int build_graph(occ_sampler *s, int cap)
 {
     const bool verbose = std::getenv("OCC_VERBOSE") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     destroy_head(s);
     int rc;
     if (s->rsr.m > 0 && !s->flag_sync) {  // reduced-rank model: GRAPH_SEQ iterations (alternating parity) on the main stream
@@ -679,7 +761,7 @@ int build_graph(occ_sampler *s, int cap)
         // the counters alone) would read the older of the two -- one sequence behind the side stream, whose gate then
         // waits for a number the main stream never announces (found by the MINRES-limit test, round 3).  Both streams are
         // idle here.  (SYNC_DEBUG, the tests' broken-hand-over word, is not a counter and stays.)
-        if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+        WAIT_TRY(s->side);
         HIP_TRY(fill_on(s, s->ctx.sync, 0, sizeof(unsigned) * SYNC_DEBUG));
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
         for (int t = 0; t < GRAPH_SEQ; ++t) {
@@ -797,45 +879,70 @@ int enqueue_sequence(occ_sampler *s)
     return take_launch_rc(s);
 }
 
-int set_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep)
+// The chains' scalars: the host's mirror when it still stands for the device (mirror_ok), else a read.
+int get_scalars(occ_sampler *s, std::vector<ChainScalars> &h)
 {
-    // (a call of a dozen iterations is all host round trips: the scalars the snapshot has just read are not read again, and
-    // what goes to the device is ordered on the stream ahead of the kernels -- no wait; win_sc is a member because the
-    // copy outlives this function, and the next write to it follows a stream synchronisation)
-    std::vector<ChainScalars> &h = s->win_sc;
-    if (s->snap_fresh) {
-        h = s->snap_sc;
-        s->snap_fresh = false;
-    } else if (s->sc_host_valid) {  // (what the last call read at its end)
-        h = s->sc_host;
-    } else {
-        int rc = read_scalars(s, h);
-        if (rc) return rc;
+    if (s->mirror_ok) { h = s->mirror; return OCC_OK; }
+    return read_scalars(s, h);
+}
+
+// Head of every occ_run / occ_step / occ_profile: opens the call's WINDOW of iterations in the chains' scalars on the
+// device -- it_base = the iteration the chain is at, it_stop = it_base + n_iter, burnin, keep, no carried solve -- in
+// front of the call's kernels on the main stream, without waiting for it.  Two forms, one decision (round 3 spread it
+// over snapshot_take / set_window and five host flags):
+//   snapshot (paths with device-side waits: the call can be re-run): ONE kernel, k_snapshot, copies eta, z, x (theta) of every
+//     chain to the snapshot buffers, resets k_iter's clock words (run = true) and makes the window's edits ON THE DEVICE;
+//     the scalars as they were BEFORE the edits stay on the host in snap_sc (what fallback_to_launch_per_step restores);
+//   upload (everything else): the host edits its copy of the scalars and sends it (page-locked staging, asynchronous).
+// The host's mirror is dropped either way: the kernels that follow change the scalars.
+int open_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep, bool snapshot, bool run)
+{
+    const Ctx &c = s->ctx;
+    std::vector<ChainScalars> h;
+    int rc = get_scalars(s, h);
+    if (rc) return rc;
+    s->mirror_ok = false;
+    // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
+    // error may have left them anywhere)
+    if (!s->clean_exit) {  // (the last call through here did not end cleanly, or there was none)
+        if (c.claim) HIP_TRY(hipMemsetAsync(c.claim, 0, sizeof(unsigned) * (size_t)c.C * 16, s->stream));
+        if (c.sync) HIP_TRY(hipMemsetAsync(c.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
     }
-    s->sc_host_valid = false;
+    s->clean_exit = false;  // until the call says otherwise
+    // tests (occ_set_state "debug_close_window"): the device gets a window of ZERO iterations while the host expects n_iter
+    const uint32_t dev_n = s->debug_close_window ? 0u : (uint32_t)n_iter;
+    s->debug_close_window = false;
+    if (snapshot) {
+        const size_t Cn = (size_t)c.C * c.n;
+        if (!s->snap_eta) {
+            if ((rc = dev_alloc(s, &s->snap_eta, Cn, false))) return rc;
+            if ((rc = dev_alloc(s, &s->snap_z, Cn, false))) return rc;
+            if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
+            if (s->rsr.m > 0 && (rc = dev_alloc(s, &s->snap_theta, (size_t)c.C * s->rsr.m, false))) return rc;
+        }
+        s->snap_sc = h;
+        s->snap_parity = s->parity;
+        hipLaunchKernelGGL(k_snapshot, dim3((unsigned)std::min<size_t>((Cn + 255) / 256, 2048)), dim3(256), 0, s->stream, c.eta, s->snap_eta, c.z, s->snap_z, c.Xv, s->snap_x,
+                           (unsigned long long)Cn, s->rsr.m > 0 ? s->rsr.theta : nullptr, s->snap_theta, (unsigned long long)c.C * (unsigned long long)std::max(s->rsr.m, 0),
+                           run ? c.iter_clock : nullptr, c.sc, c.C, s->parity, dev_n, (uint32_t)burnin, (uint32_t)keep);
+        if (hipGetLastError() != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_snapshot failed");
+        return OCC_OK;
+    }
     for (auto &sc : h) {
         Ctl &ctl = sc.ctl[s->parity];
         sc.it_base = ctl.it;
-        sc.it_stop = ctl.it + (uint32_t)n_iter;
+        sc.it_stop = ctl.it + dev_n;
         sc.burnin = (uint32_t)burnin;
         sc.keep = (uint32_t)keep;
         ctl.koff = 0;
     }
-    // (the slot counters of the one-XCD forms are zero between sequences -- k_z_ob resets them; a call that ended in an
-    // error may have left them anywhere)
-    if (!s->clean_exit) {  // (the last call through here did not end cleanly, or there was none)
-        if (s->ctx.claim) HIP_TRY(hipMemsetAsync(s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16, s->stream));
-        if (s->ctx.sync) HIP_TRY(hipMemsetAsync(s->ctx.sync + SYNC_ABORT, 0, sizeof(unsigned), s->stream));
-    }
-    s->clean_exit = false;  // until the call says otherwise
-    if (s->window_open && s->window_n == n_iter && s->window_burnin == burnin && s->window_keep == keep) {
-        s->window_open = false;  // (k_snapshot has made these edits on the device, in front of this call's kernels)
-        return OCC_OK;
-    }
-    s->window_open = false;
     if (!s->pin_sc) HIP_TRY(hipHostMalloc((void **)&s->pin_sc, 2 * sizeof(ChainScalars) * h.size(), hipHostMallocDefault));
-    std::memcpy(s->pin_sc, h.data(), sizeof(ChainScalars) * h.size());  // (free again: the last copy from it was followed by a stream synchronisation)
-    HIP_TRY(hipMemcpyAsync(s->ctx.sc, s->pin_sc, sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
+    std::memcpy(s->pin_sc, h.data(), sizeof(ChainScalars) * h.size());  // (free again: the last copy from it was followed by a wait for the stream)
+    HIP_TRY(hipMemcpyAsync(c.sc, s->pin_sc, sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
+    if (run && c.iter_clock) {  // k_iter's clock counts this run only
+        HIP_TRY(hipMemsetAsync(c.iter_clock, 0xff, sizeof(unsigned long long), s->stream));       // [0] = ~0: the earliest start so far
+        HIP_TRY(hipMemsetAsync(c.iter_clock + 1, 0, 3 * sizeof(unsigned long long), s->stream));  // [1] latest end, [2] sum, [3] launches
+    }
     return OCC_OK;
 }
 
@@ -850,20 +957,20 @@ static void pool_at_exit()
 {
     std::lock_guard<std::mutex> g(g_pool_mu);
     for (auto &kv : g_slots) {
-        std::vector<StreamPair *> &pairs = kv.second->pairs;
-        for (size_t i = 0; i < pairs.size();) {
-            StreamPair *q = pairs[i];
-            if (q->refs == 0) {
-                (void)hipSetDevice(q->device);
-                (void)hipStreamSynchronize(q->main);
-                (void)hipStreamSynchronize(q->side);
-                (void)hipStreamDestroy(q->side);
-                (void)hipStreamDestroy(q->main);
-                pairs.erase(pairs.begin() + (long)i);
-                delete q;
-            } else {
-                ++i;
-            }
+        for (StreamPair *q : kv.second->pairs) {
+            // held pairs too (an engine some Python object still owns, an exception path of a tool): their streams must not
+            // outlive this hook either.  The handles are nulled and the pair marked dead; an occ_destroy that comes later
+            // (interpreter finalisation) finds no stream to wait for or destroy.
+            if (q->dead || !q->main) { q->dead = true; continue; }
+            (void)hipSetDevice(q->device);
+            bool late_m = false, late_s = false;
+            (void)poll_stream(q->main, &late_m);
+            (void)poll_stream(q->side, &late_s);
+            q->dead = true;
+            if (late_m || late_s) continue;  // (streams that never drain are left to the runtime)
+            (void)hipStreamDestroy(q->side);
+            (void)hipStreamDestroy(q->main);
+            q->main = q->side = nullptr;
         }
     }
 }
@@ -879,6 +986,7 @@ StreamPair *acquire_pair(int device, const std::vector<uint32_t> &m_main, const 
     int live_masked = 0;
     StreamPair *match = nullptr;
     for (StreamPair *p : slot.pairs) {
+        if (p->dead) continue;  // (its queues are not being served, or the process is on its way out)
         if (p->m_main == m_main && p->m_side == m_side) match = p;
         masked += p->m_main.empty() ? 0 : 1;
         live_masked += (!p->m_main.empty() && p->refs > 0) ? 1 : 0;
@@ -892,12 +1000,14 @@ StreamPair *acquire_pair(int device, const std::vector<uint32_t> &m_main, const 
     if (!m_main.empty() && masked >= cap) {
         for (size_t i = 0; i < slot.pairs.size() && masked >= cap;) {
             StreamPair *q = slot.pairs[i];
-            if (q->refs == 0 && !q->m_main.empty()) {
+            if (q->refs == 0 && !q->m_main.empty() && !q->dead) {
+                // (idle: release_pair's caller drained both streams before it let go, and nothing has been enqueued since)
                 slot.pairs.erase(slot.pairs.begin() + (long)i);
                 (void)hipStreamDestroy(q->side);
                 (void)hipStreamDestroy(q->main);
                 delete q;
                 g_stream_gen.fetch_add(1);
+                g_pairs_evicted.fetch_add(1);
                 masked -= 1;
             } else {
                 ++i;
@@ -949,20 +1059,21 @@ void release_pair(StreamPair *p)
     // hardware queues instead of creating and destroying CU-masked streams by the dozen; the stops inside occ_create seen
     // in round 3, DESIGN 6.1, came from runs that did exactly that).  acquire_pair destroys idle pairs when it needs their
     // place under the cap; the rest go with the process.
-    (void)hipSetDevice(p->device);
-    (void)hipStreamSynchronize(p->main);
-    (void)hipStreamSynchronize(p->side);
-    (void)slot;
+    (void)slot;  // (drop_pair has drained both streams)
 }
 
 // live pairs of a device: {masked, unmasked} (occ_stats, OCC_VERBOSE)
-void count_pairs(int device, int *masked, int *plain)
+void count_pairs(int device, int *masked, int *plain, int *idle = nullptr)
 {
     DeviceSlot &slot = device_slot(device);
     std::lock_guard<std::mutex> g(g_pool_mu);
     *masked = *plain = 0;
-    for (StreamPair *p : slot.pairs)
+    if (idle) *idle = 0;
+    for (StreamPair *p : slot.pairs) {
+        if (p->dead) continue;
         if (p->refs > 0) (p->m_main.empty() ? *plain : *masked) += 1;  // (idle pairs wait for a taker: not live)
+        else if (idle) *idle += 1;
+    }
 }
 
 void adopt_pair(occ_sampler *s, StreamPair *p)
@@ -975,8 +1086,10 @@ void adopt_pair(occ_sampler *s, StreamPair *p)
 // The engine lets go of its streams (everything it enqueued has completed).
 void drop_pair(occ_sampler *s)
 {
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->side) (void)hipStreamSynchronize(s->side);
+    if (s->pair && !s->pair->dead) {  // (a pair whose queues are not served stays out of the pool's hands: acquire_pair skips it)
+        (void)wait_on(s, s->stream, __func__, __LINE__);
+        (void)wait_on(s, s->side, __func__, __LINE__);
+    }
     release_pair(s->pair);
     adopt_pair(s, nullptr);
 }
@@ -1021,19 +1134,22 @@ int stream_probe(occ_sampler *s, bool *beside)
     // process's first launch, milliseconds, and a queue's very first packet costs 0.5 ms)
     hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->side, s->probe_w + 24);
     hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, s->probe_w + 24);
-    HIP_TRY(hipStreamSynchronize(s->side));
+    WAIT_TRY(s->side);
     HIP_TRY(hipMemsetAsync(s->probe_w, 0, 32 * sizeof(unsigned), s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     const auto t0 = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(64), 0, s->side, s->probe_w);
     hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(64), 0, s->stream, s->probe_w);
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipStreamSynchronize(s->side));
+    WAIT_TRY(s->stream);
+    WAIT_TRY(s->side);
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(copy_on(s, seen, s->probe_w + 16, sizeof(seen), hipMemcpyDeviceToHost));
-    // beside each other the pair of launches completes in 30-50 us (470 us on a queue's very first launch); a queue that
-    // has to be scheduled in first costs a quantum: 10 ms and more (tools/queue_probe.hip)
-    *beside = seen[0] != 0u && us < 3000.0;
+    // The verdict is the DEVICE's: how many polls (about 2 us each) the waiting kernel made before it saw the word.  Beside
+    // each other: a few dozen (the second launch's way through its queue); a queue that has to be scheduled in first costs a
+    // quantum -- thousands of polls (10 ms and more, tools/queue_probe.hip) -- or the word is never seen.  (Round 3 also
+    // looked at the HOST's clock around the pair of launches: a pre-empted host thread or a profiler's interception then
+    // read as "not beside each other", and stayed.)
+    *beside = seen[0] != 0u && seen[1] < 1024u;
     if (std::getenv("OCC_DEBUG_STREAMS_SERIALISED")) *beside = false;  // tests: take the caller's "not beside" branch
     if (std::getenv("OCC_VERBOSE")) {
         int masked = 0, plain = 0;
@@ -1060,7 +1176,7 @@ int tiles_reset(occ_sampler *s)
     hipLaunchKernelGGL(k_tiles_reset, dim3((unsigned)((c.n + 255) / 256), (unsigned)c.C), dim3(256), 0, s->stream, s->iter);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_tiles_reset failed");
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     return OCC_OK;
 }
 
@@ -1117,16 +1233,25 @@ int occ_destroy(occ_sampler *s)
     {
         DeviceLease lease = lease_device(s->device);
         (void)hipSetDevice(s->device);
-        if (s->stream) (void)hipStreamSynchronize(s->stream);
-        if (s->side) (void)hipStreamSynchronize(s->side);
-        destroy_graph(s);
-        for (void *p : s->allocs) (void)hipFree(p);
-        if (s->rec_buf) (void)hipFree(s->rec_buf);
-        if (s->pin_sc) (void)hipHostFree(s->pin_sc);
-        if (s->pin_rec) (void)hipHostFree(s->pin_rec);
-        for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
-            if (ev) (void)hipEventDestroy(ev);
-        drop_pair(s);  // the streams go with the last engine that shares them
+        const bool pair_gone = s->pair && (s->pair->dead || !s->pair->main);  // (wedged earlier, or pool_at_exit has been here)
+        if (!pair_gone && !s->wedged) {
+            (void)wait_on(s, s->stream, __func__, __LINE__);
+            (void)wait_on(s, s->side, __func__, __LINE__);
+        }
+        if (s->wedged) {
+            // Work of this engine never completed on its streams: hipFree would wait for it (a device-wide synchronisation) and
+            // a freed buffer could still be written.  The memory and the streams are left to the process.
+            std::fprintf(stderr, "[occ] an engine whose streams never drained is closed without freeing its device memory (%s)\n", s->err.c_str());
+        } else {
+            destroy_graph(s);
+            for (void *p : s->allocs) (void)hipFree(p);
+            if (s->rec_buf) (void)hipFree(s->rec_buf);
+            if (s->pin_sc) (void)hipHostFree(s->pin_sc);
+            if (s->pin_rec) (void)hipHostFree(s->pin_rec);
+            for (hipEvent_t ev : {s->ev0, s->ev1, s->ev_z[0], s->ev_z[1], s->ev_side[0], s->ev_side[1]})
+                if (ev) (void)hipEventDestroy(ev);
+        }
+        drop_pair(s);  // the pair stays in the pool for the next engine of its partition (idle), unless it is dead
     }
     delete s;
     return OCC_OK;
@@ -1548,6 +1673,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
                     if (!beside) {
                         s->flag_sync = false;  // hand-overs by event nodes (ICAR) / everything on one stream (reduced-rank model)
                         s->streams_serialised = true;
+                        s->probe_wait = s->probe_backoff = 1;  // (asked again at the head of the next call: refresh_paths)
                     }
                 }
             } else {
@@ -1799,7 +1925,9 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         }
     }
     HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
-    HIP_TRY(hipDeviceSynchronize());
+    // (the engine's own two streams, not hipDeviceSynchronize: other engines' pooled streams are not this call's business)
+    WAIT_TRY(s->stream);
+    WAIT_TRY(s->side);
     // what the engine comes back to after a run-time fallback (try_repromote)
     s->pref.valid = true;
     s->pref.persistent = s->persistent;
@@ -1939,7 +2067,7 @@ int fixed_checksums(occ_sampler *s, std::vector<unsigned long long> &sums)
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d, sizeof(unsigned long long) * na, hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = drain_for_copy(s);
     (void)hipFree(d);
     if (e != hipSuccess) {
         s->err = std::string("checksum of the fixed arrays failed: ") + hipGetErrorString(e);
@@ -2044,6 +2172,8 @@ int occ_synchronize(occ_sampler *s)
     if (!s) return OCC_E_BADARG;
     DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
+    WAIT_TRY(s->stream);  // (bounded and self-naming; what is left for the device-wide call is other engines' work)
+    WAIT_TRY(s->side);
     HIP_TRY(hipDeviceSynchronize());
     return OCC_OK;
 }
@@ -2110,6 +2240,7 @@ int occ_create_distributed(const occ_problem *problem, occ_comm *cm, int32_t roo
     if (hipStreamSynchronize(cm->stream) != hipSuccess) bad = 1.0;
     // ... and what arrived is what was sent: every rank checksums its copies on the device, the root's sums go round,
     // the first array that differs anywhere is named on every rank
+    DeviceLease lease = lease_device(s->device);  // the checksum kernels and the mirrors' copies run on the (pooled) main stream
     {
         std::vector<unsigned long long> mine, roots;
         if (bad == 0.0 && fixed_checksums(s, mine) != OCC_OK) bad = 1.0;
@@ -2311,9 +2442,9 @@ int occ_set_keys(occ_sampler *s, const uint64_t *keys)
     return write_scalars(s, h);
 }
 
-static int step_impl(occ_sampler *s)
+static int step_impl(occ_sampler *s, bool snapshot)
 {
-    int rc = set_window(s, 1, 0, 0);
+    int rc = open_window(s, 1, 0, 0, snapshot, false);
     if (rc) return rc;
     if ((rc = eager_sequence(s))) return rc;
     std::vector<ChainScalars> h;
@@ -2321,8 +2452,8 @@ static int step_impl(occ_sampler *s)
     s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
     if ((rc = check_device_errors(s, h))) return rc;
-    s->sc_host = h;
-    s->sc_host_valid = true;
+    s->mirror = h;
+    s->mirror_ok = true;
     s->clean_exit = true;
     return OCC_OK;
 }
@@ -2347,7 +2478,7 @@ static int finish_marks(occ_sampler *s, bool last, size_t n_rec)
     return OCC_OK;
 }
 
-static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau)
+static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, double *out_beta, double *out_tau, bool snapshot)
 {
     Ctx &c = s->ctx;
     const int C = c.C, p = c.p, q = c.q;
@@ -2355,7 +2486,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     const size_t rw = (size_t)q + p + 1;
     const size_t need = (size_t)C * keep * rw;
     if (need > s->rec_cap) {  // grow the record buffer (its address lives in the device descriptor)
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        WAIT_TRY(s->stream);
         if (s->rec_buf) HIP_TRY(hipFree(s->rec_buf));
         s->rec_buf = nullptr;
         s->rec_cap = 0;
@@ -2366,16 +2497,8 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
         c.rec = s->rec_buf;
         HIP_TRY(copy_on(s, s->ctx_dev, &s->ctx, sizeof(Ctx), hipMemcpyHostToDevice));
     }
-    int rc = set_window(s, n_iter, burnin, keep);
+    int rc = open_window(s, n_iter, burnin, keep, snapshot, true);
     if (rc) return rc;
-    if (c.iter_clock) {  // k_iter's clock counts this run only
-        // (a member, not a stack array: the copy is asynchronous and the source must outlive it)
-        if (!s->clock_fresh) {
-            HIP_TRY(hipMemsetAsync(c.iter_clock, 0xff, sizeof(unsigned long long), s->stream));       // [0] = ~0: the earliest start so far
-            HIP_TRY(hipMemsetAsync(c.iter_clock + 1, 0, 3 * sizeof(unsigned long long), s->stream));  // [1] latest end, [2] sum, [3] launches
-        }
-        s->clock_fresh = false;
-    }
     std::vector<ChainScalars> h;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     s->marks_done = false;
@@ -2422,7 +2545,9 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     if (done_min < n_iter && s->side_enabled && !s->flag_sync && s->rsr.m == 0) HIP_TRY(hipEventRecord(s->ev_z[s->parity ^ 1], s->stream));
     const int64_t seq_per_enqueue = (s->flag_sync || s->rsr.m > 0) ? GRAPH_SEQ : 1;
 
-    int64_t stuck = 0;  // sequences enqueued since a chain last advanced
+    // (iteration, launches spent on a carried solve) of every chain after the previous batch: every sequence moves every
+    // unfinished chain -- by one iteration, or by the captured launches of a solve it carries on (Ctl::koff)
+    std::vector<std::pair<uint32_t, uint32_t>> seen((size_t)C, {0xffffffffu, 0xffffffffu});
     while (done_min < n_iter) {
         // every sequence advances each unfinished chain by one iteration, or (rarely) carries its eta
         // solve into the next sequence; finished chains idle.  No host work inside a batch.
@@ -2443,23 +2568,33 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
                          std::chrono::duration<double, std::micro>(hl2 - hl0).count() / batch);
         }
         if ((rc = check_device_errors(s, h))) return rc;
-        const int64_t done_before = done_min;
         done_min = n_iter;
         unsigned long long tot = 0, sq = 0, solves = 0;
         for (int ch = 0; ch < C; ++ch) {
             done_min = std::min<int64_t>(done_min, (int64_t)h[ch].ctl[s->parity].it - (int64_t)h[ch].it_base);
             tot += h[ch].krylov_total; sq += h[ch].krylov_sq_total; solves += h[ch].solves;
         }
-        // (a batch of sequences that advances no chain and reports no error must not be repeated for ever: whatever left the
-        // chains' window in that state, the caller gets an error, not a call that never returns)
-        // (a solve carried over many short sequences -- launch-per-step path with a small cap -- legitimately spends whole
-        // batches inside one iteration: the bound is in sequences, beyond what the longest admissible solve can take)
-        if (done_min <= done_before && done_min < n_iter) {
-            stuck += batch;
-            if (stuck > std::max<int64_t>(8192, 4 * (int64_t)c.maxiter))
-                return set_error(s, OCC_E_HIP, "the chains made no progress over thousands of sequences (window of iterations not open on the device?)");
-        } else {
-            stuck = 0;
+        // A batch that leaves an unfinished chain exactly where it was -- same iteration, same carried launches, no error
+        // word -- cannot happen while the chain's window is open on the device: the call ends with what it saw instead of
+        // enqueuing idle sequences for ever (round 3 recorded a call that never returned; the text below is what
+        // a recurrence reports).
+        for (int ch = 0; ch < C; ++ch) {
+            const Ctl &ctl = h[ch].ctl[s->parity];
+            const bool unfinished = (int64_t)ctl.it - (int64_t)h[ch].it_base < n_iter;
+            if (unfinished && seen[(size_t)ch].first == ctl.it && seen[(size_t)ch].second == ctl.koff) {
+                std::string msg = "no progress: a batch of " + std::to_string((long long)batch) + " sequences left chain " + std::to_string(ch) +
+                                  " where it was (the window of iterations is not open on the device?); per chain {it, koff | other parity | mid | it_base, it_stop, err}:";
+                for (int k2 = 0; k2 < C && k2 < 16; ++k2) {
+                    const ChainScalars &q2 = h[k2];
+                    char b[192];
+                    std::snprintf(b, sizeof(b), " [%d] {%u, %u | %u, %u | %u, %u / %u, %u | %u, %u, %d}", k2, q2.ctl[s->parity].it, q2.ctl[s->parity].koff, q2.ctl[s->parity ^ 1].it,
+                                  q2.ctl[s->parity ^ 1].koff, q2.mid[0].it, q2.mid[0].koff, q2.mid[1].it, q2.mid[1].koff, q2.it_base, q2.it_stop, (int)q2.err);
+                    msg += b;
+                }
+                msg += "; the host wanted " + std::to_string((long long)n_iter) + " iterations, done_min " + std::to_string((long long)done_min) + "; " + host_state(s);
+                return set_error(s, OCC_E_HIP, msg.c_str());
+            }
+            seen[(size_t)ch] = {ctl.it, ctl.koff};
         }
         if (std::getenv("OCC_VERBOSE")) {
             unsigned long long car = 0;
@@ -2489,8 +2624,8 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
     s->last_run_ms = ms;
     s->iterations = h[0].ctl[s->parity].it;
     s->krylov_last = h[0].minres_itn_last;
-    s->sc_host = h;  // the chains' scalars as this call leaves them: the next call does not ask the device again
-    s->sc_host_valid = true;
+    s->mirror = h;  // the chains' scalars as this call leaves them: the next call does not ask the device again
+    s->mirror_ok = true;
     s->clean_exit = true;
 
     const double *host = s->pin_rec;
@@ -2513,40 +2648,13 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
 // variates are functions of (key, iteration, index) and both paths return the same bits, so the caller gets exactly
 // what the fused path would have returned.  The engine stays on the launch-per-step path afterwards
 // (occ_stats::persistent_solve = 0, ::fused_fallbacks counts).
-static int snapshot_take(occ_sampler *s, int64_t n_iter = 0, int64_t burnin = 0, int64_t keep = 0)
-{
-    const Ctx &c = s->ctx;
-    const size_t Cn = (size_t)c.C * c.n;
-    int rc;
-    if (!s->snap_eta) {
-        if ((rc = dev_alloc(s, &s->snap_eta, Cn, false))) return rc;
-        if ((rc = dev_alloc(s, &s->snap_z, Cn, false))) return rc;
-        if ((rc = dev_alloc(s, &s->snap_x, Cn, false))) return rc;
-        if (s->rsr.m > 0 && (rc = dev_alloc(s, &s->snap_theta, (size_t)c.C * s->rsr.m, false))) return rc;
-    }
-    if (s->sc_host_valid) s->snap_sc = s->sc_host;  // (what the last occ_run read at its end; nothing has touched the device since)
-    else if ((rc = read_scalars(s, s->snap_sc))) return rc;
-    s->sc_host_valid = false;
-    s->snap_fresh = true;  // set_window, next, takes these
-    s->snap_parity = s->parity;
-    // one launch for the three copies (three stream copies: three launch gaps in front of the call's first kernel)
-    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)std::min<size_t>((Cn + 255) / 256, 2048)), dim3(256), 0, s->stream, c.eta, s->snap_eta, c.z, s->snap_z, c.Xv, s->snap_x,
-                       (unsigned long long)Cn, s->rsr.m > 0 ? s->rsr.theta : nullptr, s->snap_theta, (unsigned long long)c.C * (unsigned long long)std::max(s->rsr.m, 0),
-                       c.iter_clock, (n_iter > 0 && c.C <= 256) ? c.sc : nullptr, c.C, s->parity, (uint32_t)n_iter, (uint32_t)burnin, (uint32_t)keep);
-    s->clock_fresh = c.iter_clock != nullptr;
-    s->window_open = n_iter > 0 && c.C <= 256;
-    s->window_n = n_iter; s->window_burnin = burnin; s->window_keep = keep;
-    if (hipGetLastError() != hipSuccess) return set_error(s, OCC_E_HIP, "launch of k_snapshot failed");
-    return OCC_OK;
-}
-
 // Hand-overs between the two streams: device counters (`flags`) or events / one stream.  The captured graphs belong to a
 // mode and go with it; the counters restart from zero (a consistent state: sequence 0, whatever the parity).
 static int set_handover(occ_sampler *s, bool flags)
 {
     if (s->flag_sync == flags) return OCC_OK;
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+    WAIT_TRY(s->stream);
+    WAIT_TRY(s->side);
     destroy_graph(s);
     s->flag_sync = flags;
     s->ctx.sync = flags ? s->sync_buf : nullptr;
@@ -2561,8 +2669,8 @@ static int fallback_to_launch_per_step(occ_sampler *s)
 {
     Ctx &c = s->ctx;
     const size_t Cn = (size_t)c.C * c.n;
-    (void)hipStreamSynchronize(s->stream);
-    if (s->side) (void)hipStreamSynchronize(s->side);
+    WAIT_TRY(s->stream);
+    WAIT_TRY(s->side);
     (void)hipGetLastError();
     if (std::getenv("OCC_VERBOSE") || !std::getenv("OCC_QUIET"))
         std::fprintf(stderr, "[occ] %s -- re-running the call without hand-overs between the streams%s\n",
@@ -2613,8 +2721,8 @@ static int try_repromote(occ_sampler *s)
         s->promote_wait = s->promote_backoff;
         return OCC_OK;
     };
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+    WAIT_TRY(s->stream);
+    WAIT_TRY(s->side);
     destroy_graph(s);
     if (s->pref.main_cus > 0) {  // the CU partition
         std::string why;
@@ -2666,10 +2774,15 @@ static int refresh_paths(occ_sampler *s)
 {
     int rc;
     if ((rc = try_repromote(s))) return rc;
-    if (!s->demoted && s->main_cus > 0 && s->sync_buf && s->pref.flag_sync && s->probe_gen != g_stream_gen.load()) {
+    // (a negative answer is not for life either: asked again after 1, 2, 4 ... 64 calls, as try_repromote does)
+    bool ask = s->probe_gen != g_stream_gen.load();
+    if (!ask && s->streams_serialised && !s->flag_sync && --s->probe_wait <= 0) ask = true;
+    if (!s->demoted && s->main_cus > 0 && s->sync_buf && s->pref.flag_sync && ask) {
         bool beside = true;
         if ((rc = stream_probe(s, &beside))) return rc;
         s->streams_serialised = !beside;
+        if (beside) s->probe_backoff = 1;
+        else { s->probe_backoff = std::min(64, s->probe_backoff * 2); s->probe_wait = s->probe_backoff; }
         if ((rc = set_handover(s, beside))) return rc;
     }
     return OCC_OK;
@@ -2683,12 +2796,11 @@ int occ_step(occ_sampler *s)
     int rc;
     if ((rc = refresh_paths(s))) return rc;
     const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;  // paths with device-side waits: re-run without them if one gives up
-    if (fused && (rc = snapshot_take(s))) return rc;
     s->device_timeout = false;
-    rc = step_impl(s);
+    rc = step_impl(s, fused);
     if (rc == OCC_E_HIP && fused && s->device_timeout) {
         if ((rc = fallback_to_launch_per_step(s))) return rc;
-        rc = step_impl(s);
+        rc = step_impl(s, false);
     }
     return rc;
 }
@@ -2703,12 +2815,11 @@ int occ_run(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_alpha, d
     int rc;
     if ((rc = refresh_paths(s))) return rc;
     const bool fused = (s->persistent && s->rsr.m == 0) || s->flag_sync;
-    if (fused && (rc = snapshot_take(s, n_iter, burnin, n_iter - burnin))) return rc;
     s->device_timeout = false;
-    rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
+    rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau, fused);
     if (rc == OCC_E_HIP && fused && s->device_timeout) {
         if ((rc = fallback_to_launch_per_step(s))) return rc;
-        rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau);
+        rc = run_impl(s, n_iter, burnin, out_alpha, out_beta, out_tau, false);
     }
     return rc;
 }
@@ -2720,7 +2831,7 @@ int occ_get_state(occ_sampler *s, int32_t chain, const char *name, double *out, 
     if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
     DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     const std::string nm(name);
     const size_t n = (size_t)c.n, R = (size_t)c.R;
     std::vector<double> v;
@@ -2783,7 +2894,7 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
     if (chain < 0 || chain >= c.C) return set_error(s, OCC_E_BADARG, "bad chain index");
     DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     const std::string nm(name);
     const size_t n = (size_t)c.n, R = (size_t)c.R;
     auto need = [&](size_t want) { return (size_t)len == want; };
@@ -2807,12 +2918,17 @@ int occ_set_state(occ_sampler *s, int32_t chain, const char *name, const double 
         std::vector<double2> x(n);
         for (size_t i = 0; i < n; ++i) x[i] = make_double2(in[i], in[n + i]);
         HIP_TRY(copy_on(s, c.Xv + chain * n, x.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    } else if (nm == "debug_close_window") {
+        // tests of the no-progress exit of occ_run: the next call's window reaches the device with zero iterations
+        if (!need(1)) return set_error(s, OCC_E_STATE, "wrong length");
+        s->debug_close_window = in[0] != 0.0;
+        return OCC_OK;
     } else if (nm == "debug_maxiter") {
         // tests of the MINRES-did-not-converge exit (logit.py:91-92): the iteration limit of every chain's solve; 0 restores
         // scipy's default 5 * (2n).  The limit travels by value in the kernels' argument blocks: the graphs are re-captured.
         if (!need(1) || in[0] < 0.0) return set_error(s, OCC_E_STATE, "wrong length");
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        if (s->side) HIP_TRY(hipStreamSynchronize(s->side));
+        WAIT_TRY(s->stream);
+        WAIT_TRY(s->side);
         destroy_graph(s);
         s->ctx.maxiter = in[0] > 0.0 ? (long long)in[0] : 10LL * c.n;
         s->kry.maxiter = s->ctx.maxiter;
@@ -2869,10 +2985,12 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->stream_probes = (int32_t)s->stream_probes;
     out->handover_mode = s->flag_sync ? 2 : 1;
     {
-        int masked = 0, plain = 0;
-        count_pairs(s->device, &masked, &plain);
+        int masked = 0, plain = 0, idle = 0;
+        count_pairs(s->device, &masked, &plain, &idle);
         out->stream_pairs_masked = masked;
         out->stream_pairs_plain = plain;
+        out->stream_pairs_idle = idle;
+        out->stream_pairs_evicted = (int32_t)g_pairs_evicted.load();
     }
     out->demoted = s->demoted ? 1 : 0;
     out->profile_iter_dispatch_us = s->profile_iter_dispatch_us;
@@ -2906,7 +3024,7 @@ static int time_kernel_graph(occ_sampler *s, int kind, int reps, int e, int extr
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     HIP_TRY(hipGraphLaunch(exec, s->stream));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *avg_us = 1000.0 * ms / reps;
@@ -2920,8 +3038,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     if (!s || reps < 1 || !counts || !total_us) return OCC_E_BADARG;
     DeviceLease lease = lease_device(s->device);
     HIP_TRY(hipSetDevice(s->device));
-    s->sc_host_valid = false;
-    int rc = set_window(s, 1 << 30, 0, 0);  // no chain reaches its stop during the timing loops
+    int rc = open_window(s, 1 << 30, 0, 0, false, false);  // no chain reaches its stop during the timing loops
     if (rc) return rc;
     // The fused iteration kernel first, IN SITU: `reps` real iterations continue the chains from where they are
     // (nothing recorded), the side chain on the side stream as in occ_run, two HIP events around every
@@ -2964,7 +3081,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             LAUNCH(s, s->stream, K_Z_OB, pe);
             if (ev) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
             s->parity ^= 1;
-            HIP_TRY(hipStreamSynchronize(s->stream));
+            WAIT_TRY(s->stream);
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             total_us[K_ITER] += 1000.0 * ms;
@@ -3017,7 +3134,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
         for (int r = 0; r < reps; ++r) HIP_TRY(hipGraphLaunch(exec, s->stream));
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        WAIT_TRY(s->stream);
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         (void)hipGraphExecDestroy(exec);
@@ -3035,7 +3152,7 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
     // k_z_ob advances the control word of the OTHER parity; launched repeatedly with the same parity
     // it redoes the same z update and omega_b draw
     if ((rc = timed(K_Z_OB, 0))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     s->need_prologue = true;
     return take_launch_rc(s);
 }
@@ -3080,7 +3197,7 @@ int cond_begin(occ_sampler *s, int chain, const Inject &inj, uint32_t *it_out)
 
 int cond_end(occ_sampler *s, int chain, ChainScalars *out)
 {
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    WAIT_TRY(s->stream);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { s->err = std::string("kernel launch failed: ") + hipGetErrorString(le); return OCC_E_HIP; }
     std::vector<ChainScalars> h;
@@ -3155,7 +3272,7 @@ int occ_cond_eta(occ_sampler *s, int32_t chain, const double *omega_b, const dou
         else hipLaunchKernelGGL(k_minres<0>, gs, blk, 0, s->stream, s->kry, chain, e, k);
         if (k < 4) continue;
         HIP_TRY(hipMemcpyAsync(&slot, c.slots + (size_t)chain * NSLOT + (k & (NSLOT - 1)), sizeof(Slot), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        WAIT_TRY(s->stream);
         if (slot.done) { k_last = k; break; }
         if ((long long)k > c.maxiter + 3) return set_error(s, OCC_E_MINRES, "MINRES solver did not converge!");
     }

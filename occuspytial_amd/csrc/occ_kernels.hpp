@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(256) k_checksum(const unsigned char *__restric
 
 // The state a call is re-run from after a device-side wait gave up (occ_gibbs.hip, snapshot_take): eta, z, the warm start
 // (and theta of the reduced-rank model) of every chain, in ONE launch -- which also resets the fused kernel's clock words
-// and opens the call's window: no copy engine between the call's entry and its first kernel.
+// and opens the call's window (occ_gibbs.hip, open_window): no copy engine between the call's entry and its first kernel.
 __global__ void __launch_bounds__(256) k_snapshot(const double *__restrict__ eta, double *__restrict__ s_eta, const uint8_t *__restrict__ z, uint8_t *__restrict__ s_z,
                                                   const double2 *__restrict__ x, double2 *__restrict__ s_x, unsigned long long count,
                                                   const double *__restrict__ theta, double *__restrict__ s_theta, unsigned long long count_theta,
@@ -748,14 +748,16 @@ __global__ void __launch_bounds__(256) k_snapshot(const double *__restrict__ eta
 {
     if (clock != nullptr && blockIdx.x == 0 && threadIdx.x < 4) clock[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;
     // ... and opens the call's window of iterations in the chains' scalars (what set_window would upload: occ_gibbs.hip)
-    if (scs != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_chains) {
-        ChainScalars &sc = scs[threadIdx.x];
-        Ctl &ctl = sc.ctl[parity];
-        sc.it_base = ctl.it;
-        sc.it_stop = ctl.it + n_iter;
-        sc.burnin = burnin;
-        sc.keep = keep;
-        ctl.koff = 0;
+    if (scs != nullptr && blockIdx.x == 0) {
+        for (int ch = (int)threadIdx.x; ch < n_chains; ch += (int)blockDim.x) {
+            ChainScalars &sc = scs[ch];
+            Ctl &ctl = sc.ctl[parity];
+            sc.it_base = ctl.it;
+            sc.it_stop = ctl.it + n_iter;
+            sc.burnin = burnin;
+            sc.keep = keep;
+            ctl.koff = 0;
+        }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
         s_eta[i] = eta[i];
@@ -1921,7 +1923,14 @@ __global__ void __launch_bounds__(256, 3) k_omega_a(OCC_KARGS, int gate)
                 if (!sync_wait(c.sync, SYNC_MAIN, j)) scs[0].err = -2;
             }
             __syncthreads();
+            // What follows reads bytes the MAIN stream's k_z_ob wrote on other XCDs (the chains' control words, z) with plain
+            // loads, inside a kernel that started before they were written: every wave takes an agent-scope ACQUIRE behind
+            // the wait (its L1 and the non-local lines of its XCD's L2 are dropped), the invariant of every in-kernel
+            // hand-over here -- k_iter and k_z_ob read theirs through agent-scope loads instead.  (As a kernel of its own,
+            // k_gate had the kernel boundary for this.  Workgroups past GATE_FIRST start after one of the first has ended,
+            // i.e. after the hand-over; they take the acquire all the same -- their CU's L1 is not theirs alone.)
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     const Tile tile = tile_of_block_shared(c, 1, c.nb_r, chain_base);
     const int chain = tile.chain, blk = tile.blk;

@@ -211,3 +211,82 @@ def test_minres_iteration_limit_on_the_device_raises_the_references_error(monkey
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
     eng.close()
+
+
+# ---- a call that cannot advance ends, and says what it saw (round 4: DESIGN 6.4) ------------------------------------------
+@pytest.mark.parametrize('path', ['fused', 'launch_per_step'])
+def test_a_closed_window_ends_the_call_with_the_state_it_saw(monkeypatch, path):
+    """occ_run's host loop enqueues sequences until every chain has done its iterations; a chain whose window of iterations
+    is not open on the device idles through every sequence and reports no error -- round 3 recorded a call that never
+    returned.  The debug state name ``debug_close_window`` sends the NEXT call's window to the device with zero iterations
+    (both forms of open_window: the edit by k_snapshot on the fused path, the upload on the launch-per-step path): the call
+    must end at once with OCC_E_HIP and the chains' control words in the text, and the engine must go on as if the call had
+    not been made -- the same bits as an undisturbed engine."""
+    import time
+
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._lib import EngineUnavailable
+    if path == 'launch_per_step':
+        monkeypatch.setenv('OCC_NO_PERSISTENT', '1')
+    prob = _small_problem(seed=3, rows=40, cols=45)
+
+    def fresh():
+        e = Engine(prob, [KEY, KEY + 7])
+        for c in range(2):
+            e.set_start(c, **_random_start(prob, 40 + c))
+        return e
+
+    ref = fresh()
+    want = ref.run(9, 0), ref.run(20, 3)
+    want_eta = [ref.get('eta', c) for c in range(2)]
+    ref.close()
+    eng = fresh()
+    assert (eng.stats()['persistent_solve'] > 0) == (path == 'fused')
+    got0 = eng.run(9, 0)
+    eng.set('debug_close_window', 1.0)
+    t0 = time.perf_counter()
+    with pytest.raises(EngineUnavailable) as ei:
+        eng.run(20, 3)
+    assert time.perf_counter() - t0 < 1.0
+    text = str(ei.value)
+    assert 'no progress' in text and 'it_base, it_stop' in text and 'parity' in text and '{9, 0 |' in text, text
+    got1 = eng.run(20, 3)                                # the knob is consumed; the chains are where the first call left them
+    st = eng.stats()
+    assert st['fused_fallbacks'] == 0 and st['iterations'] == 29
+    for a, b in zip(want[0] + want[1], got0 + got1):
+        assert np.array_equal(a, b)
+    for c in range(2):
+        assert np.array_equal(want_eta[c], eng.get('eta', c))
+    eng.close()
+
+
+def test_a_fifth_cu_partition_evicts_an_idle_pair_and_nothing_changes(monkeypatch):
+    """The pool keeps a pair whose last engine closed, idle, for the next taker of its CU partition, and destroys idle
+    pairs only to make room under the cap of four masked pairs per device (acquire_pair's eviction branch): the one place
+    where CU-masked streams are still destroyed and created back to back inside a running process -- the sequence round 3's
+    stop inside occ_create followed.  Six distinct partitions (the default's and five more) opened, used and closed in turn: from the fifth on each evicts; then a
+    default engine returns the bits it returned before any of it."""
+    from occuspytial_amd._engine import Engine
+    prob = _small_problem(seed=3, rows=40, cols=45)
+    ref = _icar_run(prob)
+    base = ref[2]['stream_pairs_evicted']
+    seen_idle = []
+    for split in ('64', '96', '128', '192', '224'):
+        monkeypatch.setenv('OCC_CU_SPLIT', split)
+        eng = Engine(prob, [KEY, KEY + 7])
+        for c in range(2):
+            eng.set_start(c, **_random_start(prob, 40 + c))
+        rec = eng.run(6, 0)
+        st = eng.stats()
+        assert st['main_stream_cus'] == int(split) and st['handover_mode'] == 2 and st['fused_fallbacks'] == 0, st
+        assert st['stream_pairs_masked'] == 1                     # the only pair an engine HOLDS
+        assert st['stream_pairs_masked'] + st['stream_pairs_idle'] <= 4 + 1, st   # four masked pairs at most, and the device's idle plain pair
+        seen_idle.append(st['stream_pairs_idle'])
+        for a, b in zip(rec, ref[0]):                             # (the CU partition never changes a bit)
+            assert np.array_equal(a[:, :6], b[:, :6])
+        eng.close()
+    monkeypatch.delenv('OCC_CU_SPLIT')
+    alt = _icar_run(prob)
+    assert alt[2]['stream_pairs_evicted'] >= base + 2, (base, alt[2], seen_idle)   # six distinct partitions + the default's: five more partitions + the default's again under a cap of four: at least two evictions
+    assert alt[2]['fused_fallbacks'] == 0 and alt[2]['handover_mode'] == 2
+    _same(ref, alt)
