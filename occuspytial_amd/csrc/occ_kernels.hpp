@@ -808,8 +808,7 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
 #pragma unroll
         for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
         const double eta_i = eta[i];
-        Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
-        c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
+        c.omega_b[it & 1][ci] = pg1_draw(sc.key, (uint32_t)i, it, STREAM_OMEGA_B, xb + eta_i);
         quad[0] = quad_site(c, eta, i, eta_i);
     }
     if (per_wave) {  // several waves per block, partial sums still per 64-site slice (c.nb_n counts slices)
@@ -832,8 +831,7 @@ __device__ __forceinline__ void omega_b_body_g(const Ctx &c, const ChainScalars 
         double xb = 0.0;
         for (int a = 0; a < c.p; ++a) xb += c.Xt[(size_t)a * n + i] * sc.beta[a];
         const double eta_i = eta[i];
-        Cursor cur(sc.key, (uint32_t)i, it, STREAM_OMEGA_B);
-        c.omega_b[it & 1][ci] = pg1_draw(cur, xb + eta_i);
+        c.omega_b[it & 1][ci] = pg1_draw(sc.key, (uint32_t)i, it, STREAM_OMEGA_B, xb + eta_i);
         quad[0] = quad_site(c, eta, i, eta_i);
     }
     if (per_wave) {
@@ -1838,7 +1836,9 @@ __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc
     if (r < R) {
         const int info = c.row_site[r];
         const int site = info & 0x7fffffff;
-        const bool exists = (info < 0) || (c.z[(size_t)chain * c.n + site] != 0);
+        // (z: written by the MAIN stream's k_z_ob, possibly while this kernel was already waiting at its gate -- an
+        // agent-scope load, like every byte that is handed over inside a running kernel; see k_omega_a)
+        const bool exists = (info < 0) || (__hip_atomic_load(&c.z[(size_t)chain * c.n + site], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
         if (exists) {
             double w[Q], wa = 0.0;
 #pragma unroll
@@ -1850,8 +1850,7 @@ __device__ __forceinline__ void omega_a_row(const Ctx &c, const ChainScalars &sc
             if (INJ) {  // omega_a as the caller left it in the state buffer
                 om = c.omega_a[(size_t)chain * R + r];
             } else {
-                Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
-                om = pg1_draw(cur, wa);
+                om = pg1_draw(sc.key, (uint32_t)r, it, STREAM_OMEGA_A, wa);
                 c.omega_a[(size_t)chain * R + r] = om;
             }
             const double tt = (double)c.yrow[r] - 0.5;
@@ -1880,15 +1879,14 @@ __device__ __forceinline__ void omega_a_row_g(const Ctx &c, const ChainScalars &
     if (r < R) {
         const int info = c.row_site[r];
         const int site = info & 0x7fffffff;
-        exists = (info < 0) || (c.z[(size_t)chain * c.n + site] != 0);
+        exists = (info < 0) || (__hip_atomic_load(&c.z[(size_t)chain * c.n + site], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
         if (exists) {
             double wa = 0.0;
             for (int a = 0; a < q; ++a) wa = fma(c.Wt[(size_t)a * R + r], sc.alpha[a], wa);
             if (INJ) {
                 om = c.omega_a[(size_t)chain * R + r];
             } else {
-                Cursor cur(sc.key, (uint32_t)r, it, STREAM_OMEGA_A);
-                om = pg1_draw(cur, wa);
+                om = pg1_draw(sc.key, (uint32_t)r, it, STREAM_OMEGA_A, wa);
                 c.omega_a[(size_t)chain * R + r] = om;
             }
             tt = (double)c.yrow[r] - 0.5;
@@ -1923,21 +1921,22 @@ __global__ void __launch_bounds__(256, 3) k_omega_a(OCC_KARGS, int gate)
                 if (!sync_wait(c.sync, SYNC_MAIN, j)) scs[0].err = -2;
             }
             __syncthreads();
-            // What follows reads bytes the MAIN stream's k_z_ob wrote on other XCDs (the chains' control words, z) with plain
-            // loads, inside a kernel that started before they were written: every wave takes an agent-scope ACQUIRE behind
-            // the wait (its L1 and the non-local lines of its XCD's L2 are dropped), the invariant of every in-kernel
-            // hand-over here -- k_iter and k_z_ob read theirs through agent-scope loads instead.  (As a kernel of its own,
-            // k_gate had the kernel boundary for this.  Workgroups past GATE_FIRST start after one of the first has ended,
-            // i.e. after the hand-over; they take the acquire all the same -- their CU's L1 is not theirs alone.)
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // What follows reads bytes the MAIN stream's k_z_ob wrote on other XCDs -- the chain's control words, z -- inside a
+    // kernel that may have started before they were written: they are read with AGENT-SCOPE loads (L1 bypassed, coherent
+    // across the XCDs), the rule of every in-kernel hand-over here (k_iter's noise, k_z_ob's alpha).  As a kernel of its
+    // own, k_gate had the kernel boundary for this.  (Not an acquire fence per workgroup: its cache invalidation on every
+    // one of thousands of workgroups throws k_iter's exchange out of the XCDs' L2s -- k_iter 40 -> 61 us, measured.)
     const Tile tile = tile_of_block_shared(c, 1, c.nb_r, chain_base);
     const int chain = tile.chain, blk = tile.blk;
     if (chain < 0) return;
     const ChainScalars &sc = scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    Ctl ctl;
+    ctl.it = __hip_atomic_load(&sc.ctl[e].it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl.koff = __hip_atomic_load(&sc.ctl[e].koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t it_stop = __hip_atomic_load(&sc.it_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ctl.koff || ctl.it >= it_stop || __hip_atomic_load(&sc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     if constexpr (Q == 0) {
         omega_a_row_g<INJ>(c, sc, chain, ctl.it, blk * blockDim.x + threadIdx.x, blk);
     } else {
@@ -2304,7 +2303,7 @@ __global__ void __launch_bounds__(256) k_draw(int kind, uint64_t key, uint32_t i
     Cursor cur(key, (uint32_t)i, it, stream);
     double v;
     switch (kind) {
-        case DRAW_PG1: v = pg1_draw(cur, param[i]); break;
+        case DRAW_PG1: v = pg1_draw(key, (uint32_t)i, it, stream, param[i]); break;
         case DRAW_STD_GAMMA: v = std_gamma(cur, param[i]); break;
         case DRAW_NORMAL: v = block_normal(key, (uint32_t)i, 0, it, stream); break;
         default: v = block_uniform(key, (uint32_t)i, 0, it, stream); break;

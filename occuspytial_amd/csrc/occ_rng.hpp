@@ -99,128 +99,105 @@ struct Cursor {
 };
 
 // ---- PG(1, z) -------------------------------------------------------------------------------
+// Devroye's alternating-series sampler for J*(1, z/2)/4 with truncation point t = 0.64, as ONE rejection loop (round 4;
+// the specification and its derivation: oracle/occ_oracle.c "PG(1, z)", DESIGN.md "Variate streams").  Round r of a draw
+// takes the four words of Philox blocks 2r and 2r + 1 of the sub-stream (index, iteration, stream): Um picks the piece of
+// the envelope, Ux proposes on it, U2 picks the Michael-Schucany-Haas root, Us decides.
+//   * The probability of the right piece is 1 / (1 + k f exp(f t - s)): the left piece's envelope is the Levy density
+//     itself below Z = 1/t (its tilt exp(-Z^2 x/2) goes into the acceptance test) and the untruncated IG(1/Z, 1) from
+//     1/t on (a proposal beyond t is a rejected round), so cosh Z cancels and no erfc is needed (rounds 1-3: two erfc and
+//     three exp per draw, and a rejection loop of its own for the truncated inverse Gaussian).
+//   * The alternating series is tested in ratio form, U <= E (1 - r_1 + r_2 - ...), r_n = a_n / a_0 = (2n+1) exp(...):
+//     a_0 is never formed, and the first test -- one exp -- decides 99.4 % of the proposals.
+//   * A wave executes every branch some lane takes, so the round is written WITHOUT branches: both proposals, both
+//     quantile formulas and both left-piece forms are evaluated by every lane and selected -- their dependent chains then
+//     run side by side (a Polya-Gamma wave alone on its SIMD is bound by the latency of its dependent chain, not by issue:
+//     tools/pg_occupancy.py), and they share one logarithm (the right piece's exponential variate and the quantile's
+//     -log p = -(log Ux + log c)).
 constexpr double kPgT = 0.64;
+constexpr double kPgPLevy = 0.10564977366685526;      // Phi(-1/sqrt(t)) = Phi(-1.25)
+constexpr double kPgLogPLevy = -2.2476256772143182;   // its logarithm
+constexpr double kPgLogHalf = -0.69314718055994531;
+constexpr double kPgKBelow = 0.26903493944991954;     // 8 Phi(-1.25) / pi
+constexpr double kPgKAbove = 1.2732395447351628;      // 4 / pi
 
-__device__ __forceinline__ double pg_a(int n, double x)
-{
-    const double K = (n + 0.5) * kPi;
-    if (x > kPgT) return K * exp(-0.5 * K * K * x);
-    // K (2/(pi x))^(3/2) exp(-2 (n + 1/2)^2 / x): one reciprocal, one square root, one exp (no logarithms)
-    const double rx = 1.0 / x;
-    const double v = (2.0 / kPi) * rx;
-    return K * (v * sqrt(v)) * exp(-2.0 * (n + 0.5) * (n + 0.5) * rx);
-}
-__device__ __forceinline__ double log_phi(double x) { return log(0.5 * erfc(-x * kSqrtHalf)); }
-
-__device__ __forceinline__ double pg_mass_texpon(double Z)
-{
-    const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
-    const double b = sqrt(1.0 / kPgT) * (kPgT * Z - 1.0);
-    const double a = -sqrt(1.0 / kPgT) * (kPgT * Z + 1.0);
-    if (Z < 20.0) {  // everything is in range: q/p directly (two erfc, two exp), no logarithms
-        const double pb = 0.5 * erfc(-b * kSqrtHalf), pa = 0.5 * erfc(-a * kSqrtHalf);
-        const double ez = exp(Z);
-        const double qdivp = (4.0 / kPi) * fz * exp(fz * kPgT) * (pb / ez + ez * pa);
-        return 1.0 / (1.0 + qdivp);
-    }
-    const double x0 = log(fz) + fz * kPgT;
-    const double xb = x0 - Z + log_phi(b);
-    const double xa = x0 + Z + log_phi(a);
-    const double qdivp = 4.0 / kPi * (exp(xb) + exp(xa));
-    return 1.0 / (1.0 + qdivp);
-}
-
-// Standard normal quantile: Wichura (1988), algorithm AS 241 (PPND16), relative accuracy ~1e-16.
 __device__ __forceinline__ double poly8(double x, double k0, double k1, double k2, double k3, double k4, double k5,
                                         double k6, double k7)
 {
     return ((((((k7 * x + k6) * x + k5) * x + k4) * x + k3) * x + k2) * x + k1) * x + k0;
 }
-__device__ inline double ppnd16(double p)
+// -Phi^-1(p) for p in (0, 1/2]: Wichura (1988), algorithm AS 241 (PPND16, relative accuracy ~1e-16), with -log p supplied.
+// The central and the tail formula are both evaluated (a wave meets both); the far tail (p < e^-25) is a real branch.
+__device__ __forceinline__ double pg_neg_quantile(double p, double neg_log_p)
 {
     const double q = p - 0.5;
-    if (fabs(q) <= 0.425) {
-        const double r = 0.180625 - q * q;
-        return q *
-               poly8(r, 3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3, 1.3731693765509461125e4,
-                     4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3) /
-               poly8(r, 1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
-                     2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3);
+    const double rc = 0.180625 - q * q;
+    const double central = -q *
+                           poly8(rc, 3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3, 1.3731693765509461125e4,
+                                 4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3) /
+                           poly8(rc, 1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
+                                 2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3);
+    const double r = sqrt(neg_log_p);
+    const double rt = r - 1.6;
+    double tail = poly8(rt, 1.42343711074968357734, 4.63033784615654529590, 5.76949722146069140550, 3.64784832476320460504,
+                        1.27045825245236838258, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4) /
+                  poly8(rt, 1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
+                        1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9);
+    if (r > 5.0) {
+        const double rf = r - 5.0;
+        tail = poly8(rf, 6.65790464350110377720, 5.46378491116411436990, 1.78482653991729133580, 2.96560571828504891230e-1,
+                     2.65321895265761230930e-2, 1.24266094738807843860e-3, 2.71155556874348757815e-5, 2.01033439929228813265e-7) /
+               poly8(rf, 1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2,
+                     7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7, 2.04426310338993978564e-15);
     }
-    double r = (q < 0.0) ? p : 1.0 - p;
-    r = sqrt(-log(r));
-    double val;
-    if (r <= 5.0) {
-        r -= 1.6;
-        val = poly8(r, 1.42343711074968357734, 4.63033784615654529590, 5.76949722146069140550, 3.64784832476320460504,
-                    1.27045825245236838258, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4) /
-              poly8(r, 1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
-                    1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9);
-    } else {
-        r -= 5.0;
-        val = poly8(r, 6.65790464350110377720, 5.46378491116411436990, 1.78482653991729133580, 2.96560571828504891230e-1,
-                    2.65321895265761230930e-2, 1.24266094738807843860e-3, 2.71155556874348757815e-5, 2.01033439929228813265e-7) /
-              poly8(r, 1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2,
-                    7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7, 2.04426310338993978564e-15);
-    }
-    return (q < 0.0) ? -val : val;
-}
-constexpr double kPgPLevy = 0.1056497736668553;  // Phi(-1/sqrt(t)) = Phi(-1.25)
-
-// IG(1/Z, 1) truncated to (0, t].  Z < 1/t: propose X = 1/N^2 with N a standard normal tail draw
-// |N| >= 1/sqrt(t) taken by inversion (one uniform, no inner rejection loop -- on a 64-lane wave such a
-// loop runs as long as its unluckiest lane), accept with probability exp(-Z^2 X/2).  Z >= 1/t:
-// Michael-Schucany-Haas draws until one falls in (0, t].
-__device__ inline double pg_rtigauss(Cursor &c, double Z)
-{
-    double X = kPgT + 1.0;
-    if (1.0 / kPgT > Z) {
-        for (;;) {
-            const double U1 = c.unif(), U2 = c.unif();
-            const double N = -ppnd16(U1 * kPgPLevy);
-            X = 1.0 / (N * N);
-            if (X > kPgT) X = kPgT;
-            if (U2 <= exp(-0.5 * Z * Z * X)) break;
-        }
-    } else {
-        const double mu = 1.0 / Z;
-        while (X > kPgT) {
-            double Y = c.norm();
-            Y *= Y;
-            const double half_mu = 0.5 * mu, mu_Y = mu * Y;
-            X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-            if (c.unif() > mu / (mu + X)) X = mu * mu / X;
-        }
-    }
-    return X;
+    return (q >= -0.425) ? central : tail;
 }
 
-__device__ inline double pg1_draw(Cursor &c, double z)
+__device__ inline double pg1_draw(uint64_t key, uint32_t index, uint32_t it, uint32_t stream, double z)
 {
     const double Z = 0.5 * fabs(z);
-    // (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loops below, and a
+    // (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loop below, and a
     // wave that never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it.  The
-    // same for a finite argument so large that the series' coefficients overflow to inf x 0 = NaN, past |z| ~ 1e100: every
-    // comparison of the alternating series is then false and its loop never ends)
+    // same for a finite argument past |z| ~ 1e100, where Z^2 overflows)
     if (!(Z < 1.0e100)) return (z - z) * __longlong_as_double(0x7ff8000000000000LL);
     const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
-    const double ptail = pg_mass_texpon(Z);
-    for (;;) {
-        double X;
-        if (c.unif() < ptail) X = kPgT + c.expo() / fz;
-        else X = pg_rtigauss(c, Z);
-        double S = pg_a(0, X);
-        const double Y = c.unif() * S;
-        int n = 0;
-        for (;;) {
-            ++n;
-            if (n & 1) {
-                S -= pg_a(n, X);
-                if (Y <= S) return 0.25 * X;
-            } else {
-                S += pg_a(n, X);
-                if (Y > S) break;
+    const bool below = Z < 1.0 / kPgT;
+    const double ptail = 1.0 / (1.0 + (below ? kPgKBelow : kPgKAbove) * fz * exp(fz * kPgT - (below ? 0.0 : Z)));
+    const double rfz = 1.0 / fz, mu = 1.0 / (below ? 1.0 : Z), hm = 0.5 * mu, hzz = below ? 0.5 * Z * Z : 0.0;
+    const double qc = below ? kPgPLevy : 0.5, lqc = below ? kPgLogPLevy : kPgLogHalf;
+    for (uint32_t r = 0;; ++r) {
+        const Words wa = philox(key, index, 2u * r, it, stream), wb = philox(key, index, 2u * r + 1u, it, stream);
+        const double Um = u01(wa.w0), Ux = u01(wa.w1), U2 = u01(wb.w0), Us = u01(wb.w1);
+        const bool right = Um < ptail;
+        const double lg = log(Ux);
+        const double XR = kPgT - lg * rfz;                          // right piece: t + Exp(1) / f
+        const double N = pg_neg_quantile(Ux * qc, -(lg + lqc));     // left piece
+        const double Y = N * N;
+        const double XA = fmin(1.0 / Y, kPgT);                      // below 1/t: truncated Levy by inversion
+        const double muY = mu * Y;                                  // from 1/t on: IG(1/Z, 1), Michael-Schucany-Haas
+        double XB = mu + hm * muY - hm * sqrt(4.0 * muY + muY * muY);
+        XB = (U2 * (mu + XB) > mu) ? mu * mu / XB : XB;
+        const double X = right ? XR : (below ? XA : XB);
+        const bool in_range = (right || below || !(XB > kPgT)) && X > 0.0;  // (X > 0: always, for a finite Z; a NaN must not reach the series' loop)
+        const bool tilt = !right && below;
+        const double E = exp(tilt ? -hzz * X : 0.0);                // (exp(0) = 1 exactly)
+        const double e1 = exp(right ? -(kPi * kPi) * X : -4.0 / X); // n = 1: -n (n+1) pi^2 X / 2, -2 n (n+1) / X
+        double S = 1.0 - 3.0 * e1;
+        if (in_range && Us <= E * S) return 0.25 * X;
+        if (in_range && !(Us > E)) {  // between the first two partial sums (0.6 % of the proposals): the series goes on
+            bool accepted = false;
+            for (int n = 2; n < 32; ++n) {  // (decided within a few terms; the bound is there so that no lane can stay for ever)
+                const double nn = (double)n * (double)(n + 1);
+                const double rn = (double)(2 * n + 1) * exp(right ? -0.5 * (kPi * kPi) * nn * X : -2.0 * nn / X);
+                if (n & 1) {
+                    S -= rn;
+                    if (Us <= E * S) { accepted = true; break; }
+                } else {
+                    S += rn;
+                    if (Us > E * S) break;
+                }
             }
+            if (accepted) return 0.25 * X;
         }
     }
 }

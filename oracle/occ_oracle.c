@@ -99,7 +99,6 @@ static uint64_t cur_word(cursor_t *c)
     return w[0];
 }
 static double cur_unif(cursor_t *c) { return orc_u01(cur_word(c)); }
-static double cur_expo(cursor_t *c) { return -log(orc_u01(cur_word(c))); }
 static double cur_norm(cursor_t *c)
 {
     uint64_t w[2];
@@ -113,46 +112,45 @@ static double cur_norm(cursor_t *c)
  * point t = 0.64.  Stands where the reference calls polyagamma.random_polyagamma(1, b, ...)
  * (gibbs/logit.py:191-193, 202-204).  Distribution-exact; the reference's own draws come from a
  * third-party C library that is not available, so values are not comparable draw for draw.
+ *
+ * The specification (DESIGN.md "Variate streams"; round 4; csrc/occ_rng.hpp implements the same):
+ * ONE rejection loop.  With Z = |z|/2, f = pi^2/8 + Z^2/2 and Devroye's alternating series
+ * sum (-1)^n a_n(x), the target density is cosh(Z) exp(-Z^2 x/2) sum (-1)^n a_n(x).  Envelope, piecewise:
+ *   x > t            cosh Z (pi/2) exp(-f x)                      mass p  = cosh Z (pi/2) exp(-f t) / f
+ *   x <= t, Z <  1/t  cosh Z l(x), l = 2 Levy(0,1) density         mass q0 cosh Z, q0 = 4 Phi(-1/sqrt t)
+ *                     (the factor exp(-Z^2 x/2) <= 1 is left to the acceptance test)
+ *   x <= t, Z >= 1/t  cosh Z exp(-Z^2 x/2) l(x) = 2 cosh Z e^-Z IG(x; 1/Z, 1), proposed on ALL x > 0,
+ *                     a proposal beyond t rejected                 mass 2 cosh Z e^-Z
+ * so the right piece is proposed with probability 1 / (1 + k f exp(f t - s)), (k, s) = (2 q0 / pi, 0) below 1/t
+ * and (4 / pi, Z) from 1/t on -- cosh Z cancels: one exp, no erfc.  Round r of a draw takes the four words of Philox
+ * blocks 2r and 2r + 1 of the sub-stream: Um (which piece), Ux, U2, Us.
+ *   right piece   X = t - log(Ux) / f
+ *   left piece    N = -Phi^-1(Ux c) by Wichura's AS 241 with -log(Ux c) formed as -(log Ux + log c):
+ *                 Z <  1/t: c = Phi(-1/sqrt t), N >= 1/sqrt t by inversion, X = min(1/N^2, t);
+ *                 Z >= 1/t: c = 1/2, Y = N^2 is chi-square(1), Michael-Schucany-Haas root of IG(1/Z, 1) with U2
+ *                 (the smaller root X kept iff U2 (mu + X) <= mu), round rejected when X > t
+ *   acceptance    Us <= E (1 - r_1 + r_2 - ...), E = exp(-Z^2 X / 2) on the left piece below 1/t and 1 elsewhere,
+ *                 r_n = a_n / a_0 = (2n+1) exp(-2 n (n+1) / X) for X <= t and (2n+1) exp(-n (n+1) pi^2 X / 2) beyond
+ *                 (a_0 itself is never formed), decided by the alternating partial sums.
+ * Rounds 1-3 evaluated the proposal's mass by two erfc and three exp, drew the truncated inverse Gaussian in a
+ * rejection loop of its own and formed a_0, a_1 in full: about twice the arithmetic, in dependent chains.
  * ================================================================================================ */
 #define PG_T 0.64
+#define PG_P_LEVY 0.10564977366685526  /* Phi(-1/sqrt(t)) = Phi(-1.25) */
+#define PG_LOG_P_LEVY (-2.2476256772143182) /* log of it */
+#define PG_LOG_HALF (-0.69314718055994531)
+#define PG_K_BELOW 0.26903493944991954 /* 8 Phi(-1.25) / pi = 2 q0 / pi */
+#define PG_K_ABOVE 1.2732395447351628  /* 4 / pi */
 
-static double pg_a(int n, double x)
-{
-    double K = (n + 0.5) * M_PI;
-    if (x > PG_T) return K * exp(-0.5 * K * K * x);
-    /* K (2/(pi x))^(3/2) exp(-2 (n + 1/2)^2 / x), written without logarithms (the device does the same) */
-    double rx = 1.0 / x;
-    double v = (2.0 / M_PI) * rx;
-    return K * (v * sqrt(v)) * exp(-2.0 * (n + 0.5) * (n + 0.5) * rx);
-}
-static double log_phi(double x) { return log(0.5 * erfc(-x * M_SQRT1_2)); }
-
-/* probability of proposing from the exponential tail, p/(p+q) */
-static double pg_mass_texpon(double Z)
-{
-    double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
-    double b = sqrt(1.0 / PG_T) * (PG_T * Z - 1.0);
-    double a = -sqrt(1.0 / PG_T) * (PG_T * Z + 1.0);
-    if (Z < 20.0) { /* everything is in range: q/p directly, no logarithms (the device does the same) */
-        double pb = 0.5 * erfc(-b * M_SQRT1_2), pa = 0.5 * erfc(-a * M_SQRT1_2);
-        double ez = exp(Z);
-        double qdivp = (4.0 / M_PI) * fz * exp(fz * PG_T) * (pb / ez + ez * pa);
-        return 1.0 / (1.0 + qdivp);
-    }
-    double x0 = log(fz) + fz * PG_T;
-    double xb = x0 - Z + log_phi(b);
-    double xa = x0 + Z + log_phi(a);
-    double qdivp = 4.0 / M_PI * (exp(xb) + exp(xa));
-    return 1.0 / (1.0 + qdivp);
-}
-/* Standard normal quantile, Wichura (1988) algorithm AS 241, PPND16 (relative accuracy ~1e-16). */
 static double horner8(const double *k, double x)
 {
     double r = k[7];
     for (int i = 6; i >= 0; --i) r = r * x + k[i];
     return r;
 }
-static double ppnd16(double p)
+/* -Phi^-1(p) for p in (0, 1/2], Wichura (1988) algorithm AS 241 (PPND16, relative accuracy ~1e-16), with
+ * neg_log_p = -log(p) supplied by the caller */
+static double pg_neg_quantile(double p, double neg_log_p)
 {
     static const double a[8] = {3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3,
                                 1.3731693765509461125e4, 4.5921953931549871457e4, 6.7265770927008700853e4,
@@ -173,79 +171,69 @@ static double ppnd16(double p)
                                 7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7,
                                 2.04426310338993978564e-15};
     const double q = p - 0.5;
-    if (fabs(q) <= 0.425) {
+    if (q >= -0.425) {
         const double r = 0.180625 - q * q;
-        return q * horner8(a, r) / horner8(b, r);
+        return -q * horner8(a, r) / horner8(b, r);
     }
-    double r = (q < 0.0) ? p : 1.0 - p;
-    r = sqrt(-log(r));
-    double val;
-    if (r <= 5.0) { r -= 1.6; val = horner8(cc, r) / horner8(d, r); }
-    else { r -= 5.0; val = horner8(e, r) / horner8(f, r); }
-    return (q < 0.0) ? -val : val;
+    double r = sqrt(neg_log_p);
+    if (r <= 5.0) { r -= 1.6; return horner8(cc, r) / horner8(d, r); }
+    r -= 5.0;
+    return horner8(e, r) / horner8(f, r);
 }
-#define PG_P_LEVY 0.1056497736668553 /* P(N <= -1/sqrt(t)) = Phi(-1.25) */
 
-/* inverse-Gaussian(1/Z, 1) truncated to (0, t].
- * Z < 1/t: Devroye's scheme -- propose from the mu = infinity member truncated to (0, t] (X = 1/N^2 with
- * N standard normal, |N| >= 1/sqrt(t)) and accept with probability exp(-Z^2 X / 2).  The truncated
- * normal tail is drawn by inversion, N = -Phi^-1(U Phi(-1/sqrt t)), instead of the usual pair-of-
- * exponentials rejection loop: one uniform, no inner loop (on a 64-lane wave the inner loop runs as
- * long as its unluckiest lane).
- * Z >= 1/t: Michael-Schucany-Haas draws from IG(1/Z, 1) until one falls in (0, t]. */
-static double pg_rtigauss(cursor_t *c, double Z)
+static double pg1_draw_at(uint64_t key, uint32_t index, uint32_t iter, uint32_t stream, double z)
 {
-    double X = PG_T + 1.0;
-    if (1.0 / PG_T > Z) {
-        for (;;) {
-            const double U1 = cur_unif(c), U2 = cur_unif(c);
-            const double N = -ppnd16(U1 * PG_P_LEVY);
-            X = 1.0 / (N * N);
-            if (X > PG_T) X = PG_T;
-            if (U2 <= exp(-0.5 * Z * Z * X)) break;
-        }
-    } else {
-        double mu = 1.0 / Z;
-        while (X > PG_T) {
-            double Y = cur_norm(c);
-            Y *= Y;
-            double half_mu = 0.5 * mu, mu_Y = mu * Y;
-            X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-            if (cur_unif(c) > mu / (mu + X)) X = mu * mu / X;
-        }
-    }
-    return X;
-}
-static double pg1_draw(cursor_t *c, double z)
-{
-    double Z = 0.5 * fabs(z);
-    double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
-    double ptail = pg_mass_texpon(Z);
-    for (;;) {
+    const double Z = 0.5 * fabs(z);
+    if (!(Z < 1.0e100)) return (z - z) * NAN;  /* (the device returns NaN for these too: occ_rng.hpp) */
+    const double fz = 0.125 * M_PI * M_PI + 0.5 * Z * Z;
+    const int below = Z < 1.0 / PG_T;
+    const double ptail = 1.0 / (1.0 + (below ? PG_K_BELOW : PG_K_ABOVE) * fz * exp(fz * PG_T - (below ? 0.0 : Z)));
+    const double rfz = 1.0 / fz, mu = 1.0 / (below ? 1.0 : Z), hm = 0.5 * mu, hzz = below ? 0.5 * Z * Z : 0.0;
+    for (uint32_t r = 0;; ++r) {
+        uint64_t wa[2], wb[2];
+        philox_words(key, index, 2u * r, iter, stream, wa);
+        philox_words(key, index, 2u * r + 1u, iter, stream, wb);
+        const double Um = orc_u01(wa[0]), Ux = orc_u01(wa[1]), U2 = orc_u01(wb[0]), Us = orc_u01(wb[1]);
+        const int right = Um < ptail;
+        const double lg = log(Ux);
         double X;
-        if (cur_unif(c) < ptail) X = PG_T + cur_expo(c) / fz;
-        else X = pg_rtigauss(c, Z);
-        double S = pg_a(0, X);
-        double Y = cur_unif(c) * S;
-        int n = 0;
-        for (;;) {
-            ++n;
-            if (n & 1) {
-                S -= pg_a(n, X);
-                if (Y <= S) return 0.25 * X;
+        int left_below = 0;
+        if (right) {
+            X = PG_T - lg * rfz;
+        } else {
+            const double N = pg_neg_quantile(Ux * (below ? PG_P_LEVY : 0.5), -(lg + (below ? PG_LOG_P_LEVY : PG_LOG_HALF)));
+            const double Y = N * N;
+            if (below) {
+                X = 1.0 / Y;
+                if (X > PG_T) X = PG_T;
+                left_below = 1;
             } else {
-                S += pg_a(n, X);
-                if (Y > S) break;
+                const double muY = mu * Y;
+                X = mu + hm * muY - hm * sqrt(4.0 * muY + muY * muY);
+                if (U2 * (mu + X) > mu) X = mu * mu / X;
+                if (X > PG_T) continue;  /* beyond the truncation point: the round is rejected */
+            }
+        }
+        if (!(X > 0.0)) continue; /* (never, for a finite Z: the device guards its series loop the same way) */
+        const double E = left_below ? exp(-hzz * X) : 1.0;
+        if (Us > E) continue;  /* above every partial sum */
+        double S = 1.0;
+        for (int n = 1; n < 32; ++n) { /* (decided within a few terms; bounded as on the device) */
+            const double nn = (double)n * (double)(n + 1);
+            const double rn = (double)(2 * n + 1) * (right ? exp(-0.5 * M_PI * M_PI * nn * X) : exp(-2.0 * nn / X));
+            if (n & 1) {
+                S -= rn;
+                if (Us <= E * S) return 0.25 * X;
+            } else {
+                S += rn;
+                if (Us > E * S) break;
             }
         }
     }
 }
 void orc_pg1_array(uint64_t key, uint32_t iter, uint32_t stream, long n, const double *z, double *out)
 {
-    for (long i = 0; i < n; ++i) {
-        cursor_t c = cursor_open(key, (uint32_t)i, iter, stream);
-        out[i] = pg1_draw(&c, z[i]);
-    }
+    for (long i = 0; i < n; ++i) out[i] = pg1_draw_at(key, (uint32_t)i, iter, stream, z[i]);
 }
 
 /* standard gamma, Marsaglia & Tsang (2000); shape < 1 by the U^(1/a) boost.  Stands where the
@@ -691,7 +679,7 @@ int orc_update_omega_b(orc_sampler *s)
 {
     for (long i = 0; i < s->n; ++i) {
         cursor_t c = cursor_open(s->key, (uint32_t)i, s->iter, ORC_STREAM_OMEGA_B);
-        s->omega_b[i] = pg1_draw(&c, xdot(s, i, s->beta) + s->eta[i]);
+        s->omega_b[i] = pg1_draw_at(c.key, c.index, c.iter, c.stream, xdot(s, i, s->beta) + s->eta[i]);
     }
     return 0;
 }
@@ -887,7 +875,7 @@ int orc_update_omega_a(orc_sampler *s)
             double wa = 0.0;
             for (int a = 0; a < s->q; ++a) wa += s->W[r * s->q + a] * s->alpha[a];
             cursor_t c = cursor_open(s->key, (uint32_t)r, s->iter, ORC_STREAM_OMEGA_A);
-            s->omega_a[r] = pg1_draw(&c, wa);
+            s->omega_a[r] = pg1_draw_at(c.key, c.index, c.iter, c.stream, wa);
         }
     }
     return 0;
