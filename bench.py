@@ -205,27 +205,33 @@ class _Solo:
         pass
 
 
-def timed_run(eng, comm, steps, warmup):
+def timed_run(eng, comm, steps, warmup, checkpoint=False):
     """W untimed steps (graph capture included), then exactly K timed steps bracketed by a barrier and a device
-    synchronisation on both sides; the elapsed time is the MAX over ranks.  `eng` may be None (a rank without chains
-    in the 4-chain split): it still takes part in the barriers."""
-    stats_warm = None
+    synchronisation on both sides; the elapsed time is the MAX over ranks.  Every timed iteration is recorded (burnin 0:
+    nothing of the reference's loop is skipped inside the timed region).  `eng` may be None (a rank without chains in the
+    4-chain split): it still takes part in the barriers.  Returns (elapsed, stats before, stats after, the last recorded
+    (alpha, beta, tau) row of every local chain, the chains' state at the start of the timed region when asked for)."""
+    stats_warm, ckpt = None, None
     if eng is not None and warmup > 0:
         eng.run(warmup, warmup - 1)
     if eng is not None:
+        if checkpoint:
+            ckpt = eng.checkpoint()
         stats_warm = eng.stats()
         eng.synchronize()
     comm.barrier()
     t0 = time.perf_counter()
-    rec = eng.run(steps, steps - 1) if eng is not None else None
+    rec = eng.run(steps, 0) if eng is not None else None
     if eng is not None:
         eng.synchronize()
     comm.barrier()
     elapsed = float(comm.allreduce_max(time.perf_counter() - t0))
+    last = []
     if rec is not None:
         a, b, t = rec
-        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(t > 0)
-    return elapsed, stats_warm, (eng.stats() if eng is not None else None)
+        assert a.shape[1] == steps and np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(t > 0)
+        last = [np.concatenate([a[c, -1], b[c, -1], t[c, -1:]]).tolist() for c in range(a.shape[0])]
+    return elapsed, stats_warm, (eng.stats() if eng is not None else None), last, ckpt
 
 
 def main():
@@ -322,7 +328,13 @@ def main():
     eng, mine = make_engine(mine_ids, gens, prob)
     start_engine(eng, mine, mine_ids, gens, starts)
     transport = eng.transport
-    elapsed, stats_warm, stats = timed_run(eng, comm, args.steps, args.warmup)
+    elapsed, stats_warm, stats, last_rows, ckpt0 = timed_run(eng, comm, args.steps, args.warmup, checkpoint=(rank == 0 and not in_process))
+    # every chain's last recorded draw, by global chain number: the draws do not depend on how the chains are spread over
+    # GPUs (chain c owns the generator the reference gives its c-th copy), so a multi-GPU line can be checked against a
+    # one-GPU run of the same chains
+    last_draws = {}
+    for part in comm.allgather_obj(dict(zip(mine_ids, last_rows))):
+        last_draws.update(part)
 
     # ---- N > 1: SURVEY 8(e)'s split of the metric's 4 chains (4 / 2 / 1 / <= 1 per GPU), same steps ---------------
     split = None
@@ -340,12 +352,16 @@ def main():
             eng4, mine4 = make_engine(ids4, gens4, prob)
         if eng4 is not None:
             start_engine(eng4, mine4, ids4, gens4, st4)
-        el4, _, _ = timed_run(eng4, comm, args.steps, args.warmup)
+        el4, _, _, last4, _ = timed_run(eng4, comm, args.steps, args.warmup)
+        split_draws = {}
+        for part in comm.allgather_obj(dict(zip(ids4, last4))):
+            split_draws.update(part)
         if eng4 is not None:
             eng4.close()
         per = [sum(1 for c in range(4) if c % n_dev == g) for g in range(n_dev)]
         split = {'value': 4 * args.steps / el4, 'unit': 'iterations/s', 'scaling': 'strong', 'total_chains': 4,
                  'chains_per_gpu': per, 'ms_per_step': 1e3 * el4 / args.steps,
+                 'last_draws': [split_draws[c] for c in sorted(split_draws)],
                  'note': 'the metric\'s 4 chains, chain c on GPU c % N; one chain alone still pays the whole latency-bound '
                          'iteration (about 65 us at 100x100), so this split gains little over 1 GPU -- the weak line above '
                          '(4 chains on every GPU) is what more GPUs buy'}
@@ -364,7 +380,15 @@ def main():
         eng0 = eng.engines[0] if in_process else eng
         if in_process:
             stats, stats_warm = stats['per_device'][0], stats_warm['per_device'][0]
-        prof = eng0.profile(reps=200)
+        # the profile pass REPLAYS the first 200 launches of the timed region (the chains are put back to where the region
+        # started: same keys, same iterations, same solves), so the dispatch overhead it measures belongs to launches the
+        # timed region made -- same MINRES steps per launch -- not to later ones
+        stats_end = stats
+        replay = ckpt0 is not None
+        if replay:
+            eng0.restore(ckpt0)
+        stats_before_prof = eng0.stats()
+        prof = eng0.profile(reps=min(200, args.steps))
         sell = sell_entry_count(prob)
         fused = bool(stats['persistent_solve']) and prof['iter']['launches'] > 0
         if fused:
@@ -408,24 +432,27 @@ def main():
         dispatch = None
         if fused and disp_us > 0:
             # the same 200 launches by both clocks: what the dispatch adds around the kernel's own view of itself
-            n0, m0 = stats['iter_kernel_launches'], stats['iter_kernel_mean_us']
+            n0, m0 = stats_before_prof['iter_kernel_launches'], stats_before_prof['iter_kernel_mean_us']
             n1, m1 = stats_prof['iter_kernel_launches'], stats_prof['iter_kernel_mean_us']
             in_kernel_prof = (n1 * m1 - n0 * m0) / max(1, n1 - n0)
             overhead = max(0.0, disp_us - in_kernel_prof)
+            m0 = stats_end['iter_kernel_mean_us']
             est = m0 + overhead                     # dispatch duration of the TIMED REGION's launches
             achieved = bytes_launch / (est * 1e-6) / 1e9
             dispatch = {'dispatch_overhead_us': round(overhead, 3), 'profile_pass_dispatch_us': round(disp_us, 3),
                         'profile_pass_in_kernel_us': round(in_kernel_prof, 3), 'profile_pass_launches': int(n1 - n0),
+                        'profile_pass': ('a replay of the first launches of the timed region (chains restored to its start state)' if replay
+                                         else 'further launches that continue the chains after the timed region'),
                         'profile_pass_minres_steps_per_launch': round(stats_prof['profile_minres_iterations'] + 3.0, 2)}
             ka = {'avg_us': est, 'launches': ka['launches']}
             timing = ('mean DISPATCH duration of the k_iter launches of the timed region = their mean by the in-kernel clock '
-                      '(every launch; roofline.in_kernel_clock) + the dispatch overhead measured live on 200 further '
-                      'launches that continue the chains right after it: hipExtLaunchKernel start / stop events (the begin / '
-                      'end timestamps of the dispatch\'s completion signal = what rocprofv3 --kernel-trace reports; launch ramp '
-                      'and end-of-kernel release included) minus the in-kernel clock of the same launches '
-                      '(roofline.dispatch_basis).  HIP events cannot bracket a node of a replayed graph without adding nodes. '
-                      'Check: profiles/r03_bench_trace_region.json = the rocprofv3 kernel trace of this command averaged over '
-                      'the timed region\'s launches')
+                      '(every launch; roofline.in_kernel_clock) + the dispatch overhead measured live on a REPLAY of the '
+                      'region\'s first launches (chains restored to the region\'s start state: the same solves): '
+                      'hipExtLaunchKernel start / stop events (the begin / end timestamps of the dispatch\'s completion signal = '
+                      'what rocprofv3 --kernel-trace reports; launch ramp and end-of-kernel release included) minus the '
+                      'in-kernel clock of the same launches (roofline.dispatch_basis).  HIP events cannot bracket a node of a '
+                      'replayed graph without adding nodes.  Check: profiles/r04_bench_trace_region.json = the rocprofv3 kernel '
+                      'trace of this command averaged over the timed region\'s launches')
         traffic, traffic_file = pmc_traffic('occ::' + kname, f'{rows}x{cols} queen lattice, {C} chains') if args.visits == 5 else (None, None)
         total_us = sum(prof[k]['avg_us'] * per_iter[k] for k in per_iter)
         # SURVEY 8(d)'s whole-iteration accounting beside the dominant kernel's: B_iter(measured K, R_e = R, n_no = 0.4 n)
@@ -444,6 +471,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
+            'last_draws': [last_draws[c] for c in sorted(last_draws)],
             'config': {
                 'workload': f'{rows}x{cols} queen ICAR lattice, {prob.n} sites, {args.visits} visits/site, '
                             f'p=q=2, {C} chains per GPU batched in every kernel (BASELINE configs[1] data, '
