@@ -223,6 +223,7 @@ namespace {
 
 // launch sequences (iterations) per captured graph on the paths that need no host decision between iterations:
 // even, so that the sequence parity is the same at every replay; a graph boundary costs several microseconds
+constexpr int TILES_GB_DEFAULT = 1;  // tiles of a k_tiles workgroup whose gathers are in flight together (T = 4, diagonal form)
 constexpr int GRAPH_SEQ = 2;  // (16 per graph measured the same: the boundary between two replays is not what costs)
 
 #define HIP_TRY(expr)                                                                              \
@@ -512,6 +513,12 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                                                        : s->tiles_T == 2 ? (dia ? k_tiles<8, 2, 1> : k_tiles<8, 2, 0>)
                                                        : s->tiles_T == 3 ? (dia ? k_tiles<8, 3, 1> : k_tiles<8, 3, 0>)
                                                                          : (dia ? k_tiles<8, 4, 1> : k_tiles<8, 4, 0>);
+                if (dia && s->tiles_T == 4) {  // gathers of several tiles in flight together (occ_tiles.hpp, GB); OCC_TILES_GB: developer knob
+                    const char *gb = std::getenv("OCC_TILES_GB");
+                    const int g = gb ? std::atoi(gb) : TILES_GB_DEFAULT;
+                    if (g == 2) kt = k_tiles<8, 4, 1, 2>;
+                    else if (g == 4) kt = k_tiles<8, 4, 1, 4>;
+                }
                 if (s->ext_ev0) hipExtLaunchKernelGGL(kt, gt, bt, lds, st, s->ext_ev0, s->ext_ev1, 0, s->iter, e, fl);
                 else hipLaunchKernelGGL(kt, gt, bt, lds, st, s->iter, e, fl);
             }
@@ -3082,6 +3089,9 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             if (ev) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
             s->parity ^= 1;
             WAIT_TRY(s->stream);
+            // (the side stream too: launched one by one the main stream runs ahead of it, and the NEXT k_iter would spend the
+            // head of its dispatch -- inside the start / stop events, outside its own clock -- waiting for this sequence's noise)
+            if (!one_stream) WAIT_TRY(s->side);
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             total_us[K_ITER] += 1000.0 * ms;

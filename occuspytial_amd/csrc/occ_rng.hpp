@@ -101,8 +101,12 @@ struct Cursor {
 // ---- PG(1, z) -------------------------------------------------------------------------------
 // Devroye's alternating-series sampler for J*(1, z/2)/4 with truncation point t = 0.64, as ONE rejection loop (round 4;
 // the specification and its derivation: oracle/occ_oracle.c "PG(1, z)", DESIGN.md "Variate streams").  Round r of a draw
-// takes the four words of Philox blocks 2r and 2r + 1 of the sub-stream (index, iteration, stream): Um picks the piece of
-// the envelope, Ux proposes on it, U2 picks the Michael-Schucany-Haas root, Us decides.
+// takes Philox block r of the sub-stream (index, iteration, stream), its four 32-bit words (x0, x1, x2, x3): Ux = u01 of
+// the 64-bit word x1:x0 (52 bits: the proposal's variate), Um = (x2 + 1/2) 2^-32 picks the piece of the envelope, Us =
+// (x3 + 1/2) 2^-32 decides -- probabilities to within 2^-33 -- and U2 = (Um - ptail) / (1 - ptail), uniform given that
+// the left piece was picked, picks the Michael-Schucany-Haas root.  (Ten Philox rounds are 15 quarter-rate 32 x 32 -> 64
+// multiplies and as many full-rate instructions again: with two blocks per round they were a third of a round's issue
+// cycles.)
 //   * The probability of the right piece is 1 / (1 + k f exp(f t - s)): the left piece's envelope is the Levy density
 //     itself below Z = 1/t (its tilt exp(-Z^2 x/2) goes into the acceptance test) and the untruncated IG(1/Z, 1) from
 //     1/t on (a proposal beyond t is a rejected round), so cosh Z cancels and no erfc is needed (rounds 1-3: two erfc and
@@ -121,6 +125,16 @@ constexpr double kPgLogHalf = -0.69314718055994531;
 constexpr double kPgKBelow = 0.26903493944991954;     // 8 Phi(-1.25) / pi
 constexpr double kPgKAbove = 1.2732395447351628;      // 4 / pi
 
+// 1 / x to about an ulp: v_rcp_f64 and two Newton steps (5 instructions where the correctly rounded division takes 11)
+__device__ __forceinline__ double pg_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double u32_01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+
 __device__ __forceinline__ double poly8(double x, double k0, double k1, double k2, double k3, double k4, double k5,
                                         double k6, double k7)
 {
@@ -132,17 +146,16 @@ __device__ __forceinline__ double pg_neg_quantile(double p, double neg_log_p)
 {
     const double q = p - 0.5;
     const double rc = 0.180625 - q * q;
-    const double central = -q *
+    const double central = -q * pg_rcp(poly8(rc, 1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
+                                             2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3)) *
                            poly8(rc, 3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3, 1.3731693765509461125e4,
-                                 4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3) /
-                           poly8(rc, 1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
-                                 2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3);
+                                 4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3);
     const double r = sqrt(neg_log_p);
     const double rt = r - 1.6;
     double tail = poly8(rt, 1.42343711074968357734, 4.63033784615654529590, 5.76949722146069140550, 3.64784832476320460504,
-                        1.27045825245236838258, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4) /
-                  poly8(rt, 1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
-                        1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9);
+                        1.27045825245236838258, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4) *
+                  pg_rcp(poly8(rt, 1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
+                               1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9));
     if (r > 5.0) {
         const double rf = r - 5.0;
         tail = poly8(rf, 6.65790464350110377720, 5.46378491116411436990, 1.78482653991729133580, 2.96560571828504891230e-1,
@@ -153,52 +166,85 @@ __device__ __forceinline__ double pg_neg_quantile(double p, double neg_log_p)
     return (q >= -0.425) ? central : tail;
 }
 
+// What a round needs of the draw's argument (formed once per draw)
+struct PgPrep {
+    double ptail, rq, rfz, mu, hzz;  // P(right piece), 1 / (1 - ptail), 1 / f, 1 / Z (from 1/t on; 1 below), Z^2 / 2 (below 1/t; 0 from there on)
+    int below;                       // Z < 1 / t
+};
+__device__ __forceinline__ PgPrep pg_prep(double Z)
+{
+    PgPrep P;
+    const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
+    const bool below = Z < 1.0 / kPgT;
+    P.below = below ? 1 : 0;
+    P.ptail = pg_rcp(1.0 + (below ? kPgKBelow : kPgKAbove) * fz * exp(fz * kPgT - (below ? 0.0 : Z)));
+    P.rfz = pg_rcp(fz);
+    P.mu = pg_rcp(below ? 1.0 : Z);
+    P.hzz = below ? 0.5 * Z * Z : 0.0;
+    P.rq = pg_rcp(1.0 - P.ptail);
+    return P;
+}
+// Round r of the draw (index, iteration, stream): true when the proposal X is accepted.  A function of its arguments alone.
+__device__ __forceinline__ bool pg_trial(const PgPrep &P, uint64_t key, uint32_t index, uint32_t r, uint32_t it, uint32_t stream, double &Xout)
+{
+    const bool below = P.below != 0;
+    const double ptail = P.ptail, mu = P.mu, hm = 0.5 * mu;
+    const double qc = below ? kPgPLevy : 0.5, lqc = below ? kPgLogPLevy : kPgLogHalf;
+    const Words w = philox(key, index, r, it, stream);
+    const double Ux = u01(w.w0), Um = u32_01((uint32_t)w.w1), Us = u32_01((uint32_t)(w.w1 >> 32));
+    const double U2 = (Um - ptail) * P.rq;
+    const bool right = Um < ptail;
+    const double lg = log(Ux);
+    const double XR = kPgT - lg * P.rfz;                        // right piece: t + Exp(1) / f
+    const double N = pg_neg_quantile(Ux * qc, -(lg + lqc));     // left piece
+    const double Y = N * N;
+    const double XA = fmin(pg_rcp(Y), kPgT);                    // below 1/t: truncated Levy by inversion
+    const double muY = mu * Y;                                  // from 1/t on: IG(1/Z, 1), Michael-Schucany-Haas
+    double XB = mu + hm * muY - hm * sqrt(4.0 * muY + muY * muY);
+    XB = (U2 * (mu + XB) > mu) ? mu * mu * pg_rcp(XB) : XB;
+    const double X = right ? XR : (below ? XA : XB);
+    const bool in_range = (right || below || !(XB > kPgT)) && X > 0.0;  // (X > 0: always, for a finite Z; a NaN must not reach the series' loop)
+    const bool tilt = !right && below;
+    const double E = exp(tilt ? -P.hzz * X : 0.0);              // (exp(0) = 1 exactly)
+    const double rX = pg_rcp(X);
+    const double e1 = exp(right ? -(kPi * kPi) * X : -4.0 * rX);  // n = 1: -n (n+1) pi^2 X / 2, -2 n (n+1) / X
+    double S = 1.0 - 3.0 * e1;
+    Xout = X;
+    bool accepted = in_range && Us <= E * S;
+    if (in_range && !accepted && !(Us > E)) {  // between the first two partial sums (0.6 % of the proposals): the series goes on
+        for (int n = 2; n < 32; ++n) {  // (decided within a few terms; the bound is there so that no lane can stay for ever)
+            const double nn = (double)n * (double)(n + 1);
+            const double rn = (double)(2 * n + 1) * exp(right ? -0.5 * (kPi * kPi) * nn * X : -2.0 * nn * rX);
+            if (n & 1) {
+                S -= rn;
+                if (Us <= E * S) { accepted = true; break; }
+            } else {
+                S += rn;
+                if (Us > E * S) break;
+            }
+        }
+    }
+    return accepted;
+}
+
+// (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loop, and a wave that
+// never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it.  The same for a
+// finite argument past |z| ~ 1e100, where Z^2 overflows)
+__device__ __forceinline__ bool pg_bad_argument(double Z) { return !(Z < 1.0e100); }
+
+// One draw: the rounds in turn until one is accepted.  (Round 4 also tried the later rounds of a wave's unfinished draws
+// SPREAD OVER THE WAVE -- round r is a function of (key, index, r, z) alone, so k helper lanes per pending lane evaluated
+// rounds 1 ... k side by side and the wave was done after two passes, bit-identical: correct, and slower -- config 4's
+// k_omega_a 90 us against 82, k_z_ob 64 against 62: at these arguments a wave needs ~2 passes lane by lane as well, and the
+// fetched parameters and the extra registers, 21 spilled at three workgroups per CU, cost more than the rare third pass.)
 __device__ inline double pg1_draw(uint64_t key, uint32_t index, uint32_t it, uint32_t stream, double z)
 {
     const double Z = 0.5 * fabs(z);
-    // (a NaN or infinite argument -- a state that is already broken -- would never leave the rejection loop below, and a
-    // wave that never finishes hangs the device: hand the NaN on, the Cholesky factorisation downstream reports it.  The
-    // same for a finite argument past |z| ~ 1e100, where Z^2 overflows)
-    if (!(Z < 1.0e100)) return (z - z) * __longlong_as_double(0x7ff8000000000000LL);
-    const double fz = 0.125 * kPi * kPi + 0.5 * Z * Z;
-    const bool below = Z < 1.0 / kPgT;
-    const double ptail = 1.0 / (1.0 + (below ? kPgKBelow : kPgKAbove) * fz * exp(fz * kPgT - (below ? 0.0 : Z)));
-    const double rfz = 1.0 / fz, mu = 1.0 / (below ? 1.0 : Z), hm = 0.5 * mu, hzz = below ? 0.5 * Z * Z : 0.0;
-    const double qc = below ? kPgPLevy : 0.5, lqc = below ? kPgLogPLevy : kPgLogHalf;
+    if (pg_bad_argument(Z)) return (z - z) * __longlong_as_double(0x7ff8000000000000LL);
+    const PgPrep P = pg_prep(Z);
     for (uint32_t r = 0;; ++r) {
-        const Words wa = philox(key, index, 2u * r, it, stream), wb = philox(key, index, 2u * r + 1u, it, stream);
-        const double Um = u01(wa.w0), Ux = u01(wa.w1), U2 = u01(wb.w0), Us = u01(wb.w1);
-        const bool right = Um < ptail;
-        const double lg = log(Ux);
-        const double XR = kPgT - lg * rfz;                          // right piece: t + Exp(1) / f
-        const double N = pg_neg_quantile(Ux * qc, -(lg + lqc));     // left piece
-        const double Y = N * N;
-        const double XA = fmin(1.0 / Y, kPgT);                      // below 1/t: truncated Levy by inversion
-        const double muY = mu * Y;                                  // from 1/t on: IG(1/Z, 1), Michael-Schucany-Haas
-        double XB = mu + hm * muY - hm * sqrt(4.0 * muY + muY * muY);
-        XB = (U2 * (mu + XB) > mu) ? mu * mu / XB : XB;
-        const double X = right ? XR : (below ? XA : XB);
-        const bool in_range = (right || below || !(XB > kPgT)) && X > 0.0;  // (X > 0: always, for a finite Z; a NaN must not reach the series' loop)
-        const bool tilt = !right && below;
-        const double E = exp(tilt ? -hzz * X : 0.0);                // (exp(0) = 1 exactly)
-        const double e1 = exp(right ? -(kPi * kPi) * X : -4.0 / X); // n = 1: -n (n+1) pi^2 X / 2, -2 n (n+1) / X
-        double S = 1.0 - 3.0 * e1;
-        if (in_range && Us <= E * S) return 0.25 * X;
-        if (in_range && !(Us > E)) {  // between the first two partial sums (0.6 % of the proposals): the series goes on
-            bool accepted = false;
-            for (int n = 2; n < 32; ++n) {  // (decided within a few terms; the bound is there so that no lane can stay for ever)
-                const double nn = (double)n * (double)(n + 1);
-                const double rn = (double)(2 * n + 1) * exp(right ? -0.5 * (kPi * kPi) * nn * X : -2.0 * nn / X);
-                if (n & 1) {
-                    S -= rn;
-                    if (Us <= E * S) { accepted = true; break; }
-                } else {
-                    S += rn;
-                    if (Us > E * S) break;
-                }
-            }
-            if (accepted) return 0.25 * X;
-        }
+        double X;
+        if (pg_trial(P, key, index, r, it, stream, X)) return 0.25 * X;
     }
 }
 

@@ -172,7 +172,9 @@ __device__ __forceinline__ void tile_beta_terms(const double *Xt, int n, int i, 
 // DIA = 1: the off-diagonals lie on at most eight diagonals with one value each (KryArgs::dia_*: any unweighted lattice) -- a
 // site's neighbours and coefficients are (mask bit, constant offset, constant value): one register per tile where the
 // general (SELL) form keeps 24, which is what lets two tiles per workgroup fit four workgroups of 128 registers on a CU.
-template <int NW, int T, int DIA>
+// GB: tiles of the workgroup whose gathers of g are in flight together in a step (1: tile by tile, as in round 3 -- with the
+// step loop spilling registers more in flight was slower; 2, 4: the round trips of T / GB batches in a row instead of T).
+template <int NW, int T, int DIA, int GB = 1>
 __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterArgs ia, int e, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_state[];  // [T][TILE_VECS][TILE]; phase C: the block partials of beta's system
@@ -265,20 +267,27 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
     double tau_r = 0.0;   // DIA: tau (a coefficient is tau * dia_val[kk], formed where it is used: the same product)
     double dg[T];      // tau * Q_ii + omega_b
     // neighbour kk of tile t's site: offset in the exchange buffers and coefficient
+    // (DIA, in the step loop: a neighbour a site does not have is gathered from an offset OUTSIDE the exchange buffers'
+    // descriptor -- the load returns zeros without touching memory -- so its coefficient can stay the diagonal's uniform
+    // tau * value, a scalar operand: fma(c, 0, h) = h as fma(0, g_i, h) was.  Round 3 selected offset AND coefficient per lane:
+    // 96 v_cndmask per step, or, hoisted out of the loop by the compiler, 96 registers.)
+    constexpr int OOB = 0x7ffffff0;
     auto nb_off = [&](int t, int kk, int i, int myoff) -> int {
-        if constexpr (DIA) return ((dmask >> (8 * t + kk)) & 1u) ? (i + a.dia_off[kk]) * 16 : myoff;
+        if constexpr (DIA) return ((dmask >> (8 * t + kk)) & 1u) ? (i + a.dia_off[kk]) * 16 : OOB;
         else return off[t][kk];
     };
     auto nb_av = [&](int t, int kk) -> double {
-        if constexpr (DIA) return ((dmask >> (8 * t + kk)) & 1u) ? tau_r * a.dia_val[kk] : 0.0;
+        if constexpr (DIA) return tau_r * a.dia_val[kk];
         else return av[t][kk];
     };
     unsigned sc1mask = 0u;  // bit t: this lane's 128-byte line of tile t holds a site with a neighbour in another band
     int wlo = wg, whi = wg;  // the workgroups that hold this workgroup's neighbours (a superset: the range between the extremes)
     bool act[T];
-    double om[T], zv[T];
     double2 gr[T], xr[T];  // g_{k-1} and x of this lane's sites (registers: with them in LDS a CU held six tiles, now eight)
     {
+        // (omega_b and z of the sites are needed here and again in phase C, not in between: phase C loads them again --
+        // 16 registers per lane at T = 4 that the step loop spilled around until round 4)
+        double om[T], zv[T];
         double xb[T], qd[T], en[T], up[T], xav[T][NW];
         double2 x0[T], xn[T][NW];
 #pragma unroll
@@ -475,65 +484,74 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
         const int kb = __builtin_amdgcn_readfirstlane(k % 3), kn = __builtin_amdgcn_readfirstlane((k + 1) % 3), kp = __builtin_amdgcn_readfirstlane((k + 2) % 3);
         const int pa = TV_P + (k & 1), pb = TV_P + ((k + 1) & 1), wa = TV_W + (k & 1), wb = TV_W + ((k + 1) & 1);
         const int e_so = kb * e_stride, e_sp = kp * e_stride, p_so = kb * p_stride, p_sn = kn * p_stride, b_so = kb * b_stride, b_sn = kn * b_stride;  // scalar offsets
-        double part[T][4];
+        constexpr int GBT = GB > T ? T : GB;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int i = (wg * T + t) * TILE + tid;
-            const int myoff = (act[t] ? i : n - 1) * 16;
-            double2 gn;
+        for (int t0 = 0; t0 < T; t0 += GBT) {
+            // g_{k-1} at the neighbours (complete since the sums of step k - 1 arrived), GBT tiles' worth in flight
+            double2 gj[GBT][NW];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) part[t][q] = 0.0;
-            {
-                // g_{k-1} at the neighbours (complete since the sums of step k - 1 arrived)
-                double2 gj[NW];
+            for (int tt = 0; tt < GBT; ++tt) {
+                const int t = t0 + tt;
+                if (t < T) {
+                    const int i = (wg * T + t) * TILE + tid;
+                    const int myoff = (act[t] ? i : n - 1) * 16;
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk) gj[kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_sp, 16));
-                const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
-                // while the gathers travel: w_{k-2}, x_{k-2} (the rotation of iteration k - 2)
-                if (st.rotate) {
-                    const double2 w = kry_form_w(st, p3, st_vec(t, wa), st_vec(t, wb));  // (p_{k-3}, w_{k-4}, w_{k-3})
-                    xr[t].x = fma(st.phi, w.x, xr[t].x);
-                    xr[t].y = fma(st.phi, w.y, xr[t].y);
-                    st_vec(t, wa) = w;
-                    part[t][3] = dot2(xr[t], xr[t]);
+                    for (int kk = 0; kk < NW; ++kk) gj[tt][kk] = unpack_d2(__builtin_amdgcn_raw_buffer_load_b128(ebuf, nb_off(t, kk, i, myoff), e_sp, 16));
                 }
-                const double2 p = kry_form_p(st, g, p3, p2);  // p_{k-1}
-                double hx = dg[t] * g.x, hy = dg[t] * g.y;    // h = A g_{k-1}: the diagonal, then the slots in order
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const double c = nb_av(t, kk);
-                    hx = fma(c, gj[kk].x, hx);
-                    hy = fma(c, gj[kk].y, hy);
-                }
-                gn = kry_form_p(st, make_double2(hx, hy), g2r[t], g);  // g_k
-                st_vec(t, pb) = p;
-                g2r[t] = g;
-                gr[t] = gn;
-                part[t][0] = dot2(p, p);
-                part[t][1] = fma(p.y, gn.y, p.x * gn.x);
-                part[t][2] = (k >= 2) ? dot2(p, p2) : 0.0;
-                if (!act[t]) { part[t][0] = 0.0; part[t][1] = 0.0; part[t][2] = 0.0; part[t][3] = 0.0; }
             }
-            // g_k published (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
-            if (act[t]) {
-                if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 16);
-                else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 0);
+#pragma unroll
+            for (int tt = 0; tt < GBT; ++tt) {
+                const int t = t0 + tt;
+                if (t >= T) continue;
+                const int i = (wg * T + t) * TILE + tid;
+                double2 gn;
+                double part_t[4] = {0.0, 0.0, 0.0, 0.0};
+                {
+                    const double2 g = gr[t], p2 = st_vec(t, pa), p3 = st_vec(t, pb);  // g_{k-1}, p_{k-2}, p_{k-3}
+                    // while the gathers travel: w_{k-2}, x_{k-2} (the rotation of iteration k - 2)
+                    if (st.rotate) {
+                        const double2 w = kry_form_w(st, p3, st_vec(t, wa), st_vec(t, wb));  // (p_{k-3}, w_{k-4}, w_{k-3})
+                        xr[t].x = fma(st.phi, w.x, xr[t].x);
+                        xr[t].y = fma(st.phi, w.y, xr[t].y);
+                        st_vec(t, wa) = w;
+                        part_t[3] = dot2(xr[t], xr[t]);
+                    }
+                    const double2 p = kry_form_p(st, g, p3, p2);  // p_{k-1}
+                    double hx = dg[t] * g.x, hy = dg[t] * g.y;    // h = A g_{k-1}: the diagonal, then the slots in order
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const double c = nb_av(t, kk);
+                        hx = fma(c, gj[tt][kk].x, hx);
+                        hy = fma(c, gj[tt][kk].y, hy);
+                    }
+                    gn = kry_form_p(st, make_double2(hx, hy), g2r[t], g);  // g_k
+                    st_vec(t, pb) = p;
+                    g2r[t] = g;
+                    gr[t] = gn;
+                    part_t[0] = dot2(p, p);
+                    part_t[1] = fma(p.y, gn.y, p.x * gn.x);
+                    part_t[2] = (k >= 2) ? dot2(p, p2) : 0.0;
+                    if (!act[t]) { part_t[0] = 0.0; part_t[1] = 0.0; part_t[2] = 0.0; part_t[3] = 0.0; }
+                }
+                // g_k published (two instructions with complementary lane sets, decided per 128-byte line: see the head of the file)
+                if (act[t]) {
+                    if ((sc1mask >> t) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 16);
+                    else __builtin_amdgcn_raw_buffer_store_b128(pack_d2(gn), ebuf, i * 16, e_so, 0);
+                }
+                // the tile's block partials (block_partials<4>: wave sums, the waves added in wave order further down), out of the
+                // registers at once: held for all T tiles they were 32 registers of the 44 the loop spilled
+                wave_sum4(part_t);  // (the bits of four wave_sum calls)
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s_part[t][wave][q] = part_t[q];
+                }
             }
         }
         SOLVE_STAMP(1)
         // this group's record of step k + 1 (and, band leader, the band's) shows the canary before the one of step k is out
         if (tid < 2) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), pbuf, wg * 32 + tid * 16, p_sn, 0);
         if (band_leader && tid >= 2 && tid < 4) __builtin_amdgcn_raw_buffer_store_b128(pack_d2(rec_canary()), bbuf, (int)my_xcc * 32 + (tid - 2) * 16, b_sn, 16);
-        // -- the sums: block partials per tile (block_partials<4>: wave sums, waves added in wave order), the group's tiles in
-        // tile order, one record
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            wave_sum4(part[t]);  // (the bits of four wave_sum calls)
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s_part[t][wave][q] = part[t][q];
-            }
-        }
+        // -- the sums: the tiles' block partials (above) added in wave order, the group's tiles in tile order, one record
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's g_k (L2, or memory for the write-through lines) and the canaries of step k + 1 are out
         __syncthreads();
         SOLVE_STAMP(3)
@@ -643,6 +661,8 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
             const int i = (wg * T + t) * TILE + tid;
             const double2 x = xr[t];
             double eta = 0.0;
+            const size_t ci = co + (act[t] ? i : n - 1);
+            const double om_t = a.omega_b[it & 1][ci], zv_t = (double)ia.z[ci];  // (as phase A read them)
             if (act[t]) {
                 eta = eta_project(x, proj_a);
                 a.Xv[co + i] = x;
@@ -651,7 +671,7 @@ __global__ void __launch_bounds__(TILE, tiles_wg_per_cu(T)) k_tiles(const IterAr
             // the site's terms of beta's system (beta_site_terms), block partials per tile (block_partials<nacc(P)>)
             int nq = 0;
             double *bpart = reinterpret_cast<double *>(s_state) + (size_t)t * 4 * NACC_MAX;  // [4 waves][NACC_MAX]: the solve's vectors are dead
-            OCC_SWITCH_DIM(P, { nq = nacc(D); tile_beta_terms<D>(ia.Xt, n, i, act[t], om[t], eta, zv[t], bpart + wave * NACC_MAX, lane); });
+            OCC_SWITCH_DIM(P, { nq = nacc(D); tile_beta_terms<D>(ia.Xt, n, i, act[t], om_t, eta, zv_t, bpart + wave * NACC_MAX, lane); });
             __syncthreads();
             if (tid < nq && wg * T + t < nt) {
                 double tv = 0.0;

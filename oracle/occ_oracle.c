@@ -122,8 +122,10 @@ static double cur_norm(cursor_t *c)
  *   x <= t, Z >= 1/t  cosh Z exp(-Z^2 x/2) l(x) = 2 cosh Z e^-Z IG(x; 1/Z, 1), proposed on ALL x > 0,
  *                     a proposal beyond t rejected                 mass 2 cosh Z e^-Z
  * so the right piece is proposed with probability 1 / (1 + k f exp(f t - s)), (k, s) = (2 q0 / pi, 0) below 1/t
- * and (4 / pi, Z) from 1/t on -- cosh Z cancels: one exp, no erfc.  Round r of a draw takes the four words of Philox
- * blocks 2r and 2r + 1 of the sub-stream: Um (which piece), Ux, U2, Us.
+ * and (4 / pi, Z) from 1/t on -- cosh Z cancels: one exp, no erfc.  Round r of a draw takes Philox block r of the
+ * sub-stream, its four 32-bit words (x0, x1, x2, x3): Ux = u01 of the 64-bit word x1:x0 (52 bits: the proposal's variate),
+ * Um = (x2 + 1/2) 2^-32 (which piece), Us = (x3 + 1/2) 2^-32 (the acceptance test) -- probabilities to within 2^-33 --
+ * and U2 = (Um - ptail) / (1 - ptail), which is uniform given that the left piece was picked.
  *   right piece   X = t - log(Ux) / f
  *   left piece    N = -Phi^-1(Ux c) by Wichura's AS 241 with -log(Ux c) formed as -(log Ux + log c):
  *                 Z <  1/t: c = Phi(-1/sqrt t), N >= 1/sqrt t by inversion, X = min(1/N^2, t);
@@ -189,11 +191,12 @@ static double pg1_draw_at(uint64_t key, uint32_t index, uint32_t iter, uint32_t 
     const int below = Z < 1.0 / PG_T;
     const double ptail = 1.0 / (1.0 + (below ? PG_K_BELOW : PG_K_ABOVE) * fz * exp(fz * PG_T - (below ? 0.0 : Z)));
     const double rfz = 1.0 / fz, mu = 1.0 / (below ? 1.0 : Z), hm = 0.5 * mu, hzz = below ? 0.5 * Z * Z : 0.0;
+    const double rq = 1.0 / (1.0 - ptail);
     for (uint32_t r = 0;; ++r) {
-        uint64_t wa[2], wb[2];
-        philox_words(key, index, 2u * r, iter, stream, wa);
-        philox_words(key, index, 2u * r + 1u, iter, stream, wb);
-        const double Um = orc_u01(wa[0]), Ux = orc_u01(wa[1]), U2 = orc_u01(wb[0]), Us = orc_u01(wb[1]);
+        uint64_t w[2];
+        philox_words(key, index, r, iter, stream, w);
+        const double Ux = orc_u01(w[0]), Um = ((double)(uint32_t)w[1] + 0.5) * 0x1.0p-32, Us = ((double)(uint32_t)(w[1] >> 32) + 0.5) * 0x1.0p-32;
+        const double U2 = (Um - ptail) * rq;
         const int right = Um < ptail;
         const double lg = log(Ux);
         double X;

@@ -14,6 +14,7 @@ ap.add_argument('--chains', type=int, default=4)
 ap.add_argument('--iters', type=int, default=2000)
 ap.add_argument('--warm', type=int, default=200)
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--kernels', action='store_true', help='also: in-graph launch time of k_omega_a / k_z_ob / k_omega_b / k_noise (occ_profile)')
 ap.add_argument('libs', nargs='+')
 a = ap.parse_args()
 Q, W, X, y, *_ = make_lattice_problem(a.lattice[0], a.lattice[1], visits=5, p=2, q=2, random_state=0)
@@ -31,7 +32,8 @@ for rep in range(a.reps):
         eng.run(a.warm, a.warm - 1)
         t0 = time.perf_counter(); eng.run(a.iters, a.iters - 1); dt = time.perf_counter() - t0
         st = eng.stats()
-        res[path].append((1e6 * dt / a.iters, st['iter_kernel_mean_us']))
+        pr = eng.profile(50) if a.kernels else None
+        res[path].append((1e6 * dt / a.iters, st['iter_kernel_mean_us']) + ((pr['omega_a']['avg_us'], pr['z_ob']['avg_us'], pr['omega_b']['avg_us'], pr['noise']['avg_us']) if pr else ()))
         eng.close()
 for p, v in res.items():
-    print(p, ' '.join('%.2f/%.2f' % t for t in v))
+    print(p, ' '.join('/'.join('%.2f' % x for x in t) for t in v))
