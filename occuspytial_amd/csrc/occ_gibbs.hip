@@ -1641,6 +1641,10 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         // one XCD whatever the number of chains, two per CU
         if (s->xl_candidate) nmain = s->xl_main;  // 0: none
         if (pb->rsr_dim > 0) nmain = ((ncu * 3 / 4) / 8) * 8;  // reduced-rank model: k_rsr_gram's tiles and the theta solve
+        // ... with a large basis (the m x m system in device memory: k_rsr_gram32, k_rsrb_*) the main sequence is milliseconds of
+        // device-filling kernels and the side sequence 30 us: no partition, one stream (round 3 kept 64 CUs for a side stream
+        // whose k_omega_a spent 4.3 ms of a 4.4 ms iteration waiting at its gate)
+        if (pb->rsr_dim > RSR_MAX_DIM) nmain = 0;
         if (s->tiles) nmain = tiles_main_cus(ncu);             // k_tiles: eight tiles per CU
         if (const char *split = std::getenv("OCC_CU_SPLIT")) {  // developer knob: CUs of the main stream; 0: no masks
             nmain = std::atoi(split);

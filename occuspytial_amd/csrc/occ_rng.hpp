@@ -184,16 +184,24 @@ __device__ __forceinline__ PgPrep pg_prep(double Z)
     P.rq = pg_rcp(1.0 - P.ptail);
     return P;
 }
-// Round r of the draw (index, iteration, stream): true when the proposal X is accepted.  A function of its arguments alone.
-__device__ __forceinline__ bool pg_trial(const PgPrep &P, uint64_t key, uint32_t index, uint32_t r, uint32_t it, uint32_t stream, double &Xout)
+// Round r of the draw (index, iteration, stream), in two parts: the straight-line part -- proposal, tilt, first term of the
+// series: no branch, so that two rounds written one after the other overlap their dependent chains -- and the series'
+// continuation for the 0.6 % of proposals the first test leaves open.  A function of its arguments alone.
+struct PgRound {
+    double X, rX, E, S, Us;
+    bool right, in_range;
+};
+__device__ __forceinline__ PgRound pg_round(const PgPrep &P, uint64_t key, uint32_t index, uint32_t r, uint32_t it, uint32_t stream)
 {
+    PgRound o;
     const bool below = P.below != 0;
     const double ptail = P.ptail, mu = P.mu, hm = 0.5 * mu;
     const double qc = below ? kPgPLevy : 0.5, lqc = below ? kPgLogPLevy : kPgLogHalf;
     const Words w = philox(key, index, r, it, stream);
-    const double Ux = u01(w.w0), Um = u32_01((uint32_t)w.w1), Us = u32_01((uint32_t)(w.w1 >> 32));
+    const double Ux = u01(w.w0), Um = u32_01((uint32_t)w.w1);
+    o.Us = u32_01((uint32_t)(w.w1 >> 32));
     const double U2 = (Um - ptail) * P.rq;
-    const bool right = Um < ptail;
+    o.right = Um < ptail;
     const double lg = log(Ux);
     const double XR = kPgT - lg * P.rfz;                        // right piece: t + Exp(1) / f
     const double N = pg_neg_quantile(Ux * qc, -(lg + lqc));     // left piece
@@ -202,25 +210,29 @@ __device__ __forceinline__ bool pg_trial(const PgPrep &P, uint64_t key, uint32_t
     const double muY = mu * Y;                                  // from 1/t on: IG(1/Z, 1), Michael-Schucany-Haas
     double XB = mu + hm * muY - hm * sqrt(4.0 * muY + muY * muY);
     XB = (U2 * (mu + XB) > mu) ? mu * mu * pg_rcp(XB) : XB;
-    const double X = right ? XR : (below ? XA : XB);
-    const bool in_range = (right || below || !(XB > kPgT)) && X > 0.0;  // (X > 0: always, for a finite Z; a NaN must not reach the series' loop)
-    const bool tilt = !right && below;
-    const double E = exp(tilt ? -P.hzz * X : 0.0);              // (exp(0) = 1 exactly)
-    const double rX = pg_rcp(X);
-    const double e1 = exp(right ? -(kPi * kPi) * X : -4.0 * rX);  // n = 1: -n (n+1) pi^2 X / 2, -2 n (n+1) / X
-    double S = 1.0 - 3.0 * e1;
-    Xout = X;
-    bool accepted = in_range && Us <= E * S;
-    if (in_range && !accepted && !(Us > E)) {  // between the first two partial sums (0.6 % of the proposals): the series goes on
+    o.X = o.right ? XR : (below ? XA : XB);
+    o.in_range = (o.right || below || !(XB > kPgT)) && o.X > 0.0;  // (X > 0: always, for a finite Z; a NaN must not reach the series' loop)
+    const bool tilt = !o.right && below;
+    o.E = exp(tilt ? -P.hzz * o.X : 0.0);                       // (exp(0) = 1 exactly)
+    o.rX = pg_rcp(o.X);
+    const double e1 = exp(o.right ? -(kPi * kPi) * o.X : -4.0 * o.rX);  // n = 1: -n (n+1) pi^2 X / 2, -2 n (n+1) / X
+    o.S = 1.0 - 3.0 * e1;
+    return o;
+}
+__device__ __forceinline__ bool pg_accept(const PgRound &o)
+{
+    bool accepted = o.in_range && o.Us <= o.E * o.S;
+    if (o.in_range && !accepted && !(o.Us > o.E)) {  // between the first two partial sums (0.6 % of the proposals): the series goes on
+        double S = o.S;
         for (int n = 2; n < 32; ++n) {  // (decided within a few terms; the bound is there so that no lane can stay for ever)
             const double nn = (double)n * (double)(n + 1);
-            const double rn = (double)(2 * n + 1) * exp(right ? -0.5 * (kPi * kPi) * nn * X : -2.0 * nn * rX);
+            const double rn = (double)(2 * n + 1) * exp(o.right ? -0.5 * (kPi * kPi) * nn * o.X : -2.0 * nn * o.rX);
             if (n & 1) {
                 S -= rn;
-                if (Us <= E * S) { accepted = true; break; }
+                if (o.Us <= o.E * S) { accepted = true; break; }
             } else {
                 S += rn;
-                if (Us > E * S) break;
+                if (o.Us > o.E * S) break;
             }
         }
     }
@@ -232,19 +244,21 @@ __device__ __forceinline__ bool pg_trial(const PgPrep &P, uint64_t key, uint32_t
 // finite argument past |z| ~ 1e100, where Z^2 overflows)
 __device__ __forceinline__ bool pg_bad_argument(double Z) { return !(Z < 1.0e100); }
 
-// One draw: the rounds in turn until one is accepted.  (Round 4 also tried the later rounds of a wave's unfinished draws
-// SPREAD OVER THE WAVE -- round r is a function of (key, index, r, z) alone, so k helper lanes per pending lane evaluated
-// rounds 1 ... k side by side and the wave was done after two passes, bit-identical: correct, and slower -- config 4's
-// k_omega_a 90 us against 82, k_z_ob 64 against 62: at these arguments a wave needs ~2 passes lane by lane as well, and the
-// fetched parameters and the extra registers, 21 spilled at three workgroups per CU, cost more than the rare third pass.)
+// One draw: the rounds in turn until one is accepted.
+// (Round 4 tried two ways of not waiting for a wave's unluckiest lane, both bit-identical to this loop, both slower.  The later
+// rounds of a wave's unfinished draws SPREAD OVER THE WAVE -- k helper lanes per pending lane evaluating its rounds 1 ... k side
+// by side: config 4's k_omega_a 90 us against 82, k_z_ob 64 against 62; the fetched parameters and the extra registers, 21
+// spilled at three workgroups per CU, cost more than the rare third pass.  Rounds r and r + 1 evaluated TOGETHER in one pass
+// for the sake of a lone wave's latency -- k_z_ob's draws, one wave per SIMD, are 8.5 us of its 14 -- : two copies of the
+// round need 280 registers, one workgroup per CU, k_z_ob 14 -> 30 us.)
 __device__ inline double pg1_draw(uint64_t key, uint32_t index, uint32_t it, uint32_t stream, double z)
 {
     const double Z = 0.5 * fabs(z);
     if (pg_bad_argument(Z)) return (z - z) * __longlong_as_double(0x7ff8000000000000LL);
     const PgPrep P = pg_prep(Z);
     for (uint32_t r = 0;; ++r) {
-        double X;
-        if (pg_trial(P, key, index, r, it, stream, X)) return 0.25 * X;
+        const PgRound a = pg_round(P, key, index, r, it, stream);
+        if (pg_accept(a)) return 0.25 * a.X;
     }
 }
 

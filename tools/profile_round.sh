@@ -1,13 +1,13 @@
 #!/bin/bash
 # Developer script (GPU box): the profiles a round commits.  Usage: bash tools/profile_round.sh r03 [part ...]
-# (parts: bench pmc c4 rsr rsrb sizes line; default: all).  Every rocprofv3 command line is echoed into
+# (parts: bench pmc c4 valu rsr rsrb sizes line; default: all).  Every rocprofv3 command line is echoed into
 # $out/commands.log (and copied to profiles/<tag>_commands.log): the flags a number was taken with are part of the
 # evidence.  Counter passes (--pmc) never share a command with a trace domain other than --kernel-trace, and run the
 # engine eagerly (OCC_EAGER_ONLY=1: counter collection cannot follow hipGraph launches on ROCm 7.2).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 shift || true
-parts=${*:-bench pmc c4 rsr rsrb sizes line}
+parts=${*:-bench pmc c4 valu rsr rsrb sizes line}
 out=gpurun_out/prof_$tag
 mkdir -p $out profiles
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -22,6 +22,9 @@ cp "$(ls -t $out/stats/*/*kernel_stats.csv | head -n 1)" profiles/${tag}_bench_k
 cp "$(ls -t $out/stats/*/*domain_stats.csv | head -n 1)" profiles/${tag}_bench_domain_stats.csv || true
 tail -n 1 $out/bench_under_rocprof.json > profiles/${tag}_bench_under_rocprof.json
 python3 tools/trace_region.py "$(ls -t $out/stats/*/*kernel_trace.csv | head -n 1)" 200 2000 profiles/${tag}_bench_trace_region.json > $out/trace_region.log
+# ... and of the driver's own short call
+run rocprofv3 --kernel-trace --output-format csv -d $out/stats20 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench20_under_rocprof.json 2> $out/stats20.log
+python3 tools/trace_region.py "$(ls -t $out/stats20/*/*kernel_trace.csv | head -n 1)" 5 20 profiles/${tag}_bench_20_steps_trace_region.json > $out/trace_region20.log
 fi
 if has pmc; then
 # 2. HBM traffic per kernel: separate counter passes, eager launches
@@ -41,6 +44,20 @@ OCC_EAGER_ONLY=1 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/c4_w
 python3 tools/pmc_traffic.py $out/c4_fetch $out/c4_write profiles/${tag}_c4_pmc_hbm_traffic.json "500x500 queen lattice, 1 chains" > $out/c4_pmc.log
 python3 bench.py $C4 2> $out/c4_bench.err | tail -n 1 > profiles/${tag}_c4_bench.json
 OCC_NO_TILES=1 python3 bench.py $C4 2> $out/c4_lps.err | tail -n 1 > profiles/${tag}_c4_bench_launch_per_step.json
+fi
+if has valu; then
+# 3b. the Polya-Gamma kernels, SQ counters, BEFORE (round 3's build, tools/libocc_gibbs_r3.so: built by hand from commit c4e04c1,
+#     see DESIGN 6.2) and AFTER, config 4 and the headline, eager launches
+SQC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+echo "OCC_EAGER_ONLY=1 [OCC_LIB=tools/libocc_gibbs_r3.so]" >> $out/commands.log
+if [ -f tools/libocc_gibbs_r3.so ]; then
+OCC_LIB=tools/libocc_gibbs_r3.so OCC_EAGER_ONLY=1 run rocprofv3 --pmc $SQC --output-format csv -d $out/valu_c4_before -- python3 tools/pmc_run.py 500 500 1 10 > $out/valu_c4_before.log 2>&1
+OCC_LIB=tools/libocc_gibbs_r3.so OCC_EAGER_ONLY=1 run rocprofv3 --pmc $SQC --output-format csv -d $out/valu_head_before -- python3 tools/pmc_run.py 100 100 4 30 > $out/valu_head_before.log 2>&1
+fi
+OCC_EAGER_ONLY=1 run rocprofv3 --pmc $SQC --output-format csv -d $out/valu_c4_after -- python3 tools/pmc_run.py 500 500 1 10 > $out/valu_c4_after.log 2>&1
+OCC_EAGER_ONLY=1 run rocprofv3 --pmc $SQC --output-format csv -d $out/valu_head_after -- python3 tools/pmc_run.py 100 100 4 30 > $out/valu_head_after.log 2>&1
+python3 tools/pmc_valu.py profiles/${tag}_pmc_valu.json c4_before=$out/valu_c4_before c4_after=$out/valu_c4_after headline_before=$out/valu_head_before headline_after=$out/valu_head_after > $out/valu.log 2>&1
+cat $out/valu.log
 fi
 if has rsr; then
 # 4. the reduced-rank sampler (LogitRSRGibbs), LDS-resident solve (m = 100)
