@@ -104,10 +104,6 @@ struct occ_sampler {
     bool persistent = false;
     int iter_window = 8;     // neighbour window of k_iter: 8 (two workgroups per CU) or 16 (rows of 9-16 off-diagonals, one per CU)
     bool xcd_local = false;  // k_iter<8, 1>: one XCD per chain, exchange through that XCD's L2 (occ_iter.hpp)
-    // k_iter's TAIL (occ_iter.hpp): the scalar-wave form can do k_z_ob's work as its last phase -- one kernel per iteration on
-    // the main stream.  iter_tail: the engine's form allows it; tail_now: the sequence being built / launched uses it (hand-overs
-    // by device counters, or everything on one stream: with event nodes the side chain joins between k_iter and k_z_ob)
-    bool iter_tail = false, tail_now = false;
     bool xl_candidate = false, fused_fallback = false;
     // k_tiles (occ_tiles.hpp): the persistent solve for problems too large for k_iter -- tiles of 256 sites with their vectors
     // in LDS, T tiles per workgroup, G workgroups per chain in eight bands of B (one per XCD).  tiles_layout: the problem has
@@ -532,15 +528,13 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                     ia.chain_base = base;
                     if (s->ext_ev0 && base == 0) {  // occ_profile: the dispatch's own begin / end timestamps
                         const int fl = (s->launch_sync ? 1 : 0) | s->iter_flags_extra;
-                        if (s->xl_wide == 1 && s->tail_now) hipExtLaunchKernelGGL((k_iter<8, 1, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
-                        else if (s->xl_wide == 1) hipExtLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
+                        if (s->xl_wide == 1) hipExtLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         else if (s->xl_wide == 2) hipExtLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         else if (s->iter_window == 16) hipExtLaunchKernelGGL((k_iter<16, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         else hipExtLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, s->ext_ev0, s->ext_ev1, 0, ia, e, fl);
                         continue;
                     }
-                    if (s->xl_wide == 1 && s->tail_now) hipLaunchKernelGGL((k_iter<8, 1, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra | ((s->zob_debug & 16) ? 4 : 0) | ((s->zob_debug & 8) ? 8 : 0));
-                    else if (s->xl_wide == 1) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
+                    if (s->xl_wide == 1) hipLaunchKernelGGL((k_iter<8, 1, 1>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else if (s->xl_wide == 2) hipLaunchKernelGGL((k_iter<8, 1, 2>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG_XL), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else if (s->iter_window == 16) hipLaunchKernelGGL((k_iter<16, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
                     else hipLaunchKernelGGL((k_iter<8, 1, 0>), dim3(XL_SLOTS * (unsigned)(ia.nbg + 1)), dim3(ITER_WG), 0, st, ia, e, (s->launch_sync ? 1 : 0) | s->iter_flags_extra);
@@ -585,9 +579,6 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
             s->launch_err = s->err;                          \
         }                                                    \
     } while (0)
-// k_iter does k_z_ob's work as its last phase (occ_iter.hpp, TAIL) in the sequence being built: the engine's form allows it
-static bool tail_form(const occ_sampler *s) { return s->rsr.m == 0 && s->persistent && s->xcd_local && s->xl_wide == 1 && s->iter_tail && !s->tiles; }
-
 int take_launch_rc(occ_sampler *s)
 {
     const int rc = s->launch_rc;
@@ -694,7 +685,6 @@ int eager_sequence(occ_sampler *s)
     }
     LAUNCH(s, s->stream, K_OMEGA_A, e);
     LAUNCH(s, s->stream, K_NOISE, e, 1);
-    s->tail_now = tail_form(s);  // (one stream: alpha of this iteration is there before k_iter starts)
     if (s->persistent) {
         LAUNCH(s, s->stream, K_ITER, e);
     } else {
@@ -705,8 +695,7 @@ int eager_sequence(occ_sampler *s)
         s->calib_max = std::max(s->calib_max, k_last - 3);
         LAUNCH(s, s->stream, K_BETA_PARTIAL, e, k_last);
     }
-    if (!s->tail_now) LAUNCH(s, s->stream, K_Z_OB, e);
-    s->tail_now = false;
+    LAUNCH(s, s->stream, K_Z_OB, e);
     s->parity ^= 1;
     s->eager_iterations += 1;
     return take_launch_rc(s);
@@ -782,7 +771,6 @@ int build_graph(occ_sampler *s, int cap)
         WAIT_TRY(s->side);
         HIP_TRY(fill_on(s, s->ctx.sync, 0, sizeof(unsigned) * SYNC_DEBUG));
         HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        s->tail_now = tail_form(s);  // (hand-overs by device counters: the tail waits for alpha itself)
         for (int t = 0; t < GRAPH_SEQ; ++t) {
             const int e = s->parity ^ (t & 1);
             if (s->rsr.m > 0) {  // reduced-rank model: k_rsr_gram opens the sequence as k_iter does
@@ -792,9 +780,8 @@ int build_graph(occ_sampler *s, int cap)
             } else {
                 LAUNCH(s, s->stream, K_ITER, e);
             }
-            if (!s->tail_now) LAUNCH(s, s->stream, K_Z_OB, e);
+            LAUNCH(s, s->stream, K_Z_OB, e);
         }
-        s->tail_now = false;
         HIP_TRY(hipStreamEndCapture(s->stream, &s->head_graph[0]));
         HIP_TRY(hipGraphInstantiate(&s->head[0], s->head_graph[0], nullptr, nullptr, 0));
         HIP_TRY(hipStreamBeginCapture(s->side, hipStreamCaptureModeThreadLocal));
@@ -960,9 +947,8 @@ int open_window(occ_sampler *s, int64_t n_iter, int64_t burnin, int64_t keep, bo
     std::memcpy(s->pin_sc, h.data(), sizeof(ChainScalars) * h.size());  // (free again: the last copy from it was followed by a wait for the stream)
     HIP_TRY(hipMemcpyAsync(c.sc, s->pin_sc, sizeof(ChainScalars) * h.size(), hipMemcpyHostToDevice, s->stream));
     if (run && c.iter_clock) {  // k_iter's clock counts this run only
-        HIP_TRY(hipMemsetAsync(c.iter_clock, 0, 8 * sizeof(unsigned long long), s->stream));      // [1] latest end, [2] sum, [3] launches; [5]: parity 1's end
         HIP_TRY(hipMemsetAsync(c.iter_clock, 0xff, sizeof(unsigned long long), s->stream));       // [0] = ~0: the earliest start so far
-        HIP_TRY(hipMemsetAsync(c.iter_clock + 4, 0xff, sizeof(unsigned long long), s->stream));   // [4]: parity 1's (k_iter's tail)
+        HIP_TRY(hipMemsetAsync(c.iter_clock + 1, 0, 3 * sizeof(unsigned long long), s->stream));  // [1] latest end, [2] sum, [3] launches
     }
     return OCC_OK;
 }
@@ -1215,11 +1201,9 @@ int residency_probe(occ_sampler *s, bool *ok)
     int rc;
     for (int rep = 0; rep < 3 && *ok; ++rep) {
         s->iter_flags_extra = 2;
-        s->tail_now = s->iter_tail && s->xcd_local && s->xl_wide == 1 && !s->tiles;  // (the instantiation the engine will launch: its registers and LDS)
         HIP_TRY(fill_on(s, s->ctx.claim, 0, sizeof(unsigned) * (size_t)s->ctx.C * 16));
         LAUNCH(s, s->stream, K_ITER, 0);
         s->iter_flags_extra = 0;
-        s->tail_now = false;
         if ((rc = take_launch_rc(s))) return rc;
         if ((rc = read_scalars(s, h))) return rc;
         for (auto &sc : h)
@@ -1826,7 +1810,7 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         s->iter.tiles_T = s->tiles_T; s->iter.tiles_G = s->tiles_G; s->iter.tiles_B = s->tiles_B;
     }
     if (s->persistent) {
-        if ((rc = dev_alloc(s, &c.iter_clock, 8))) return rc;  // {start, end} of parity 0, {sum, launches}, {start, end} of parity 1 (k_iter's tail)
+        if ((rc = dev_alloc(s, &c.iter_clock, 4))) return rc;
         s->iter.clock = c.iter_clock;
         if ((rc = dev_alloc(s, &c.bar, (size_t)C * BAR_STRIDE))) return rc;
         if ((rc = dev_alloc(s, &c.claim, (size_t)C * 16))) return rc;
@@ -1866,7 +1850,6 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         t.Xt = c.Xt; t.z = c.z;
         for (int b = 0; b < 2; ++b) { t.enorm[b] = c.enorm[b]; t.uprior[b] = c.uprior[b]; }
         t.rhs = c.rhs; t.eta = c.eta; t.part_quad = c.part_quad; t.part_beta = c.part_beta;
-        t.ctx = s->ctx_dev;
         t.tau_rate = c.tau_rate; t.tau_shape = c.tau_shape;
         t.C = c.C; t.p = c.p; t.q = c.q;
     }
@@ -1887,13 +1870,12 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         if (s->xl_candidate) {
             s->xcd_local = true;
             s->iter.nbg = s->xl_nbg;
-            s->iter_tail = s->xl_wide == 1 && !std::getenv("OCC_NO_TAIL");  // (diagnostic: k_z_ob as a kernel of its own, as until round 4)
             ok = trust;
             if (!trust && (rc = residency_probe(s, &ok))) return rc;
             if (std::getenv("OCC_VERBOSE"))
                 std::fprintf(stderr, "[occ] one XCD per chain: %d workgroups of %d threads per chain, main stream %d CUs (%d on a chain's XCD): %s\n",
                              s->xl_nbg, s->xl_wide ? ITER_WG_XL : ITER_WG, s->main_cus, s->main_hot_cus, ok ? "resident" : "NOT resident");
-            if (!ok) { s->xcd_local = false; s->iter_tail = false; }
+            if (!ok) s->xcd_local = false;
         }
         if (!ok && s->any_fits) {
             s->xl_wide = 0;
@@ -3027,12 +3009,8 @@ int occ_get_stats(occ_sampler *s, occ_stats *out)
     out->iter_kernel_launches = 0;
     out->iter_kernel_mean_us = 0.0;
     if (s->ctx.iter_clock) {
-        unsigned long long clk[8];
+        unsigned long long clk[4];
         HIP_TRY(copy_on(s, clk, s->ctx.iter_clock, sizeof(clk), hipMemcpyDeviceToHost));
-        if (s->iter_tail) {  // (with the tail a launch's {start, end} is folded into the sum by the NEXT launch: the last ones here)
-            for (int pe : {0, 4})
-                if (clk[pe + 1] != 0ull && clk[pe] != ~0ull) { clk[2] += clk[pe + 1] - clk[pe]; clk[3] += 1ull; }
-        }
         int khz = 0;
         HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device));
         out->iter_kernel_launches = (int64_t)clk[3];
@@ -3107,13 +3085,11 @@ int occ_profile(occ_sampler *s, int32_t reps, int64_t counts[OCC_N_KERNEL_KINDS]
             HIP_TRY(hipEventRecord(s->ev0, s->stream));
             s->ext_ev0 = pev[0];  // the dispatch's own start / stop (hipExtLaunchKernel): rocprofv3's basis for a kernel's duration
             s->ext_ev1 = pev[1];
-            s->tail_now = tail_form(s) && !ev;  // (as occ_run launches it in this mode)
             LAUNCH(s, s->stream, K_ITER, pe);
             s->ext_ev0 = s->ext_ev1 = nullptr;
             HIP_TRY(hipEventRecord(s->ev1, s->stream));
             if (ev) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_side[pe], 0));
-            if (!s->tail_now) LAUNCH(s, s->stream, K_Z_OB, pe);
-            s->tail_now = false;
+            LAUNCH(s, s->stream, K_Z_OB, pe);
             if (ev) HIP_TRY(hipEventRecord(s->ev_z[pe], s->stream));
             s->parity ^= 1;
             WAIT_TRY(s->stream);

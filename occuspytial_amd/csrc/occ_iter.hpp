@@ -79,9 +79,8 @@ struct IterArgs {
     const uint8_t *z;
     const double *enorm[2], *uprior[2];
     double *rhs, *eta;
-    double *part_quad;    // read by phase A (the previous sequence's); written by the tail (TAIL: the coming sequence's)
+    const double *part_quad;
     double *part_beta;
-    const Ctx *ctx;       // the device copy of the descriptor (TAIL: the z update and the records go through it, off the solve's path)
     double tau_rate, tau_shape;
     unsigned *bar;        // [C][BAR_STRIDE]
     unsigned *claim;      // [C][16] one XCD per chain: the next free workgroup slot of the chain
@@ -337,163 +336,6 @@ __device__ __forceinline__ bool poll_slice_records(__amdgpu_buffer_rsrc_t buf, i
     return true;
 }
 
-// ---- k_iter's tail (template parameter TAIL): the rest of the iteration, k_z_ob's work --------------------------------------
-// What the last kernel of a main-stream sequence hands to the next sequence (k_z_ob's writer, occ_kernels.hpp): the control
-// word of the other parity, the sequence number, the slot counter of the OTHER parity (this launch's own may still be claimed
-// from by workgroups of its grid that arrive late), by one thread per chain.
-__device__ __forceinline__ void iter_tail_handover(const IterArgs &ia, ChainScalars &sc, int chain, Ctl ctl, int e, bool advance, bool synced)
-{
-    Ctl nx = ctl;  // a chain that idles (or failed) keeps its iteration number
-    if (advance) nx.it = ctl.it + 1u;
-    sc.ctl[e ^ 1] = nx;
-    if (chain == ia.chain_base && synced) ia.sync[SYNC_MAIN_SEQ + (e ^ 1)] = ia.sync[SYNC_MAIN_SEQ + e] + 1u;
-    ia.claim[(size_t)chain * 16 + ((e ^ 1) & 1)] = 0u;
-}
-// The clock of a launch with the tail: {earliest start, latest end} in the pair of the sequence's parity (words 0, 1 / 4, 5 of
-// Ctx::iter_clock); the launch folds the OTHER pair -- the previous launch's, complete -- into {sum, launches} (words 2, 3) at
-// its start, the host adds the last one (occ_get_stats).  (Without the tail k_z_ob folds pair 0 behind every k_iter.)
-__device__ __forceinline__ void iter_tail_fold_clock(unsigned long long *clock, int e)
-{
-    unsigned long long *prev = clock + ((e & 1) ? 0 : 4);
-    if (prev[1] != 0ull) {
-        clock[2] += prev[1] - prev[0];
-        clock[3] += 1ull;
-        prev[0] = ~0ull;
-        prev[1] = 0ull;
-    }
-}
-// beta, omega_b of the next iteration with the partial sums of eta'Q eta, the z update, the record: logit.py:232, 195-204,
-// 208, 234-252, base.py:238-239 -- k_z_ob's operations in k_z_ob's order (reduce_partials' order, precision_mvnorm_reg, the fma
-// chains of x'beta, pg1_draw, quad_site, the z update's expit products, the record): the same bits.  Called by every thread of
-// every workgroup of the chain behind a chain barrier (eta and the partial sums of beta's system of the whole chain are in
-// the XCD's L2).  Only the beta draw depends on the number of covariates at compile time (register arrays): the rest runs on
-// the run-time p, so that the Polya-Gamma sampler's code exists once.
-template <int D>
-__device__ __forceinline__ bool iter_tail_beta(const IterArgs &ia, const Ctx &c, const ChainScalars &sc, int chain, uint32_t it, int lane, double (&beta8)[MAXC])
-{
-    const int nb = ia.a.nb_n;
-    double sums[nacc(D)], beta[D];
-    const double *pb = ia.part_beta + (size_t)chain * nacc(D) * nb;
-    reduce_partials_wave<nacc(D)>(nb, lane, sums, [&](int idx) { return load_agent(pb + idx); });
-    const double *b_prec = c.hyp + c.q * c.q + c.q, *b_pbm = b_prec + D * D;
-    const bool ok = precision_mvnorm_reg<D>(sums, b_prec, b_pbm, sc.key, it, STREAM_BETA, beta);
-#pragma unroll
-    for (int aa = 0; aa < MAXC; ++aa) beta8[aa] = 0.0;
-#pragma unroll
-    for (int aa = 0; aa < D; ++aa) beta8[aa] = beta[aa];
-    return ok;
-}
-// (debug: bit 2 of k_iter's flags = no omega_b draw, bit 3 = no z update -- timing experiments, OCC_DEBUG_ZOB_SKIP)
-// The z update of a site is a chain of dependent loads (surveyed index -> detection flag, row range -> the visits' design rows)
-// in front of a few expit's: as k_z_ob's role it hides beside the Polya-Gamma blocks, here it would follow the draw on the same
-// lanes (8.3 us, measured).  So its inputs are fetched FIRST -- alpha is there (thread 0 waited for the side stream before the
-// chain barrier), the design rows of up to ZPRE visits go into w'alpha at once -- and travel while beta is drawn and during
-// the Polya-Gamma draw; what is left behind the draw is arithmetic.
-constexpr int ZPRE = 8;
-__device__ __forceinline__ void iter_tail(const IterArgs &ia, ChainScalars &sc, int chain, uint32_t it, int e, int i, bool act, int slice, bool slice_act,
-                                          int lane, double eta, double tau, bool synced, bool writer, bool scalar_wave, double *s_beta, const int *s_alpha_ok, int dbg)
-{
-    const Ctx &c = *ia.ctx;
-    const KryArgs &a = ia.a;
-    const int n = a.n, nb = a.nb_n, P = ia.p, Q = c.q;
-    double alpha[MAXC];
-    if (synced) {
-        if (!*s_alpha_ok && writer) sc.err = -2;
-#pragma unroll
-        for (int aa = 0; aa < MAXC; ++aa) alpha[aa] = (aa < Q) ? load_agent(&sc.alpha[aa]) : 0.0;
-    } else {
-#pragma unroll
-        for (int aa = 0; aa < MAXC; ++aa) alpha[aa] = (aa < Q) ? sc.alpha[aa] : 0.0;
-    }
-    // ---- the z update's inputs (z_update_site's loads, its w'alpha chains in its order)
-    bool zdo = false, not_surveyed = true;
-    int r0 = 0, nvis = 0;
-    double wa[ZPRE];
-#pragma unroll
-    for (int k = 0; k < ZPRE; ++k) wa[k] = 0.0;
-    if (!scalar_wave && act && !(dbg & 8)) {
-        const int sidx = c.site_sidx[i];
-        not_surveyed = sidx < 0;
-        zdo = not_surveyed || !c.obs_site[sidx];  // (a detection seen: z stays 1, base.py:116-118)
-        if (zdo && !not_surveyed) {
-            r0 = c.site_ptr[sidx];
-            nvis = c.site_ptr[sidx + 1] - r0;
-#pragma unroll
-            for (int k = 0; k < ZPRE; ++k) {
-                const int r = r0 + ((k < nvis) ? k : 0);
-#pragma unroll
-                for (int aa = 0; aa < MAXC; ++aa)
-                    if (aa < Q) wa[k] = fma(c.Wt[(size_t)aa * c.R + r], -alpha[aa], wa[k]);
-            }
-        }
-    }
-    // ---- beta
-    double beta[MAXC];
-    if (scalar_wave) {  // (every workgroup's: uniform inputs, the same draw everywhere)
-        bool ok = true;
-        OCC_SWITCH_DIM(P, ok = iter_tail_beta<D>(ia, c, sc, chain, it, lane, beta));
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int aa = 0; aa < MAXC; ++aa) s_beta[aa] = beta[aa];
-        }
-        if (writer) {
-            if (!ok) sc.err = -4;  // OCC_E_CHOLESKY
-            for (int aa = 0; aa < P; ++aa) sc.beta[aa] = beta[aa];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int aa = 0; aa < MAXC; ++aa) beta[aa] = s_beta[aa];
-    // x_i'beta: the fma chain of omega_b_xb / z_update_site, in their order
-    double xb = 0.0;
-    if (!scalar_wave && act) xb = xdot(ia.Xt, n, i, beta, P);
-    // ---- omega_b of the NEXT iteration and this slice's part of eta'Q eta (omega_b_body at 64 sites per wave)
-    if (!scalar_wave) {
-        double quad = 0.0;
-        if (act && !(dbg & 4)) {
-            const_cast<double *>(a.omega_b[(it + 1u) & 1u])[(size_t)chain * n + i] = pg1_draw(sc.key, (uint32_t)i, it + 1u, STREAM_OMEGA_B, xb + eta);
-            quad = quad_site<true>(c, ia.eta + (size_t)chain * n, i, eta);
-        }
-        const double t = wave_sum(quad);
-        if (lane == 0 && slice_act) ia.part_quad[(size_t)chain * nb + slice] = t;
-    }
-    if (writer) {  // the record (record_draws)
-        const uint32_t rel = it - sc.it_base;
-        if (c.rec != nullptr && rel >= sc.burnin && rel - sc.burnin < sc.keep) {
-            double *row = c.rec + ((size_t)chain * sc.keep + (rel - sc.burnin)) * (size_t)(Q + P + 1);
-            for (int aa = 0; aa < Q; ++aa) row[aa] = alpha[aa];
-            for (int aa = 0; aa < P; ++aa) row[Q + aa] = beta[aa];
-            row[Q + P] = tau;
-        }
-    }
-    // ---- the z update's arithmetic (z_update_site's, on the inputs fetched above)
-    if (zdo) {
-        const double num1 = expit(xb + eta);
-        double pr = num1;
-        if (!not_surveyed) {
-            double prod = 1.0;
-#pragma unroll
-            for (int k = 0; k < ZPRE; ++k) {
-                if (k < nvis) {
-                    const double ex = expit(wa[k]);
-                    prod = (k == 0) ? ex : prod * ex;
-                }
-            }
-            for (int k = ZPRE; k < nvis; ++k) {  // (more visits than were fetched ahead)
-                double w = 0.0;
-#pragma unroll
-                for (int aa = 0; aa < MAXC; ++aa)
-                    if (aa < Q) w = fma(c.Wt[(size_t)aa * c.R + r0 + k], -alpha[aa], w);
-                prod = prod * expit(w);
-            }
-            const double num = num1 * prod;
-            pr = num / ((1.0 - num1) + num);
-        }
-        const double u = block_uniform(sc.key, (uint32_t)i, 0, it, STREAM_Z);
-        c.z[(size_t)chain * n + i] = (u < pr) ? 1 : 0;
-    }
-}
-
 // NW = width of the register-resident neighbour window: 8 (<= 256 VGPRs, two workgroups per CU) or 16 (one per CU);
 // XL = 1: one XCD per chain (see the head of this file)
 //
@@ -513,18 +355,9 @@ __device__ __forceinline__ void iter_tail(const IterArgs &ia, ChainScalars &sc, 
 // does nothing but one barrier among the workgroups of every chain, with a short time limit -- the same kernel, grid,
 // registers and LDS as the real launch, so it passes exactly when all workgroups of a chain are resident together
 // (and, XL, sit on one XCD: the flags carry their writers' XCC_ID).  The host runs it at creation (create_impl).
-//
-// TAIL = 1 (with the scalar-wave form, hand-overs by device counters or everything on one stream): the rest of the iteration --
-// k_z_ob's work -- as the last phase of the launch, so that an iteration is ONE kernel on the main stream: a chain barrier
-// behind phase C (eta and the partial sums of beta's system are then in the XCD's L2), beta drawn by the scalar wave of every
-// workgroup (reduce_partials' order, precision_mvnorm_reg: k_z_ob's bits), omega_b of the NEXT iteration and the partial sums of
-// eta'Q eta by the site waves, the z update behind the side stream's alpha, the record and the control words by the chain's
-// writer.  Round 1 and round 3 measured such a tail at +2 and +1 us: then a Polya-Gamma draw cost 3 000 instructions; with
-// round 4's sampler (1 000) the tail is shorter than k_z_ob plus the launch boundary in front of it.
-template <int NW, int XL, int W512, int TAIL = 0>
+template <int NW, int XL, int W512>
 __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512) ? 2 : 1) k_iter(const IterArgs ia, int e, int flags)
 {
-    static_assert(!TAIL || (XL == 1 && W512 == 1 && NW == 8), "the tail exists for the scalar-wave form");
     const bool probe = (flags & 2) != 0;
     const int sync_on = probe ? 0 : (flags & 1);
     const unsigned spin_limit = probe ? ITER_PROBE_SPIN_LIMIT : ITER_SPIN_LIMIT;
@@ -569,9 +402,7 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     size_t chain64 = (size_t)chain;
     asm volatile("" : "+s"(chain64));
     if (XL) {
-        // (the counter of this sequence's PARITY: a launch with the tail resets the other one -- its own cannot be reset while
-        // workgroups of its grid may still arrive -- and k_z_ob, where it still runs, resets both)
-        if (threadIdx.x == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + chain64 * 16 + (e & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) ticket = (int)__hip_atomic_fetch_add(ia.claim + chain64 * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_setprio(3);  // critical path: issue ahead of any co-resident Polya-Gamma waves
     // what needs neither the slot nor the noise is on its way while the claim's atomic returns: the chain's control words,
@@ -611,12 +442,8 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
     // 57 us.  (Later -- after the first barrier among the chain's workgroups -- changes nothing.)
     if (synced && writer && chain == 0) sync_set(ia.sync + SYNC_MAIN, ia.sync[SYNC_MAIN_SEQ + e]);
     // (a chain whose error word is set idles like a finished one: see chain_fail)
-    if (TAIL && !probe && writer && chain == ia.chain_base) iter_tail_fold_clock(ia.clock, e);
     if (!probe && (ctl.koff || ctl.it >= it_stop || err0 != 0)) {  // uniform over the chain's workgroups
-        if (writer) {
-            sc.mid[e] = ctl;
-            if (TAIL) iter_tail_handover(ia, sc, chain, ctl, e, false, synced);
-        }
+        if (writer) sc.mid[e] = ctl;
         return;
     }
     const unsigned long long clk0 = writer ? (unsigned long long)wall_clock64() : 0ull;
@@ -870,7 +697,6 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
                 sc.solves += 1ull;
                 if (s.istop == 6 && !failed) sc.err = -3;  // OCC_E_MINRES (logit.py:91-92)
             }
-            if (TAIL && threadIdx.x == 0) s_noise_ok = (s.istop == 6) ? 0 : 1;  // (the word is free after phase A: 0 = the iteration ends here)
         } else {
             KryStep st = {};
             // One step.  The histories are passed in the roles they play in THIS step -- (h1, h2) = p_{k-2}, p_{k-3} at the
@@ -1128,30 +954,13 @@ __global__ void __launch_bounds__(W512 ? ITER_WG_XL : ITER_WG, (NW == 8 && !W512
         ia.eta[co + i] = eta;
     }
     OCC_SWITCH_DIM(ia.p, beta_partials_slice<D>(ia, chain, i, act, slice, slice_act, om, eta, zval));
-    if constexpr (TAIL) {
-        // ---- the tail: the rest of the iteration (see the head of the kernel).  Behind one more barrier among the chain's
-        // workgroups: eta and the partial sums of beta's system are then in the XCD's L2 for everybody.
-        bool go = !failed;
-        if (go) {
-            // (alpha of this iteration, the side stream's: normally there since long; the verdict travels with the barrier)
-            if (synced && threadIdx.x == 0) s_claim = sync_wait(ia.sync, SYNC_ALPHA, (ia.sync[SYNC_MAIN_SEQ + e] + 1u) * (unsigned)ia.C) ? 1 : 0;
-            ++nbar;
-            OCC_CHAIN_BARRIER(s_flag);  // (its workgroup barriers also publish s_noise_ok, the solve's verdict)
-            go = s_flag == 0;
-            if (!go && writer) chain_fail(sc);
-        }
-        go = go && __builtin_amdgcn_readfirstlane(s_noise_ok) != 0;
-        if (go) iter_tail(ia, sc, chain, it, e, i, act, slice, slice_act, lane, eta, tau, synced, writer, scalar_wave, s_bcast, &s_claim, flags);
-        if (writer) iter_tail_handover(ia, sc, chain, ctl, e, go && chain_err(sc) == 0, synced);
-    }
     if (writer) {
         Ctl m = ctl;
         m.koff = 0u;
         sc.mid[e] = m;
         sc.bar_base = bar_base + nbar * (XL ? 1u : (unsigned)ia.nbg);
-        unsigned long long *clk = ia.clock + ((TAIL && (e & 1)) ? 4 : 0);
-        atomicMin(clk, clk0);
-        atomicMax(clk + 1, (unsigned long long)wall_clock64());
+        atomicMin(ia.clock, clk0);
+        atomicMax(ia.clock + 1, (unsigned long long)wall_clock64());
     }
     PHASE_STAMP(STAMP_STEPS - 1, 2)
 }

@@ -443,37 +443,6 @@ __device__ __forceinline__ void reduce_partials(const double *part, int nb, doub
     }
 }
 
-// The same reduction by ONE wave with the loads supplied by the caller (k_iter's tail reads the partial sums other
-// workgroups of the running launch stored: L1-bypassing loads) -- the order of reduce_partials, the same bits.
-template <int NQ, class F>
-__device__ __forceinline__ void reduce_partials_wave(int nb, int lane, double (&out)[NQ], F load)
-{
-    double acc[NQ];
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) acc[qi] = 0.0;
-    constexpr int R = NQ <= 8 ? 4 : (NQ <= 20 ? 2 : 1);
-    for (int b0 = lane; b0 < nb; b0 += 64 * R) {
-        double v[R][NQ];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int b = b0 + 64 * r;
-            const int bc = min(b, nb - 1);
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) {
-                const double t = load(qi * nb + bc);
-                v[r][qi] = (b < nb) ? t : 0.0;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) acc[qi] += v[r][qi];
-        }
-    }
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) out[qi] = wave_sum(acc[qi]);
-}
-
 // Runtime quantity count (the p x p / q x q systems): waves share the quantities, results go to LDS.
 __device__ __forceinline__ void reduce_partials_lds(const double *part, int nq, int nw, double *lds_out)
 {
@@ -777,7 +746,7 @@ __global__ void __launch_bounds__(256) k_snapshot(const double *__restrict__ eta
                                                   unsigned long long *__restrict__ clock,  // k_iter's clock words of the call that follows (or null)
                                                   ChainScalars *__restrict__ scs, int n_chains, int parity, uint32_t n_iter, uint32_t burnin, uint32_t keep)
 {
-    if (clock != nullptr && blockIdx.x == 0 && threadIdx.x < 8) clock[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 4) ? ~0ull : 0ull;  // (words 4, 5: k_iter's tail)
+    if (clock != nullptr && blockIdx.x == 0 && threadIdx.x < 4) clock[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;
     // ... and opens the call's window of iterations in the chains' scalars (what set_window would upload: occ_gibbs.hip)
     if (scs != nullptr && blockIdx.x == 0) {
         for (int ch = (int)threadIdx.x; ch < n_chains; ch += (int)blockDim.x) {
@@ -814,30 +783,14 @@ __global__ void __launch_bounds__(64) k_gate(const Ctx *__restrict__ cp, ChainSc
 #define OCC_KARGS const Ctx *__restrict__ cp, ChainScalars *__restrict__ scs, Slot *__restrict__ slots, int chain_base, int e
 
 // eta_i (Q eta)_i: site i's term of eta'Q eta (logit.py:208)
-// (AGENT: eta at the neighbours was stored by other workgroups of the RUNNING launch -- k_iter's tail: L1-bypassing loads)
-template <bool AGENT = false>
 __device__ __forceinline__ double quad_site(const Ctx &c, const double *eta, int i, double eta_i)
 {
     const int lane = i & 63;
     int base, width;
     slice_of(c, i, base, width);
     double qe = c.qdiag[i] * eta_i;
-    for (int k = 0; k < width; ++k) {
-        const double *pe = eta + c.sell_col[base + k * 64 + lane];
-        qe = fma(c.sell_val[base + k * 64 + lane], AGENT ? load_agent(pe) : *pe, qe);
-    }
+    for (int k = 0; k < width; ++k) qe = fma(c.sell_val[base + k * 64 + lane], eta[c.sell_col[base + k * 64 + lane]], qe);
     return eta_i * qe;
-}
-
-// x_i'beta of omega_b's argument (logit.py:197): shared by k_z_ob / k_omega_b and by k_iter's tail (occ_iter.hpp), the
-// contraction explicit so that both evaluate the same operations
-template <int P>
-__device__ __forceinline__ double omega_b_xb(const double *Xt, int n, int i, const double (&beta)[P])
-{
-    double xb = 0.0;
-#pragma unroll
-    for (int a = 0; a < P; ++a) xb = fma(Xt[(size_t)a * n + i], beta[a], xb);
-    return xb;
 }
 
 // omega_b ~ PG(1, x_i'beta + eta_i) of iteration `it` into omega_b[it & 1], and the partials of eta'Q eta
@@ -851,7 +804,9 @@ __device__ __forceinline__ void omega_b_body(const Ctx &c, const ChainScalars &s
     if (i < n) {
         const size_t ci = (size_t)chain * n + i;
         const double *eta = c.eta + (size_t)chain * n;
-        const double xb = omega_b_xb<P>(c.Xt, n, i, beta);
+        double xb = 0.0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) xb += c.Xt[(size_t)a * n + i] * beta[a];
         const double eta_i = eta[i];
         c.omega_b[it & 1][ci] = pg1_draw(sc.key, (uint32_t)i, it, STREAM_OMEGA_B, xb + eta_i);
         quad[0] = quad_site(c, eta, i, eta_i);
