@@ -147,7 +147,7 @@ typedef struct occ_stats {
     double iter_kernel_mean_us;       /* ... and their mean duration, first workgroup in to last chain out, by the
                                          device's constant-rate wall clock read inside the kernel */
     /* ABI 5: streams are pooled per (process, device, CU partition) -- a CU-masked stream holds one of the device's 24
-     * hardware queues for itself, and a process that oversubscribes them gets its queues time-sliced (DESIGN 6.4) */
+     * hardware queues for itself, and a process that oversubscribes them gets its queues time-sliced (DESIGN 7) */
     int32_t repromotions;         /* returns to the fused kernel / device-side hand-overs after a run-time fallback */
     int32_t stream_probes;        /* "do my two streams run beside each other?" asked so far (creation + whenever the
                                      process's set of streams changed before a call) */

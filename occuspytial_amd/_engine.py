@@ -1,5 +1,7 @@
 """Thin object wrapper over the C ABI: one ``Engine`` = one device-resident batch of chains."""
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -60,6 +62,20 @@ class ProblemMeta:
         return {f: getattr(self, f) for f in self.FIELDS}
 
 
+_LIVE = weakref.WeakSet()   # engines not yet closed: closed at interpreter exit, before the library's own exit hook runs
+
+
+@atexit.register
+def _close_live_engines():
+    """An engine some object still holds when the interpreter exits (an uncollected sampler, an exception path) would keep its
+    CU-masked streams alive into the HIP runtime's -- and a profiler's -- finalisers (a rocprofv3 crash seen in round 3)."""
+    for eng in list(_LIVE):
+        try:
+            eng.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """Device-resident sampler state for ``n_chains`` chains of one :class:`FlatProblem`.
 
@@ -84,6 +100,7 @@ class Engine:
         self.n_chains = len(keys)
         self.device = int(device)
         self.keys = [int(v) & (2 ** 64 - 1) for v in keys]
+        _LIVE.add(self)
         return self
 
     @classmethod
@@ -134,6 +151,7 @@ class Engine:
         if getattr(self, '_h', None):
             self._lib.occ_destroy(self._h)
             self._h = None
+            _LIVE.discard(self)
 
     def __del__(self):
         try:

@@ -238,7 +238,7 @@ constexpr int GRAPH_SEQ = 2;  // (16 per graph measured the same: the boundary b
 // ---- host waits have a deadline and name themselves ------------------------------------------------------------------
 // Every device-side wait of the engine is bounded (SYNC_SPIN_LIMIT, ITER_SPIN_LIMIT), so a host wait on one of its streams
 // that outlasts seconds is not the kernels' doing (round 3 recorded two such stops, one inside occ_create and one inside
-// occ_run, with nothing but Python frames to go by: DESIGN 6.4).  The engine therefore never blocks inside
+// occ_run, with nothing but Python frames to go by: DESIGN 7).  The engine therefore never blocks inside
 // hipStreamSynchronize / hipDeviceSynchronize: it polls hipStreamQuery against a deadline (OCC_HOST_WAIT_S, default 20 s)
 // and a wait that runs into it returns OCC_E_HIP naming the call site and the engine's host-side state; the engine is then
 // `wedged` -- its streams hold work that never completed, so nothing of it is freed, destroyed or handed to another engine.
@@ -1064,7 +1064,7 @@ void release_pair(StreamPair *p)
     // The last engine that held the pair is gone: the streams stay, idle, for the next engine that wants this partition (a
     // process that creates and closes engines one after the other -- a test-suite, a parameter sweep -- then keeps ONE set of
     // hardware queues instead of creating and destroying CU-masked streams by the dozen; the stops inside occ_create seen
-    // in round 3, DESIGN 6.1, came from runs that did exactly that).  acquire_pair destroys idle pairs when it needs their
+    // in round 3, HISTORY.md, came from runs that did exactly that).  acquire_pair destroys idle pairs when it needs their
     // place under the cap; the rest go with the process.
     (void)slot;  // (drop_pair has drained both streams)
 }
@@ -2587,7 +2587,7 @@ static int run_impl(occ_sampler *s, int64_t n_iter, int64_t burnin, double *out_
         }
         // A batch that leaves an unfinished chain exactly where it was -- same iteration, same carried launches, no error
         // word -- cannot happen while the chain's window is open on the device: the call ends with what it saw instead of
-        // enqueuing idle sequences for ever (round 3 recorded a call that never returned, DESIGN 6.4; the text below is what
+        // enqueuing idle sequences for ever (round 3 recorded a call that never returned, DESIGN 7; the text below is what
         // a recurrence reports).
         for (int ch = 0; ch < C; ++ch) {
             const Ctl &ctl = h[ch].ctl[s->parity];

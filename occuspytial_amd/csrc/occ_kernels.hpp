@@ -2218,6 +2218,8 @@ __global__ void __launch_bounds__(256) k_beta_draw(OCC_KARGS)
     }
 }
 
+// (three workgroups per CU: at two -- no spilled registers -- k_z_ob takes 19 us instead of 14 at the headline and 76 instead of 61
+// at 500x500, measured in round 4 with the new sampler as in round 2 with the old one)
 template <int P>
 __global__ void __launch_bounds__(256, 3) k_z_ob(OCC_KARGS, int flags)  // bit 0: stream hand-overs on, bit 1: per_wave, bit 2: beta ready
 {

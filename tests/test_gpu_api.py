@@ -124,7 +124,7 @@ def test_posterior_agrees_with_reference_chains(case):
     same sizes.  For every recorded coordinate that mixes (all of them, tau included, where the tau prior is
     informative): split R-hat over {4 reference, 4 device} chains < 1.05, means within 3 standard errors, standard
     deviations within 4.  The one test that sees an error shared by the oracle and the device in the edge-form prior
-    term (DESIGN 2.2, replaces logit.py:66-67,77) or in the Polya-Gamma sampler (replaces logit.py:191-193,202-204)."""
+    term (DESIGN 2, item 2: replaces logit.py:66-67,77) or in the Polya-Gamma sampler (replaces logit.py:191-193,202-204)."""
     from occuspytial_amd import LogitICARGibbs
     from .test_reference_chains import compare_with_reference, problem_of
     Q, W, X, y, hp, ch = problem_of(case)

@@ -542,7 +542,7 @@ def test_headline_config_100x100_four_chains_lockstep(oracle):
     keys = [int(g.bit_generator.random_raw()) for g in gens]
     worst, stats = _lockstep_chains(oracle, prob, starts, keys, 3)
     assert stats['persistent_solve'] == 2 and stats['n_chains'] == 4 and stats['fused_fallbacks'] == 0
-    # the scalar recurrence divides once and multiplies (DESIGN 2.6): measured worst case 1.4e-8 on xz
+    # the scalar recurrence divides once and multiplies (DESIGN 2, item 5): measured worst case 1.4e-8 on xz
     assert worst['xz'] < 3e-8 and worst['eta'] < 6e-8, worst
     print('100x100 x 4 chains lock step, worst relative deviations:', {k: float('%.2e' % v) for k, v in worst.items()})
 

@@ -1,4 +1,4 @@
-"""Streams are a process-wide resource (DESIGN 6.4, round 3): the condition behind round 2's hand-over stall, reproduced
+"""Streams are a process-wide resource (DESIGN 7): the condition behind round 2's hand-over stall, reproduced
 deterministically, and the device's error exits.
 
 An MI355X has 24 hardware queue slots per device (KFD topology ``num_cp_queues``); every CU-masked stream holds one for
@@ -213,7 +213,7 @@ def test_minres_iteration_limit_on_the_device_raises_the_references_error(monkey
     eng.close()
 
 
-# ---- a call that cannot advance ends, and says what it saw (round 4: DESIGN 6.4) ------------------------------------------
+# ---- a call that cannot advance ends, and says what it saw (round 4: DESIGN 7) ------------------------------------------
 @pytest.mark.parametrize('path', ['fused', 'launch_per_step'])
 def test_a_closed_window_ends_the_call_with_the_state_it_saw(monkeypatch, path):
     """occ_run's host loop enqueues sequences until every chain has done its iterations; a chain whose window of iterations

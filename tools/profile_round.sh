@@ -47,7 +47,7 @@ OCC_NO_TILES=1 python3 bench.py $C4 2> $out/c4_lps.err | tail -n 1 > profiles/${
 fi
 if has valu; then
 # 3b. the Polya-Gamma kernels, SQ counters, BEFORE (round 3's build, tools/libocc_gibbs_r3.so: built by hand from commit c4e04c1,
-#     see DESIGN 6.2) and AFTER, config 4 and the headline, eager launches
+#     see DESIGN 4) and AFTER, config 4 and the headline, eager launches
 SQC="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 echo "OCC_EAGER_ONLY=1 [OCC_LIB=tools/libocc_gibbs_r3.so]" >> $out/commands.log
 if [ -f tools/libocc_gibbs_r3.so ]; then

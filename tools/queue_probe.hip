@@ -1,4 +1,4 @@
-// Developer probe (round 3): when do two streams of one process stop running BESIDE each other?
+// Developer probe (round 3; DESIGN 7, HISTORY.md): when do two streams of one process stop running BESIDE each other?
 // A kernel on stream B waits (bounded) for a word that a kernel launched AFTER it on stream A sets.  Streams that
 // are served one after the other (one hardware queue, or queues the scheduler time-slices) never see the word.
 //   part 1: K live pairs of CU-masked streams (the engine's kind), K = 1 .. kmax: probe the newest and the oldest pair
