@@ -290,3 +290,34 @@ def test_a_fifth_cu_partition_evicts_an_idle_pair_and_nothing_changes(monkeypatc
     assert alt[2]['stream_pairs_evicted'] >= base + 2, (base, alt[2], seen_idle)   # six distinct partitions + the default's: five more partitions + the default's again under a cap of four: at least two evictions
     assert alt[2]['fused_fallbacks'] == 0 and alt[2]['handover_mode'] == 2
     _same(ref, alt)
+
+
+def test_a_host_wait_that_runs_out_names_its_call_site(monkeypatch):
+    """No call of the library blocks without a limit on its own streams: every host wait polls the stream against a
+    deadline (``OCC_HOST_WAIT_S``).  With the deadline at a millisecond a call of two thousand iterations runs into it: the
+    call returns OCC_E_HIP with the waiting function, its source line and the engine's host-side state in the text; the engine
+    is then closed without waiting for, freeing or handing on anything its streams may still hold; and the next engine -- on
+    a fresh pair of streams -- returns the bits of a clean process state."""
+    import time
+
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._lib import EngineUnavailable
+    prob = _small_problem(seed=3, rows=40, cols=45)
+    ref = _icar_run(prob)
+    eng = Engine(prob, [KEY, KEY + 7])
+    for c in range(2):
+        eng.set_start(c, **_random_start(prob, 40 + c))
+    eng.run(4, 0)                                     # (graphs captured, everything warm)
+    monkeypatch.setenv('OCC_HOST_WAIT_S', '0.001')
+    t0 = time.perf_counter()
+    with pytest.raises(EngineUnavailable) as ei:
+        eng.run(4000, 3999)
+    text = str(ei.value)
+    assert 'host wait `' in text and 'occ_gibbs.hip:' in text and 'did not drain within' in text and 'parity' in text, text
+    eng.close()                                       # returns at once: nothing is waited for or freed
+    assert time.perf_counter() - t0 < 5.0
+    monkeypatch.delenv('OCC_HOST_WAIT_S')
+    time.sleep(1.0)                                   # (the abandoned batch drains on its own: 4 000 iterations of 40 us)
+    alt = _icar_run(prob)
+    assert alt[2]['fused_fallbacks'] == 0 and alt[2]['handover_mode'] == 2
+    _same(ref, alt)
