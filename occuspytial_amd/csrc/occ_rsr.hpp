@@ -747,16 +747,20 @@ __global__ void __launch_bounds__(256) k_rsrb_assemble(const RsrArgs a, int e)
 // (u[r] = entry (r, c)).  Row i: the pivot comes by v_readlane from lane i, the row is divided by its root, and every later
 // row r takes its update with U_ir read from lane r -- no LDS, no barrier (round 2: the block in LDS, three workgroup
 // barriers per row, every workgroup of the launch for itself: 30 of the panel kernel's 38 us).  The operations are those of
-// the row-by-row loop it replaces (sqrt, division, fma in the same order): the same bits.  Returns false on a pivot <= 0.
+// the row-by-row loop it replaces.  Round 4: the pivot's RECIPROCAL root (v_rsq_f64 + two Newton steps, as in the small path)
+// instead of a square root and a division per row -- a dependent chain of ~6 instead of ~25 instructions on the one wave
+// every workgroup of the launch waits for, 32 times per panel -- and the diagonal of the stored factor holds 1 / U_ii: nothing
+// downstream needs U_ii itself, everything divides by it.  Returns false on a pivot <= 0.
 __device__ __forceinline__ bool rsrb_diag_factor(double (&u)[RSR_PANEL], int kb, int lane)
 {
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < RSR_PANEL; ++i) {
         const double piv = readlane_f64(u[i], i);
-        if (i < kb && !(piv > 0.0)) ok = false;
-        const double d = sqrt(piv);
-        u[i] = (lane == i) ? d : ((lane > i) ? u[i] / d : u[i]);
+        const bool good = piv > 0.0;
+        if (i < kb && !good) ok = false;
+        const double rinv = rsqrt_pivot(good ? piv : 1.0);
+        u[i] = (lane == i) ? rinv : ((lane > i) ? u[i] * rinv : u[i]);
 #pragma unroll
         for (int r = i + 1; r < RSR_PANEL; ++r) {
             const double uir = readlane_f64(u[i], r);  // U_ir (lane r's entry of row i)
@@ -825,7 +829,7 @@ __global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int 
 #pragma unroll
                 for (int q = 0; q < RSR_PANEL; ++q)
                     if (q < t) v = fma(-D[q][t], x[q], v);
-                x[t] = v / D[t][t];
+                x[t] = v * D[t][t];  // (the diagonal holds 1 / U_tt)
             }
         }
 #pragma unroll
@@ -909,20 +913,52 @@ __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
         if (tid < 64) {
             double v = (tid < kb) ? y[k0 + tid] : 0.0;
             const double *Fk = F + (size_t)(k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
-            const double dg = (tid < kb) ? Fk[tid * RSR_PANEL + tid] : 1.0;
-            for (int s2 = kb - 1; s2 >= 0; --s2) {
-                const double ts = readlane_f64(v, s2) / readlane_f64(dg, s2);
-                const double us = (tid < s2) ? Fk[tid * RSR_PANEL + s2] : 0.0;  // column s2 of the block
-                if (tid == s2) v = ts;
-                else if (tid < s2) v = fma(-us, ts, v);
+            // (round 4: this lane's row of the block loaded whole, ahead of the 32 dependent steps -- one load per step sat on
+            // the chain before)
+            double fr[RSR_PANEL];
+#pragma unroll
+            for (int s2 = 0; s2 < RSR_PANEL; ++s2) fr[s2] = (tid < kb && s2 < kb && tid <= s2) ? Fk[tid * RSR_PANEL + s2] : 0.0;
+            double dg = 1.0;
+#pragma unroll
+            for (int s2 = 0; s2 < RSR_PANEL; ++s2) dg = (tid == s2) ? fr[s2] : dg;
+#pragma unroll
+            for (int s2 = RSR_PANEL - 1; s2 >= 0; --s2) {
+                if (s2 < kb) {
+                    const double ts = readlane_f64(v, s2) * readlane_f64(dg, s2);  // (the stored diagonal is 1 / U_ss)
+                    if (tid == s2) v = ts;
+                    else if (tid < s2) v = fma(-fr[s2], ts, v);  // column s2 of the block
+                }
             }
             if (tid < kb) y[k0 + tid] = v;
         }
         __syncthreads();
-        for (int i = tid; i < k0; i += 1024) {
-            double v = y[i];
-            for (int s2 = 0; s2 < kb; ++s2) v = fma(-U[(size_t)i * m + k0 + s2], y[k0 + s2], v);
-            y[i] = v;
+        // rows above the panel: y_i -= sum_s U_i,k0+s y_k0+s.  A wave takes two rows per load -- lanes 0-31 the 32 entries of
+        // one row (256 contiguous bytes), lanes 32-63 those of the next -- and adds the products up over the 32 lanes.  (Until
+        // round 4 a thread walked along its own row: every load instruction of a wave touched 64 different cache lines, and
+        // the kernel, 15 us per panel, was bound by exactly that.)
+        {
+            const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, c = lane & 31;
+            const double yc = (c < kb) ? y[k0 + c] : 0.0;
+            constexpr int UB = 8;  // row pairs in flight per wave (the loads of a batch go out together)
+            for (int i0 = 2 * wave; i0 < k0; i0 += 32 * UB) {
+                double t[UB];
+#pragma unroll
+                for (int b = 0; b < UB; ++b) {
+                    const int i = i0 + 32 * b + half;
+                    t[b] = (i < k0 && c < kb) ? U[(size_t)i * m + k0 + c] : 0.0;
+                }
+#pragma unroll
+                for (int b = 0; b < UB; ++b) {
+                    const int i = i0 + 32 * b + half;
+                    double v = t[b] * yc;
+                    v += dpp_shifted<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+                    v += dpp_shifted<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+                    v += dpp_shifted<0x141, 0xf>(v);  // row_half_mirror
+                    v += dpp_shifted<0x140, 0xf>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
+                    v += __shfl_xor(v, 16);           // the two rows of 16 of this half
+                    if (c == 0 && i < k0) y[i] -= v;
+                }
+            }
         }
         __syncthreads();
     }
