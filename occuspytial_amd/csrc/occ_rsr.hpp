@@ -894,6 +894,171 @@ __global__ void __launch_bounds__(256) k_rsrb_update(const RsrArgs a, int e, int
     }
 }
 
+// ---- round 4: the trailing update of panel step k0 AND the panel work of step k0 + kb in ONE launch ---------------------
+// k_rsrb_panel + k_rsrb_update were 2 x 40 launches per iteration at m = 1 280 (23 + 12 us and two launch gaps per step:
+// 1.7 ms of a 3.5 ms iteration), although a step's panel work needs nothing but the previous step's update of ITS OWN block
+// row.  Here the workgroups of the first tile row pair (blockIdx.y == 0) -- whose tiles are the next panel's 32 rows -- go on
+// after their update: each forms the NEXT diagonal block's update and factor for itself (three more 16 x 16 tiles and one
+// wave's work: cheaper than a hand-over between workgroups, and nothing is assumed about the order workgroups are dispatched
+// in -- the panel kernel does the same), then solves U_kk' X = P for its own 32 columns from the tiles it holds; the
+// right-hand side's workgroup does the same for the panel's 32 entries.  The rest of the grid is k_rsrb_update unchanged.
+// The same operations on the same operands as the two kernels: the same bits.
+__device__ __forceinline__ v4d rsrb_tile_update(const double *P, int m, int k0, int kb, int i0, int j0, int lc, int lk)
+{
+    v4d acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = i0 + 4 * v + lk, c = j0 + lc;
+        acc[v] = (r < m && c < m) ? P[(size_t)r * m + c] : 0.0;
+    }
+    double av[RSR_PANEL / 4], bv[RSR_PANEL / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) {
+        const int t = 4 * s4 + lk;
+        const bool in = t < kb;
+        const double *row = P + (size_t)(k0 + (in ? t : 0)) * m;
+        const double ua = (in && i0 + lc < m) ? row[min(i0 + lc, m - 1)] : 0.0, ub = (in && j0 + lc < m) ? row[min(j0 + lc, m - 1)] : 0.0;
+        av[s4] = -ua;
+        bv[s4] = ub;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+    return acc;
+}
+// The next panel's diagonal block (rows / columns base .. base + kb2), updated by panel step k0 and factored, into D (upper
+// factor, 1 / U_tt on the diagonal); every thread of the workgroup calls it.  `mine`: this workgroup's own tiles ARE the
+// block (acc_own of waves 0, 1, 3); else waves 0, 1, 2 form tiles (0,0), (0,1), (1,1) from P.  Returns false on a pivot <= 0.
+__device__ __forceinline__ bool rsrb_next_diag(const double *P, int m, int k0, int kb, int base, int kb2, bool mine, v4d acc_own,
+                                               double (&Dblk)[RSR_PANEL][RSR_PANEL + 1], double (&D)[RSR_PANEL][RSR_PANEL + 1], int *s_bad)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 15, lk = lane >> 4;
+    int ti = -1, tj = -1;
+    if (mine) { if (wave != 2) { ti = wave >> 1; tj = wave & 1; } }  // waves 0, 1, 3 hold (0,0), (0,1), (1,1)
+    else if (wave < 3) { ti = wave == 2 ? 1 : 0; tj = wave == 0 ? 0 : 1; }
+    if (ti >= 0) {
+        const v4d acc = mine ? acc_own : rsrb_tile_update(P, m, k0, kb, base + 16 * ti, base + 16 * tj, lc, lk);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Dblk[16 * ti + 4 * v + lk][16 * tj + lc] = acc[v];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double u[RSR_PANEL];
+#pragma unroll
+        for (int r = 0; r < RSR_PANEL; ++r) {
+            const bool in = tid < kb2 && r < kb2 && tid >= r;
+            u[r] = in ? Dblk[r][tid & (RSR_PANEL - 1)] : ((r == tid) ? 1.0 : 0.0);
+        }
+        const bool ok = rsrb_diag_factor(u, kb2, tid);
+        if (tid == 0) *s_bad = ok ? 0 : 1;
+        if (tid < RSR_PANEL) {
+#pragma unroll
+            for (int r = 0; r < RSR_PANEL; ++r) D[r][tid] = (r <= tid && tid < kb2 && r < kb2) ? u[r] : 0.0;
+        }
+    }
+    __syncthreads();
+    return *s_bad == 0;
+}
+__global__ void __launch_bounds__(256) k_rsrb_step(const RsrArgs a, int e, int k0)
+{
+    __shared__ double Dblk[RSR_PANEL][RSR_PANEL + 1], D[RSR_PANEL][RSR_PANEL + 1];
+    __shared__ int s_bad;
+    const int chain = blockIdx.z, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 15, lk = lane >> 4;
+    ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
+    const int kb = min(RSR_PANEL, m - k0), base = k0 + kb, kb2 = min(RSR_PANEL, m - base);  // (launched only while base < m)
+    double *P = a.gram + (size_t)chain * m * m;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    if (blockIdx.y == gridDim.y - 1) {  // ---- the right-hand side: k_rsrb_update's row, then the next panel's entries
+        double *rhs = a.big_rhs + (size_t)chain * m;
+        const int j = base + (int)blockIdx.x * 256 + tid;
+        double v = 0.0;
+        if (j < m) {
+            v = rhs[j];
+            for (int t = 0; t < kb; ++t) v = fma(-P[(size_t)(k0 + t) * m + j], rhs[k0 + t], v);
+            if (blockIdx.x != 0 || tid >= kb2) rhs[j] = v;
+        }
+        if (blockIdx.x != 0) return;
+        const bool ok = rsrb_next_diag(P, m, k0, kb, base, kb2, false, zero4, Dblk, D, &s_bad);
+        if (!ok) return;  // (the tile row's first workgroup reports it)
+        if (tid < kb2) Dblk[0][tid] = v;  // (Dblk is free again: the panel's updated entries, one per thread)
+        __syncthreads();
+        if (tid == 0) {  // U_kk' y_k = rhs_k (k_rsrb_panel's last thread)
+            double x[RSR_PANEL];
+#pragma unroll
+            for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb2) ? Dblk[0][t] : 0.0;
+#pragma unroll
+            for (int t = 0; t < RSR_PANEL; ++t) {
+                if (t < kb2) {
+                    double w = x[t];
+#pragma unroll
+                    for (int q = 0; q < RSR_PANEL; ++q)
+                        if (q < t) w = fma(-D[q][t], x[q], w);
+                    x[t] = w * D[t][t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < RSR_PANEL; ++t)
+                if (t < kb2) rhs[base + t] = x[t];
+        }
+        return;
+    }
+    // ---- tiles of the trailing block (k_rsrb_update): workgroup (bx, by) holds tiles (2 by + wave / 2, 2 bx + wave % 2)
+    const int ti = 2 * (int)blockIdx.y + (wave >> 1), tj = 2 * (int)blockIdx.x + (wave & 1);
+    const int i0 = base + 16 * ti, j0 = base + 16 * tj;
+    const bool have = !(tj < ti || i0 >= m || j0 >= m);
+    v4d acc = zero4;
+    if (have) acc = rsrb_tile_update(P, m, k0, kb, i0, j0, lc, lk);
+    if (blockIdx.y != 0) {
+        if (have) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = i0 + 4 * v + lk, c = j0 + lc;
+                if (r < m && c < m && c >= r) P[(size_t)r * m + c] = acc[v];
+            }
+        }
+        return;
+    }
+    // ---- the first tile row pair: the next panel (rows base .. base + kb2)
+    const bool first = blockIdx.x == 0;
+    const bool ok = rsrb_next_diag(P, m, k0, kb, base, kb2, first, acc, Dblk, D, &s_bad);
+    if (!ok) {
+        if (first && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
+        return;
+    }
+    if (first) {  // the factored diagonal block, for k_rsrb_solve (P's diagonal block is never read again)
+        double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + base / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
+        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) F[t] = D[t / RSR_PANEL][t % RSR_PANEL];
+        return;
+    }
+    // this workgroup's 32 columns of the block row: the updated tiles through LDS (Dblk is free), one column per thread
+    __syncthreads();
+    if (have) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Dblk[16 * (wave >> 1) + 4 * v + lk][16 * (wave & 1) + lc] = acc[v];
+    }
+    __syncthreads();
+    const int j = base + 32 * (int)blockIdx.x + tid;
+    if (tid < RSR_PANEL && j < m) {
+        double x[RSR_PANEL];
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb2) ? Dblk[t][tid] : 0.0;
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) {
+            if (t < kb2) {
+                double w = x[t];
+#pragma unroll
+                for (int q = 0; q < RSR_PANEL; ++q)
+                    if (q < t) w = fma(-D[q][t], x[q], w);
+                x[t] = w * D[t][t];  // (the diagonal holds 1 / U_tt)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t)
+            if (t < kb2) P[(size_t)(base + t) * m + j] = x[t];
+    }
+}
+
 // U theta = y (backward), blocked by panels, one workgroup per chain; y = the right-hand side as the panel steps left it
 // (the forward substitution travels with the factorisation).
 __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
