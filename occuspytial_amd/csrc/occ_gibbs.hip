@@ -287,7 +287,10 @@ static int wait_on(occ_sampler *s, hipStream_t st, const char *func, int line)
     if (e == hipSuccess) return OCC_OK;
     if (late) {
         s->wedged = true;
-        if (s->pair) s->pair->dead = true;
+        if (s->pair) {
+            std::lock_guard<std::mutex> g(g_pool_mu);  // (the pool reads the mark under its lock)
+            s->pair->dead = true;
+        }
         char lim[64];
         std::snprintf(lim, sizeof(lim), "%.0f s", host_wait_limit_s());
         s->err = std::string("host wait `") + what + "`: the " + (st == s->side ? "side" : "main") + " stream did not drain within " + lim +
@@ -312,7 +315,10 @@ static hipError_t drain_for_copy(occ_sampler *s)
     const hipError_t e = poll_stream(s->stream, &late);
     if (late) {  // (HIP_TRY reports the expression; the state goes to stderr once, here)
         s->wedged = true;
-        if (s->pair) s->pair->dead = true;
+        if (s->pair) {
+            std::lock_guard<std::mutex> g(g_pool_mu);
+            s->pair->dead = true;
+        }
         std::fprintf(stderr, "[occ] a copy or fill on the main stream did not complete within %.0f s: %s\n", host_wait_limit_s(), host_state(s).c_str());
     }
     return e;
