@@ -497,24 +497,12 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
                 const int m = s->rsr.m;
                 hipLaunchKernelGGL(k_rsrb_tau, dim3((unsigned)((m + RSRB_QROWS - 1) / RSRB_QROWS), (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
                 hipLaunchKernelGGL(k_rsrb_assemble, dim3((unsigned)m, (unsigned)c.C), dim3(256), 0, st, s->rsr, e);
-                if (std::getenv("OCC_RSRB_TWO_KERNELS")) {  // diagnostic: a panel and an update launch per step, as until round 4
-                    for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
-                        const int kb = std::min(RSR_PANEL, m - k0), cols = m - k0 - kb;
-                        hipLaunchKernelGGL(k_rsrb_panel, dim3((unsigned)std::max(1, (cols + 255) / 256) + 1u, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
-                        if (cols > 0) {  // 2 x 2 tiles of 16 x 16 per workgroup; one more workgroup row for the right-hand side
-                            const unsigned tt = (unsigned)((cols + 31) / 32);
-                            hipLaunchKernelGGL(k_rsrb_update, dim3(tt, tt + 1, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
-                        }
-                    }
-                } else {
-                    // the first panel, then per step ONE launch: the step's trailing update and the next step's panel work (k_rsrb_step)
-                    hipLaunchKernelGGL(k_rsrb_panel, dim3((unsigned)std::max(1, (m - std::min(RSR_PANEL, m) + 255) / 256) + 1u, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, 0);
-                    for (int k0 = 0; k0 < m; k0 += RSR_PANEL) {
-                        const int kb = std::min(RSR_PANEL, m - k0), cols = m - k0 - kb;
-                        if (cols <= 0) break;
-                        const unsigned tt = (unsigned)((cols + 31) / 32);
-                        hipLaunchKernelGGL(k_rsrb_step, dim3(tt, tt + 1, (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0);
-                    }
+                // the head (the first panel's factor and block row), then per panel step one launch: the step's trailing update
+                // and the next step's panel work
+                hipLaunchKernelGGL(k_rsrb_step, dim3((unsigned)((m + 31) / 32), 2u * (unsigned)c.C), dim3(256), 0, st, s->rsr, e, -1, c.C);
+                for (int k0 = 0; k0 + RSR_PANEL < m; k0 += RSR_PANEL) {
+                    const unsigned tt = (unsigned)((m - k0 - RSR_PANEL + 31) / 32);
+                    hipLaunchKernelGGL(k_rsrb_step, dim3(tt, (tt + 1) * (unsigned)c.C), dim3(256), 0, st, s->rsr, e, k0, c.C);
                 }
                 hipLaunchKernelGGL(k_rsrb_solve, dim3(1, (unsigned)c.C), dim3(1024), 0, st, s->rsr, e);
             }

@@ -46,7 +46,7 @@ struct RsrArgs {
     double *big_scal;   // [C][2] (unused since round 3)
     double *big_quad;   // [C][ceil(m / 64)] theta' Qr theta by slices of 64 rows (k_rsrb_tau -> k_rsrb_assemble)
     double *big_rhs;    // [C][m]
-    double *big_dfac;   // [C][ceil(m / RSR_PANEL)][RSR_PANEL][RSR_PANEL] the factored diagonal blocks (k_rsrb_panel -> k_rsrb_solve)
+    double *big_dfac;   // [C][ceil(m / RSR_PANEL)][RSR_PANEL][RSR_PANEL] the factored diagonal blocks (k_rsrb_step -> k_rsrb_solve)
     double tau_rate, tau_shape;
     ChainScalars *scs;
     unsigned *sync;     // hand-over counters of the two streams (Ctx::sync), or null
@@ -674,9 +674,7 @@ __global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS
 // lattice at the default r = 0.5 -- 1 280 columns at 100x100); the LDS-resident solve above stops at 128.  Here:
 //   k_rsrb_tau       eps2, theta' Qr theta, tau                                       one workgroup per chain
 //   k_rsrb_assemble  prec = G + tau Qr (upper triangle, in place in `gram`), rhs = K'u + sqrt(tau) E eps2   one per row
-//   k_rsrb_panel     panel by panel (RSR_PANEL rows): the diagonal block's upper Cholesky factor in LDS (every workgroup
-//                    for itself), then U_kk' X = P_k,rest for the block row right of it, one column per thread
-//   k_rsrb_update    P_ij -= sum_t U_ti U_tj over the panel's rows t, 16 x 16 tiles of the trailing upper triangle
+//   k_rsrb_step      the blocked upper Cholesky factorisation, panels of RSR_PANEL rows, one launch per panel (see there)
 //   k_rsrb_solve     U'y = rhs, U theta = y, blocked by panels                          one workgroup per chain
 // k_rsr_gram and k_rsr_eta_beta are the general kernels above.  Every sum has a fixed order (no atomics); the order
 // is not the small path's (the two agree to rounding, like the oracle).  Plain kernels: at m = 1 280 the conditional is
@@ -744,172 +742,150 @@ __global__ void __launch_bounds__(256) k_rsrb_assemble(const RsrArgs a, int e)
 }
 
 // Upper Cholesky factor of one RSR_PANEL x RSR_PANEL block by ONE WAVE, the block in registers: lane c < kb owns column c
-// (u[r] = entry (r, c)).  Row i: the pivot comes by v_readlane from lane i, the row is divided by its root, and every later
-// row r takes its update with U_ir read from lane r -- no LDS, no barrier (round 2: the block in LDS, three workgroup
-// barriers per row, every workgroup of the launch for itself: 30 of the panel kernel's 38 us).  The operations are those of
-// the row-by-row loop it replaces.  Round 4: the pivot's RECIPROCAL root (v_rsq_f64 + two Newton steps, as in the small path)
-// instead of a square root and a division per row -- a dependent chain of ~6 instead of ~25 instructions on the one wave
-// every workgroup of the launch waits for, 32 times per panel -- and the diagonal of the stored factor holds 1 / U_ii: nothing
-// downstream needs U_ii itself, everything divides by it.  Returns false on a pivot <= 0.
-__device__ __forceinline__ bool rsrb_diag_factor(double (&u)[RSR_PANEL], int kb, int lane)
+// (u[r] = entry (r, c)).  Row i: the pivot comes by v_readlane from lane i, the row is multiplied by its reciprocal root
+// (v_rsq_f64 + two Newton steps, as in the small path; the stored diagonal holds 1 / U_ii -- nothing downstream needs U_ii
+// itself), and a later row r takes its update with U_ir read from lane r -- no barrier.  (Round 2: the block in LDS, three
+// workgroup barriers per row: 30 of the panel kernel's 38 us.)
+// Round 4, second pass (tools/rsrb_stamps.py: 7.7 us of a 19 us step for the 496 row pairs, five instructions each): the
+// block as 2 x 2 blocks of 16.  Rows 0-15 update only rows up to 15 (120 pairs; lanes 16-31 ride along, which IS
+// U11' U12 = A12); then A22 -= U12' U12 on the matrix cores -- four v_mfma_f64_16x16x4_f64, operands and tile passed through
+// `scr` (512 doubles of LDS; the wave's own, no barrier) -- and rows 16-31 among themselves (120 pairs).  The update is no
+// longer masked to lanes >= r: entries below the diagonal take finite garbage that nothing reads (a pair is two v_readlane
+// and one FMA).  Row i + 1 is updated first and its pivot's chain (readlane, v_rsq_f64, Newton: ~130 cycles) started before
+// the other rows' updates, which hide it.  Returns false on a pivot <= 0.
+#ifdef OCC_SOLVE_STAMPS
+#define RSRB_SUB(pt) if (stamp) g_solve_stamps[64 + 24 + (pt)] = wall_clock64();
+#else
+#define RSRB_SUB(pt)
+#endif
+template <int I0>
+__device__ __forceinline__ bool rsrb_factor16(double (&u)[RSR_PANEL], int kb, int lane)
 {
     bool ok = true;
+    double piv = readlane_f64(u[I0], I0);
+    bool good = piv > 0.0;
+    double rinv = rsqrt_pivot(good ? piv : 1.0);
 #pragma unroll
-    for (int i = 0; i < RSR_PANEL; ++i) {
-        const double piv = readlane_f64(u[i], i);
-        const bool good = piv > 0.0;
+    for (int i = I0; i < I0 + 16; ++i) {
         if (i < kb && !good) ok = false;
-        const double rinv = rsqrt_pivot(good ? piv : 1.0);
-        u[i] = (lane == i) ? rinv : ((lane > i) ? u[i] * rinv : u[i]);
-#pragma unroll
-        for (int r = i + 1; r < RSR_PANEL; ++r) {
-            const double uir = readlane_f64(u[i], r);  // U_ir (lane r's entry of row i)
-            if (lane >= r) u[r] = fma(-uir, u[i], u[r]);
+        u[i] = (lane == i) ? rinv : u[i] * rinv;  // (lanes < i: below the diagonal, never read)
+        if (i + 1 < I0 + 16) {
+            u[i + 1] = fma(-readlane_f64(u[i], i + 1), u[i], u[i + 1]);
+            piv = readlane_f64(u[i + 1], i + 1);
+            good = piv > 0.0;
+            rinv = rsqrt_pivot(good ? piv : 1.0);
+            asm volatile("" : "+v"(rinv));  // (keeps the chain's start here, ahead of the updates below)
         }
+#pragma unroll
+        for (int r = i + 2; r < I0 + 16; ++r) u[r] = fma(-readlane_f64(u[i], r), u[i], u[r]);  // U_ir from lane r
     }
     return ok;
 }
-
-// Panel step k0: the diagonal block's factor (wave 0 of every workgroup, for itself: 5 us, cheaper than a launch of its
-// own), then U_kk' X = P_k,rest for this workgroup's 256 columns of the block row, one column per thread.  The last
-// workgroup of the grid takes the right-hand side along -- U_kk' y_k = rhs_k: the forward substitution is finished with
-// the factor, as in the small path; workgroup 0 stores the factored block (big_dfac: see below).
-__global__ void __launch_bounds__(256) k_rsrb_panel(const RsrArgs a, int e, int k0)
+__device__ __forceinline__ bool rsrb_diag_factor(double (&u)[RSR_PANEL], int kb, int lane, double *scr, bool stamp = false)
 {
-    __shared__ double D[RSR_PANEL][RSR_PANEL + 1];
-    __shared__ int s_bad;
-    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x;
-    ChainScalars &sc = a.scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    const int kb = min(RSR_PANEL, m - k0);
-    double *P = a.gram + (size_t)chain * m * m;
-    if (tid < 64) {
-        double u[RSR_PANEL];
+    RSRB_SUB(0)
+    static_assert(RSR_PANEL == 32, "two blocks of 16");
+    const bool ok0 = rsrb_factor16<0>(u, kb, lane);
+    RSRB_SUB(1)
+    double *T = scr, *S = scr + 256;  // T[k][j] = U12 (row k < 16, column 16 + j), S[r][j] = A22
+    const int j = lane & 15, lk = lane >> 4;
+    if (lk == 1) {
 #pragma unroll
-        for (int r = 0; r < RSR_PANEL; ++r) {
-            const bool in = tid < kb && r < kb && tid >= r;
-            const double v = P[(size_t)(k0 + (in ? r : 0)) * m + k0 + (in ? tid : 0)];
-            u[r] = in ? v : ((r == tid) ? 1.0 : 0.0);  // (identity outside the block: nothing divides by zero)
-        }
-        const bool ok = rsrb_diag_factor(u, kb, tid);
-        if (tid == 0) s_bad = ok ? 0 : 1;
-        if (tid < RSR_PANEL) {
-#pragma unroll
-            for (int r = 0; r < RSR_PANEL; ++r) D[r][tid] = (r <= tid && tid < kb && r < kb) ? u[r] : 0.0;
+        for (int k = 0; k < 16; ++k) {
+            T[16 * k + j] = u[k];
+            S[16 * k + j] = u[16 + k];
         }
     }
-    __syncthreads();
-    if (s_bad) {
-        if (blockIdx.x == 0 && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
-        return;
-    }
-    // The factored diagonal block goes to a buffer of its own, NOT back into P: every workgroup of this launch loads the
-    // unfactored block from P above, and nothing orders those loads before a write-back by workgroup 0.  P's
-    // diagonal block is never read again; k_rsrb_solve takes the factor from big_dfac.
-    if (blockIdx.x == 0) {
-        double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
-        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) F[t] = D[t / RSR_PANEL][t % RSR_PANEL];
-    }
-    // the block row right of the diagonal block: U_kk' x = p, one column per thread; the last thread of workgroup 0: the
-    // right-hand side's entries of this panel
-    // (the LAST workgroup of the grid is the right-hand side's: its thread 0)
-    const bool rhs_wg = blockIdx.x == gridDim.x - 1;
-    const int j = rhs_wg ? m : k0 + kb + (int)blockIdx.x * 256 + tid;
-    const bool is_rhs = rhs_wg && tid == 0;
-    double *rhs = a.big_rhs + (size_t)chain * m;
-    if (j < m || is_rhs) {
-        double x[RSR_PANEL];
-#pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb) ? (is_rhs ? rhs[k0 + t] : P[(size_t)(k0 + t) * m + j]) : 0.0;
-#pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t) {
-            if (t < kb) {
-                double v = x[t];
-#pragma unroll
-                for (int q = 0; q < RSR_PANEL; ++q)
-                    if (q < t) v = fma(-D[q][t], x[q], v);
-                x[t] = v * D[t][t];  // (the diagonal holds 1 / U_tt)
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t)
-            if (t < kb) {
-                if (is_rhs) rhs[k0 + t] = x[t];
-                else P[(size_t)(k0 + t) * m + j] = x[t];
-            }
-    }
-}
-
-// Trailing update of panel step k0 on the matrix cores: P_ij -= sum_t U_ti U_tj over the panel's rows t, one WAVE per
-// 16 x 16 tile of the trailing upper triangle (four tiles per workgroup): v_mfma_f64_16x16x4_f64 with A = -U[:, i-block]'
-// and B = U[:, j-block], four panel rows per instruction, the tile as the accumulator (lane l: rows 4 v + l / 16, column
-// l % 16; operands: 4 x 128-byte row segments per load).  (Round 2: one thread per entry, 64 scalar loads and 32 FMAs:
-// 10-134 us per launch, 2.1 ms per iteration at m = 1 280.)  The last workgroup row of the grid updates the right-hand
-// side: rhs_j -= sum_t U_tj y_t.
-__global__ void __launch_bounds__(256) k_rsrb_update(const RsrArgs a, int e, int k0)
-{
-    const int chain = blockIdx.z, m = a.m, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
-    const ChainScalars &sc = a.scs[chain];
-    const Ctl ctl = sc.ctl[e];
-    if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    const int kb = min(RSR_PANEL, m - k0), base = k0 + kb;
-    double *P = a.gram + (size_t)chain * m * m;
-    if (blockIdx.y == gridDim.y - 1) {  // the right-hand side: one thread per trailing entry
-        double *rhs = a.big_rhs + (size_t)chain * m;
-        const int j = base + (int)blockIdx.x * 256 + (int)threadIdx.x;
-        if (j < m) {
-            double v = rhs[j];
-            for (int t = 0; t < kb; ++t) v = fma(-P[(size_t)(k0 + t) * m + j], rhs[k0 + t], v);
-            rhs[j] = v;
-        }
-        return;
-    }
-    // tile (ti, tj) of the trailing block, ti <= tj: workgroup (bx, by) holds tiles (2 by + wave / 2, 2 bx + wave % 2)
-    const int ti = 2 * (int)blockIdx.y + (wave >> 1), tj = 2 * (int)blockIdx.x + (wave & 1);
-    const int i0 = base + 16 * ti, j0 = base + 16 * tj;
-    if (tj < ti || i0 >= m || j0 >= m) return;
     v4d acc;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int r = i0 + 4 * v + lk, c = j0 + lc;
-        acc[v] = (r < m && c < m) ? P[(size_t)r * m + c] : 0.0;
-    }
-    double av[RSR_PANEL / 4], bv[RSR_PANEL / 4];
+    for (int v = 0; v < 4; ++v) acc[v] = S[16 * (4 * v + lk) + j];
 #pragma unroll
-    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) {
-        const int t = 4 * s4 + lk;
-        const bool in = t < kb;
-        const double *row = P + (size_t)(k0 + (in ? t : 0)) * m;
-        const double ua = (in && i0 + lc < m) ? row[min(i0 + lc, m - 1)] : 0.0, ub = (in && j0 + lc < m) ? row[min(j0 + lc, m - 1)] : 0.0;
-        av[s4] = -ua;
-        bv[s4] = ub;
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const double b = T[16 * (4 * s4 + lk) + j];  // A = -U12' and B = U12 take the same entry in this lane
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-b, b, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+    for (int v = 0; v < 4; ++v) S[16 * (4 * v + lk) + j] = acc[v];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int r = i0 + 4 * v + lk, c = j0 + lc;
-        if (r < m && c < m && c >= r) P[(size_t)r * m + c] = acc[v];
+    for (int r = 0; r < 16; ++r) {
+        const double sv = S[16 * r + j];
+        u[16 + r] = (lk == 1) ? sv : u[16 + r];
+    }
+    RSRB_SUB(2)
+    const bool ok1 = rsrb_factor16<16>(u, kb, lane);
+    RSRB_SUB(3)
+    return ok0 && ok1;
+}
+// The inverses of the factor's two diagonal blocks of 16 come with it: lanes 32 + c start as the unit vector e_c in rows
+// 0-15 and lanes 48 + c as e_c in rows 16-31, and the row operations of the factorisation -- which every lane takes --
+// turn a column b into U^-T b (the forward substitution that also carries the right-hand side): afterwards lane 32 + c
+// holds row c of V11 = U11^-1 in u[0..15] and lane 48 + c row c of V22 = U22^-1 in u[16..31].  With them the panel's
+// triangular solves are products on the matrix cores (rsrb_apply) instead of 496 dependent FMAs per column (5 us of a step,
+// tools/rsrb_stamps.py), and U12 is still where rsrb_diag_factor staged it (scr[16 k + j] = U_k,16+j).
+constexpr int RSRB_VS = 17;  // row stride of V11 / V22 in LDS (the writing lanes own rows)
+__device__ __forceinline__ void rsrb_store_inverses(const double (&u)[RSR_PANEL], double *Vs, int lane)
+{
+    if (lane >= 32) {
+        const int c = lane & 15;
+        if (lane < 48) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Vs[RSRB_VS * c + r] = u[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Vs[16 * RSRB_VS + RSRB_VS * c + r] = u[16 + r];
+        }
     }
 }
+// X = U^-T P for 16 columns (block cb) of a 32-row panel on the matrix cores, one wave: X1 = V11' P1, then
+// P2 - U12' X1, then X2 = V22' (...).  An MFMA's result tile (lane (lk, lc): rows 4 v + lk, column lc) IS the next
+// product's B operand, slice by slice -- nothing moves between the three.  Pb: the panel's entries in LDS.
+__device__ __forceinline__ void rsrb_apply(const double *U12, const double *Vs, const double (&Pb)[RSR_PANEL][RSR_PANEL + 1], int cb, int lc, int lk,
+                                           v4d &x1, v4d &x2)
+{
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    v4d p1, p2;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        p1[v] = Pb[4 * v + lk][16 * cb + lc];
+        p2[v] = Pb[16 + 4 * v + lk][16 * cb + lc];
+    }
+    x1 = zero4;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[RSRB_VS * (4 * s4 + lk) + lc], p1[s4], x1, 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U12[16 * (4 * s4 + lk) + lc], x1[s4], p2, 0, 0, 0);
+    x2 = zero4;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[16 * RSRB_VS + RSRB_VS * (4 * s4 + lk) + lc], p2[s4], x2, 0, 0, 0);
+}
 
-// ---- round 4: the trailing update of panel step k0 AND the panel work of step k0 + kb in ONE launch ---------------------
-// k_rsrb_panel + k_rsrb_update were 2 x 40 launches per iteration at m = 1 280 (23 + 12 us and two launch gaps per step:
-// 1.7 ms of a 3.5 ms iteration), although a step's panel work needs nothing but the previous step's update of ITS OWN block
-// row.  Here the workgroups of the first tile row pair (blockIdx.y == 0) -- whose tiles are the next panel's 32 rows -- go on
-// after their update: each forms the NEXT diagonal block's update and factor for itself (three more 16 x 16 tiles and one
-// wave's work: cheaper than a hand-over between workgroups, and nothing is assumed about the order workgroups are dispatched
-// in -- the panel kernel does the same), then solves U_kk' X = P for its own 32 columns from the tiles it holds; the
-// right-hand side's workgroup does the same for the panel's 32 entries.  The rest of the grid is k_rsrb_update unchanged.
-// The same operations on the same operands as the two kernels: the same bits.
+// ---- the blocked factorisation: ONE kernel per panel step ------------------------------------------------------------
+// Launch `k0` does the trailing update of panel step k0 (P_ij -= sum_t U_ti U_tj over the panel's 32 rows t, one WAVE per
+// 16 x 16 tile of the trailing upper triangle: v_mfma_f64_16x16x4_f64 with A = -U[:, i-block]' and B = U[:, j-block], the
+// tile as the accumulator; the right-hand side's row: rhs_j -= sum_t U_tj y_t) AND the panel work of step k0 + 32: the
+// workgroups of the first tile row pair -- whose tiles are the next panel's 32 rows -- go on after their update.  Each forms
+// the NEXT diagonal block's update and factor for itself (three 16 x 16 tiles and one wave's work: cheaper than a hand-over
+// between workgroups, and nothing is assumed about the order workgroups are dispatched in), then X = U_kk^-T P for its own 32
+// columns from the tiles it holds (rsrb_apply); the right-hand side's workgroup does the same for the panel's 32 entries (the
+// forward substitution travels with the factorisation, as in the small path).  The launch with k0 < 0 is the head: no
+// update, the first panel's work.  (Until round 4: a panel and an update kernel per step, 2 x 40 launches per iteration at
+// m = 1 280, 23 + 12 us and two launch gaps per step: 1.7 ms of a 3.5 ms iteration; the triangular solves one column per
+// thread.)
+// Order inside a workgroup of the first tile row (tools/rsrb_stamps.py): waves 0-2 form the diagonal block's three tiles
+// FIRST (wave 3 its own tile meanwhile); wave 3 factors and inverts while waves 0-2 form their own tiles -- the factor, the
+// one serial piece, waits for nothing but the three tiles it needs.  Grid: x = tile column pair, y = (row, chain) with row 0
+// the right-hand side's and row 1 the first tile row pair, so the workgroups with the serial work are dispatched first, for
+// every chain.
 __device__ __forceinline__ v4d rsrb_tile_update(const double *P, int m, int k0, int kb, int i0, int j0, int lc, int lk)
 {
+    // (every load at a clamped, valid address and the value selected afterwards: a conditional load is a branch each)
     v4d acc;
+    const int cj = min(j0 + lc, m - 1), ci = min(i0 + lc, m - 1);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int r = i0 + 4 * v + lk, c = j0 + lc;
-        acc[v] = (r < m && c < m) ? P[(size_t)r * m + c] : 0.0;
+        const int r = i0 + 4 * v + lk;
+        const double p = P[(size_t)min(r, m - 1) * m + cj];
+        acc[v] = (r < m && j0 + lc < m) ? p : 0.0;
     }
     double av[RSR_PANEL / 4], bv[RSR_PANEL / 4];
 #pragma unroll
@@ -917,100 +893,40 @@ __device__ __forceinline__ v4d rsrb_tile_update(const double *P, int m, int k0, 
         const int t = 4 * s4 + lk;
         const bool in = t < kb;
         const double *row = P + (size_t)(k0 + (in ? t : 0)) * m;
-        const double ua = (in && i0 + lc < m) ? row[min(i0 + lc, m - 1)] : 0.0, ub = (in && j0 + lc < m) ? row[min(j0 + lc, m - 1)] : 0.0;
-        av[s4] = -ua;
-        bv[s4] = ub;
+        const double ua = row[ci], ub = row[cj];
+        av[s4] = (in && i0 + lc < m) ? -ua : 0.0;
+        bv[s4] = (in && j0 + lc < m) ? ub : 0.0;
     }
 #pragma unroll
     for (int s4 = 0; s4 < RSR_PANEL / 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
     return acc;
 }
-// The next panel's diagonal block (rows / columns base .. base + kb2), updated by panel step k0 and factored, into D (upper
-// factor, 1 / U_tt on the diagonal); every thread of the workgroup calls it.  `mine`: this workgroup's own tiles ARE the
-// block (acc_own of waves 0, 1, 3); else waves 0, 1, 2 form tiles (0,0), (0,1), (1,1) from P.  Returns false on a pivot <= 0.
-__device__ __forceinline__ bool rsrb_next_diag(const double *P, int m, int k0, int kb, int base, int kb2, bool mine, v4d acc_own,
-                                               double (&Dblk)[RSR_PANEL][RSR_PANEL + 1], double (&D)[RSR_PANEL][RSR_PANEL + 1], int *s_bad)
+#ifdef OCC_SOLVE_STAMPS  // tools/rsrb_stamps.py: the second workgroup of the first tile row, chain 0, panel step 20
+#define RSRB_STAMP(pt) if (chain == 0 && row == 1 && blockIdx.x == 1 && (threadIdx.x & 63) == 0 && k0 == 20 * RSR_PANEL) g_solve_stamps[64 + 4 * (pt) + (threadIdx.x >> 6)] = wall_clock64();
+#else
+#define RSRB_STAMP(pt)
+#endif
+__global__ void __launch_bounds__(256) k_rsrb_step(const RsrArgs a, int e, int k0, int n_chains)
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 15, lk = lane >> 4;
-    int ti = -1, tj = -1;
-    if (mine) { if (wave != 2) { ti = wave >> 1; tj = wave & 1; } }  // waves 0, 1, 3 hold (0,0), (0,1), (1,1)
-    else if (wave < 3) { ti = wave == 2 ? 1 : 0; tj = wave == 0 ? 0 : 1; }
-    if (ti >= 0) {
-        const v4d acc = mine ? acc_own : rsrb_tile_update(P, m, k0, kb, base + 16 * ti, base + 16 * tj, lc, lk);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) Dblk[16 * ti + 4 * v + lk][16 * tj + lc] = acc[v];
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double u[RSR_PANEL];
-#pragma unroll
-        for (int r = 0; r < RSR_PANEL; ++r) {
-            const bool in = tid < kb2 && r < kb2 && tid >= r;
-            u[r] = in ? Dblk[r][tid & (RSR_PANEL - 1)] : ((r == tid) ? 1.0 : 0.0);
-        }
-        const bool ok = rsrb_diag_factor(u, kb2, tid);
-        if (tid == 0) *s_bad = ok ? 0 : 1;
-        if (tid < RSR_PANEL) {
-#pragma unroll
-            for (int r = 0; r < RSR_PANEL; ++r) D[r][tid] = (r <= tid && tid < kb2 && r < kb2) ? u[r] : 0.0;
-        }
-    }
-    __syncthreads();
-    return *s_bad == 0;
-}
-__global__ void __launch_bounds__(256) k_rsrb_step(const RsrArgs a, int e, int k0)
-{
-    __shared__ double Dblk[RSR_PANEL][RSR_PANEL + 1], D[RSR_PANEL][RSR_PANEL + 1];
+    __shared__ double Scr[512], Dblk[RSR_PANEL][RSR_PANEL + 1], Xblk[RSR_PANEL][RSR_PANEL + 1];  // Scr: rsrb_diag_factor's, then U12
     __shared__ int s_bad;
-    const int chain = blockIdx.z, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 15, lk = lane >> 4;
+    const int row = (int)blockIdx.y / n_chains, chain = (int)blockIdx.y % n_chains, m = a.m;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 15, lk = lane >> 4;
     ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
-    const int kb = min(RSR_PANEL, m - k0), base = k0 + kb, kb2 = min(RSR_PANEL, m - base);  // (launched only while base < m)
+    const bool head = k0 < 0;
+    const int kr = head ? 0 : k0, kb = head ? 0 : min(RSR_PANEL, m - k0), base = kr + kb, kb2 = min(RSR_PANEL, m - base);  // (base < m)
     double *P = a.gram + (size_t)chain * m * m;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-    if (blockIdx.y == gridDim.y - 1) {  // ---- the right-hand side: k_rsrb_update's row, then the next panel's entries
-        double *rhs = a.big_rhs + (size_t)chain * m;
-        const int j = base + (int)blockIdx.x * 256 + tid;
-        double v = 0.0;
-        if (j < m) {
-            v = rhs[j];
-            for (int t = 0; t < kb; ++t) v = fma(-P[(size_t)(k0 + t) * m + j], rhs[k0 + t], v);
-            if (blockIdx.x != 0 || tid >= kb2) rhs[j] = v;
-        }
-        if (blockIdx.x != 0) return;
-        const bool ok = rsrb_next_diag(P, m, k0, kb, base, kb2, false, zero4, Dblk, D, &s_bad);
-        if (!ok) return;  // (the tile row's first workgroup reports it)
-        if (tid < kb2) Dblk[0][tid] = v;  // (Dblk is free again: the panel's updated entries, one per thread)
-        __syncthreads();
-        if (tid == 0) {  // U_kk' y_k = rhs_k (k_rsrb_panel's last thread)
-            double x[RSR_PANEL];
-#pragma unroll
-            for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb2) ? Dblk[0][t] : 0.0;
-#pragma unroll
-            for (int t = 0; t < RSR_PANEL; ++t) {
-                if (t < kb2) {
-                    double w = x[t];
-#pragma unroll
-                    for (int q = 0; q < RSR_PANEL; ++q)
-                        if (q < t) w = fma(-D[q][t], x[q], w);
-                    x[t] = w * D[t][t];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < RSR_PANEL; ++t)
-                if (t < kb2) rhs[base + t] = x[t];
-        }
-        return;
-    }
-    // ---- tiles of the trailing block (k_rsrb_update): workgroup (bx, by) holds tiles (2 by + wave / 2, 2 bx + wave % 2)
-    const int ti = 2 * (int)blockIdx.y + (wave >> 1), tj = 2 * (int)blockIdx.x + (wave & 1);
+    const bool rhs_row = row == 0, first = blockIdx.x == 0;
+    // tile (ti, tj) of the trailing block, ti <= tj: workgroup (bx, row) holds tiles (2 (row - 1) + wave / 2, 2 bx + wave % 2)
+    const int ti = 2 * (row - 1) + (wave >> 1), tj = 2 * (int)blockIdx.x + (wave & 1);
     const int i0 = base + 16 * ti, j0 = base + 16 * tj;
-    const bool have = !(tj < ti || i0 >= m || j0 >= m);
-    v4d acc = zero4;
-    if (have) acc = rsrb_tile_update(P, m, k0, kb, i0, j0, lc, lk);
-    if (blockIdx.y != 0) {
+    const bool have = !rhs_row && !(tj < ti || i0 >= m || j0 >= m);
+    if (row > 1) {  // ---- the trailing update, nothing else
         if (have) {
+            const v4d acc = rsrb_tile_update(P, m, kr, kb, i0, j0, lc, lk);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = i0 + 4 * v + lk, c = j0 + lc;
@@ -1019,110 +935,210 @@ __global__ void __launch_bounds__(256) k_rsrb_step(const RsrArgs a, int e, int k
         }
         return;
     }
-    // ---- the first tile row pair: the next panel (rows base .. base + kb2)
-    const bool first = blockIdx.x == 0;
-    const bool ok = rsrb_next_diag(P, m, k0, kb, base, kb2, first, acc, Dblk, D, &s_bad);
-    if (!ok) {
-        if (first && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
+    double *rhs = a.big_rhs + (size_t)chain * m;
+    double rv = 0.0;
+    if (rhs_row) {  // ---- the right-hand side's update; workgroup 0 goes on to the next panel's entries
+        const int j = base + (int)blockIdx.x * 256 + tid;
+        if (j < m) {
+            rv = rhs[j];
+            for (int t = 0; t < kb; ++t) rv = fma(-P[(size_t)(kr + t) * m + j], rhs[kr + t], rv);
+            if (!first || tid >= kb2) rhs[j] = rv;
+        }
+        if (!first) return;
+    }
+    RSRB_STAMP(0)
+    // ---- the next panel (rows base .. base + kb2): its diagonal block, updated by step k0, into Dblk.  The first workgroup
+    // of the tile row holds the block's tiles (waves 0, 1, 3: (0,0), (0,1), (1,1)); elsewhere waves 0-2 form them.
+    v4d acc = zero4;
+    if (first && !rhs_row) {
+        if (have) acc = rsrb_tile_update(P, m, kr, kb, i0, j0, lc, lk);
+        if (wave != 2) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Dblk[16 * (wave >> 1) + 4 * v + lk][16 * (wave & 1) + lc] = acc[v];
+        }
+    } else if (wave < 3) {
+        const int di = wave == 2 ? 1 : 0, dj = wave == 0 ? 0 : 1;
+        const v4d d = rsrb_tile_update(P, m, kr, kb, base + 16 * di, base + 16 * dj, lc, lk);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Dblk[16 * di + 4 * v + lk][16 * dj + lc] = d[v];
+    } else if (have) {
+        acc = rsrb_tile_update(P, m, kr, kb, i0, j0, lc, lk);
+    }
+    __syncthreads();
+    RSRB_STAMP(1)
+    if (wave == 3) {  // the factor and its diagonal blocks' inverses, by one wave
+        double u[RSR_PANEL];
+#pragma unroll
+        for (int r = 0; r < RSR_PANEL; ++r) {
+            const double d = Dblk[r][lane & (RSR_PANEL - 1)];
+            const bool in = lane < kb2 && r < kb2 && lane >= r;
+            // outside a short block: the identity; lanes 32-63: the unit vectors that become V11 and V22
+            const int unit = lane < 32 ? lane : lane - 32;  // (lanes 48-63: rows 16-31)
+            u[r] = in ? d : ((r == unit && (lane < 32 || (r < 16) == (lane < 48))) ? 1.0 : 0.0);
+        }
+#ifdef OCC_SOLVE_STAMPS
+        const bool stamp = chain == 0 && row == 1 && blockIdx.x == 1 && lane == 0 && k0 == 20 * RSR_PANEL;
+        const bool ok = rsrb_diag_factor(u, kb2, lane, Scr, stamp);
+#else
+        const bool ok = rsrb_diag_factor(u, kb2, lane, Scr);
+#endif
+        if (lane == 0) s_bad = ok ? 0 : 1;
+        RSRB_SUB(4)
+        if (first && !rhs_row) {
+            // the factored diagonal block, for k_rsrb_solve (P's diagonal block is never read again): F[q][t] = U_qt,
+            // row-major, 1 / U_tt on the diagonal -- from the registers, a row of the block per store instruction
+            if (ok && lane < RSR_PANEL) {
+                double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + base / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
+#pragma unroll
+                for (int q = 0; q < RSR_PANEL; ++q) F[q * RSR_PANEL + lane] = (q <= lane) ? u[q] : 0.0;
+            }
+        } else {
+            rsrb_store_inverses(u, &Dblk[0][0], lane);  // (Dblk is this wave's alone since the barrier)
+        }
+    } else if (!first && have) {  // meanwhile: this workgroup's own tiles
+        acc = rsrb_tile_update(P, m, kr, kb, i0, j0, lc, lk);
+    }
+    RSRB_STAMP(2)
+    if (rhs_row) {
+        if (tid < RSR_PANEL) Xblk[tid][0] = (tid < kb2) ? rv : 0.0;  // the panel's updated entries: column 0 of a block like the others'
+    } else if (!first) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xblk[16 * (wave >> 1) + 4 * v + lk][16 * (wave & 1) + lc] = acc[v];  // (zero where there is no tile)
+    }
+    __syncthreads();
+    RSRB_STAMP(3)
+    if (s_bad) {
+        if (first && !rhs_row && tid == 0) sc.err = -4;  // OCC_E_CHOLESKY
         return;
     }
-    if (first) {  // the factored diagonal block, for k_rsrb_solve (P's diagonal block is never read again)
-        double *F = a.big_dfac + ((size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) + base / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
-        for (int t = tid; t < RSR_PANEL * RSR_PANEL; t += 256) F[t] = D[t / RSR_PANEL][t % RSR_PANEL];
-        return;
-    }
-    // this workgroup's 32 columns of the block row: the updated tiles through LDS (Dblk is free), one column per thread
-    __syncthreads();
-    if (have) {
+    if (first && !rhs_row) return;  // (wave 3 has stored the factored block)
+    // X = U_kk^-T P: this workgroup's 32 columns of the block row, 16 per wave (waves 0, 1); the right-hand side's
+    // workgroup: the panel's entries, column 0 of wave 0's block
+    if (wave < (rhs_row ? 1 : 2)) {
+        v4d x1, x2;
+        rsrb_apply(Scr, &Dblk[0][0], Xblk, wave, lc, lk, x1, x2);
+        RSRB_STAMP(4)
+        if (rhs_row) {
+            if (lc == 0) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Dblk[16 * (wave >> 1) + 4 * v + lk][16 * (wave & 1) + lc] = acc[v];
-    }
-    __syncthreads();
-    const int j = base + 32 * (int)blockIdx.x + tid;
-    if (tid < RSR_PANEL && j < m) {
-        double x[RSR_PANEL];
+                for (int v = 0; v < 4; ++v) {
+                    if (4 * v + lk < kb2) rhs[base + 4 * v + lk] = x1[v];
+                    if (16 + 4 * v + lk < kb2) rhs[base + 16 + 4 * v + lk] = x2[v];
+                }
+            }
+        } else {
+            const int j = base + 32 * (int)blockIdx.x + 16 * wave + lc;
+            if (j < m) {
 #pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t) x[t] = (t < kb2) ? Dblk[t][tid] : 0.0;
-#pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t) {
-            if (t < kb2) {
-                double w = x[t];
-#pragma unroll
-                for (int q = 0; q < RSR_PANEL; ++q)
-                    if (q < t) w = fma(-D[q][t], x[q], w);
-                x[t] = w * D[t][t];  // (the diagonal holds 1 / U_tt)
+                for (int v = 0; v < 4; ++v) {
+                    if (4 * v + lk < kb2) P[(size_t)(base + 4 * v + lk) * m + j] = x1[v];
+                    if (16 + 4 * v + lk < kb2) P[(size_t)(base + 16 + 4 * v + lk) * m + j] = x2[v];
+                }
             }
         }
-#pragma unroll
-        for (int t = 0; t < RSR_PANEL; ++t)
-            if (t < kb2) P[(size_t)(base + t) * m + j] = x[t];
     }
+    RSRB_STAMP(5)
 }
 
 // U theta = y (backward), blocked by panels, one workgroup per chain; y = the right-hand side as the panel steps left it
 // (the forward substitution travels with the factorisation).
+// Round 4: LEFT-looking -- y_k = U_kk^-1 (y_k - sum_{panels j > k} U_kj y_j) with the sums taken along U's ROWS, which is how
+// the factor lies in memory (a wave reads 512 contiguous bytes per load), and pipelined: while wave 0 solves panel k's
+// triangle (32 dependent steps, the block from LDS), waves 1-15 form panel k - 1's sums over every entry already solved
+// (`far`), fetch its diagonal block and its 32 x 32 coupling to panel k (`near`, finished right after panel k).  A panel
+// costs the longer of the two; until then every panel's solve was followed by an update of ALL rows above it through
+// 256-byte column slabs, one dependent pair per panel (9 us a panel, 0.36 ms at m = 1 280).  Every sum has a fixed order.
 __global__ void __launch_bounds__(1024) k_rsrb_solve(const RsrArgs a, int e)
 {
     __shared__ double y[RSR_BIG_MAX];
-    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x;
+    __shared__ double Fs[2][RSR_PANEL][RSR_PANEL + 1];  // the diagonal blocks' factors (F[q][t] = U_qt, 1 / U_tt on the diagonal)
+    __shared__ double s_far[2][RSR_PANEL], s_near[RSR_PANEL];
+    const int chain = blockIdx.y, m = a.m, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const ChainScalars &sc = a.scs[chain];
     const Ctl ctl = sc.ctl[e];
     if (ctl.koff || ctl.it >= sc.it_stop || sc.err != 0) return;
     const double *U = a.gram + (size_t)chain * m * m;
-    const double *F = a.big_dfac + (size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);  // the diagonal blocks' factors
+    const double *F = a.big_dfac + (size_t)chain * ((m + RSR_PANEL - 1) / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
+    const int npan = (m + RSR_PANEL - 1) / RSR_PANEL;
     for (int t = tid; t < m; t += 1024) y[t] = a.big_rhs[(size_t)chain * m + t];
+    {  // the last panel: nothing beyond it
+        const double *Fk = F + (size_t)(npan - 1) * (RSR_PANEL * RSR_PANEL);
+        Fs[(npan - 1) & 1][tid >> 5][tid & 31] = Fk[tid];
+        if (tid < RSR_PANEL) { s_far[(npan - 1) & 1][tid] = 0.0; s_near[tid] = 0.0; }
+    }
+    // `near`: wave w takes rows 2 w and 2 w + 1 of a panel, lanes 0-31 / 32-63 the 32 columns of the panel after it
+    const int nrow = 2 * wave + (lane >> 5), ncol = lane & 31;
+    double un = 0.0;  // U[row nrow of the panel about to be solved][column ncol of the panel solved before it]
     __syncthreads();
-    const int last = ((m - 1) / RSR_PANEL) * RSR_PANEL;
-    for (int k0 = last; k0 >= 0; k0 -= RSR_PANEL) {
-        const int kb = min(RSR_PANEL, m - k0);
-        if (tid < 64) {
-            double v = (tid < kb) ? y[k0 + tid] : 0.0;
-            const double *Fk = F + (size_t)(k0 / RSR_PANEL) * (RSR_PANEL * RSR_PANEL);
-            // (round 4: this lane's row of the block loaded whole, ahead of the 32 dependent steps -- one load per step sat on
-            // the chain before)
+    for (int k = npan - 1; k >= 0; --k) {
+        const int k0 = k * RSR_PANEL, kb = min(RSR_PANEL, m - k0);
+        if (k < npan - 1) {  // panel k + 1 has just been solved: its part of panel k's sums
+            const int c = k0 + RSR_PANEL + ncol;
+            double v = (c < m) ? un * y[c] : 0.0;
+            v += dpp_shifted<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+            v += dpp_shifted<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+            v += dpp_shifted<0x141, 0xf>(v);  // row_half_mirror
+            v += dpp_shifted<0x140, 0xf>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
+            v += __shfl_xor(v, 16);           // the two rows of 16 of this half
+            if (ncol == 0) s_near[nrow] = v;
+            __syncthreads();
+        }
+        // the coupling of panel k - 1 to panel k, fetched now, used after this panel's solve
+        if (k > 0) {
+            const int r = k0 - RSR_PANEL + nrow, c = k0 + ncol;
+            un = U[(size_t)r * m + min(c, m - 1)];
+        }
+        if (wave == 0) {  // ---- panel k's triangle: U_kk y_k = y_k - far - near, from the bottom
+            const int r = lane & (RSR_PANEL - 1);
+            double v = (lane < kb) ? (y[k0 + lane] - s_far[k & 1][r]) - s_near[r] : 0.0;
             double fr[RSR_PANEL];
 #pragma unroll
-            for (int s2 = 0; s2 < RSR_PANEL; ++s2) fr[s2] = (tid < kb && s2 < kb && tid <= s2) ? Fk[tid * RSR_PANEL + s2] : 0.0;
+            for (int s2 = 0; s2 < RSR_PANEL; ++s2) {
+                const double f = Fs[k & 1][r][s2];
+                fr[s2] = (lane < kb && s2 < kb && lane <= s2) ? f : 0.0;
+            }
             double dg = 1.0;
 #pragma unroll
-            for (int s2 = 0; s2 < RSR_PANEL; ++s2) dg = (tid == s2) ? fr[s2] : dg;
+            for (int s2 = 0; s2 < RSR_PANEL; ++s2) dg = (lane == s2) ? fr[s2] : dg;
 #pragma unroll
             for (int s2 = RSR_PANEL - 1; s2 >= 0; --s2) {
                 if (s2 < kb) {
                     const double ts = readlane_f64(v, s2) * readlane_f64(dg, s2);  // (the stored diagonal is 1 / U_ss)
-                    if (tid == s2) v = ts;
-                    else if (tid < s2) v = fma(-fr[s2], ts, v);  // column s2 of the block
+                    v = (lane == s2) ? ts : fma(-fr[s2], ts, v);  // column s2 of the block (fr is zero at and below the diagonal)
                 }
             }
-            if (tid < kb) y[k0 + tid] = v;
-        }
-        __syncthreads();
-        // rows above the panel: y_i -= sum_s U_i,k0+s y_k0+s.  A wave takes two rows per load -- lanes 0-31 the 32 entries of
-        // one row (256 contiguous bytes), lanes 32-63 those of the next -- and adds the products up over the 32 lanes.  (Until
-        // round 4 a thread walked along its own row: every load instruction of a wave touched 64 different cache lines, and
-        // the kernel, 15 us per panel, was bound by exactly that.)
-        {
-            const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, c = lane & 31;
-            const double yc = (c < kb) ? y[k0 + c] : 0.0;
-            constexpr int UB = 8;  // row pairs in flight per wave (the loads of a batch go out together)
-            for (int i0 = 2 * wave; i0 < k0; i0 += 32 * UB) {
-                double t[UB];
+            if (lane < kb) y[k0 + lane] = v;
+        } else if (k > 0) {  // ---- meanwhile, for panel k - 1: its diagonal block, and its sums over everything solved before panel k
+            const int t = tid - 64;  // 0 .. 959
+            const double *Fk = F + (size_t)(k - 1) * (RSR_PANEL * RSR_PANEL);
+            for (int q = t; q < RSR_PANEL * RSR_PANEL; q += 960) Fs[(k - 1) & 1][q >> 5][q & 31] = Fk[q];
+            // rows wave - 1, wave + 14, wave + 29 of panel k - 1, columns k0 + 32 .. m - 1 over the lanes
+            const int r0 = wave - 1, nr = (r0 + 30 < RSR_PANEL) ? 3 : 2, j0 = k0 + RSR_PANEL;
+            const double *row = U + (size_t)(k0 - RSR_PANEL + r0) * m;
+            double acc[3] = {0.0, 0.0, 0.0};
+            constexpr int FB = 8;  // column chunks (of 64) in flight per row
+            for (int jb = j0; jb < m; jb += 64 * FB) {
+                double t0[FB], t1[FB], t2[FB];
 #pragma unroll
-                for (int b = 0; b < UB; ++b) {
-                    const int i = i0 + 32 * b + half;
-                    t[b] = (i < k0 && c < kb) ? U[(size_t)i * m + k0 + c] : 0.0;
+                for (int b = 0; b < FB; ++b) {
+                    const int j = min(jb + 64 * b + lane, m - 1);
+                    t0[b] = row[j];
+                    t1[b] = row[(size_t)15 * m + j];
+                    t2[b] = (nr == 3) ? row[(size_t)30 * m + j] : 0.0;
                 }
 #pragma unroll
-                for (int b = 0; b < UB; ++b) {
-                    const int i = i0 + 32 * b + half;
-                    double v = t[b] * yc;
-                    v += dpp_shifted<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-                    v += dpp_shifted<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-                    v += dpp_shifted<0x141, 0xf>(v);  // row_half_mirror
-                    v += dpp_shifted<0x140, 0xf>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
-                    v += __shfl_xor(v, 16);           // the two rows of 16 of this half
-                    if (c == 0 && i < k0) y[i] -= v;
+                for (int b = 0; b < FB; ++b) {
+                    const int j = jb + 64 * b + lane;
+                    const double yj = (j < m) ? y[j] : 0.0;
+                    acc[0] = fma(t0[b], yj, acc[0]);
+                    acc[1] = fma(t1[b], yj, acc[1]);
+                    acc[2] = fma(t2[b], yj, acc[2]);
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double sm = wave_sum(acc[q]);
+                if (lane == 0 && q < nr) s_far[(k - 1) & 1][r0 + 15 * q] = sm;
             }
         }
         __syncthreads();
