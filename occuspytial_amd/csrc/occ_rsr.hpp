@@ -938,12 +938,16 @@ __global__ void __launch_bounds__(256) k_rsrb_step(const RsrArgs a, int e, int k
     double *rhs = a.big_rhs + (size_t)chain * m;
     double rv = 0.0;
     if (rhs_row) {  // ---- the right-hand side's update; workgroup 0 goes on to the next panel's entries
-        const int j = base + (int)blockIdx.x * 256 + tid;
-        if (j < m) {
-            rv = rhs[j];
-            for (int t = 0; t < kb; ++t) rv = fma(-P[(size_t)(kr + t) * m + j], rhs[kr + t], rv);
-            if (!first || tid >= kb2) rhs[j] = rv;
-        }
+        // (the panel's 32 entries of this column all loaded before the first is used: as a loop over a run-time kb the
+        // compiler took them one round trip at a time, and this workgroup is on every launch's critical path)
+        const int j = base + (int)blockIdx.x * 256 + tid, jc = min(j, m - 1);
+        double pv[RSR_PANEL];
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) pv[t] = P[(size_t)(kr + (t < kb ? t : 0)) * m + jc];
+        rv = rhs[jc];
+#pragma unroll
+        for (int t = 0; t < RSR_PANEL; ++t) rv = fma(-pv[t], (t < kb) ? rhs[kr + t] : 0.0, rv);
+        if (j < m && (!first || tid >= kb2)) rhs[j] = rv;
         if (!first) return;
     }
     RSRB_STAMP(0)
