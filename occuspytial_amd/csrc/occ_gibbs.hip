@@ -481,11 +481,13 @@ int launch_kind(occ_sampler *s, hipStream_t st, int kind, int e, int extra = 0)
         case K_GATE: hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s->ctx_dev, s->ctx.sc); break;
         case K_RSR_GRAM:
             if (s->rsr.m > RSR_MAX_DIM && !std::getenv("OCC_NO_GRAM32")) {  // large bases: 32 x 32 blocks of G, then the K'u workgroups alone
+                // (8 waves per workgroup whatever the chain count: a chain's bits do not depend on how many chains run beside it)
                 if (c.C > 1 && !std::getenv("OCC_GRAM32_ONE_CHAIN"))  // two chains per workgroup: K streamed once for both
-                    hipLaunchKernelGGL(k_rsr_gram32<2>, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)((c.C + 1) / 2)), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
+                    hipLaunchKernelGGL((k_rsr_gram32<2, GRAM32_WAVES>), dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)((c.C + 1) / 2)), dim3(64 * GRAM32_WAVES), rsr_gram32_lds(GRAM32_WAVES), st, s->rsr, e, s->launch_sync ? 1 : 0);
                 else
-                    hipLaunchKernelGGL(k_rsr_gram32<1>, dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), RSR_GRAM32_LDS, st, s->rsr, e, s->launch_sync ? 1 : 0);
-                hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)((s->rsr.m + 15) / 16), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, (s->launch_sync ? 1 : 0) | 2);
+                    hipLaunchKernelGGL((k_rsr_gram32<1, GRAM32_WAVES>), dim3((unsigned)rsr_gram32_blocks(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM32_WAVES), rsr_gram32_lds(GRAM32_WAVES), st, s->rsr, e, s->launch_sync ? 1 : 0);
+                hipLaunchKernelGGL(k_rsrb_u, dim3((unsigned)((s->rsr.n + 255) / 256), (unsigned)c.C), dim3(256), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
+                hipLaunchKernelGGL(k_rsrb_ktu, dim3((unsigned)s->rsr.m, (unsigned)((c.C + 3) / 4)), dim3(256), 0, st, s->rsr, e);
             } else {
                 hipLaunchKernelGGL(k_rsr_gram, dim3((unsigned)rsr_gram_tiles(s->rsr.m), (unsigned)c.C), dim3(64 * GRAM_WAVES), 0, st, s->rsr, e, s->launch_sync ? 1 : 0);
             }
@@ -1925,17 +1927,18 @@ static int create_impl(occ_sampler *s, const HostLayout &L, int32_t n_chains, co
         r.scs = c.sc;
         r.sync = c.sync;
         s->rsr_K_host = Kh;
-        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr; r.big_dfac = nullptr; r.big_quad = nullptr;
+        r.E = nullptr; r.big_eps = nullptr; r.big_scal = nullptr; r.big_rhs = nullptr; r.big_dfac = nullptr; r.big_quad = nullptr; r.big_u = nullptr;
         if (m <= RSR_MAX_DIM) {
             HIP_TRY(hipFuncSetAttribute((const void *)pick_rsr_solve(m), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(double) * rsr_solve_lds_doubles(m))));
         } else {  // the global-memory solve (k_rsrb_*)
-            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSR_GRAM32_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<1, GRAM32_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsr_gram32_lds(GRAM32_WAVES)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rsr_gram32<2, GRAM32_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsr_gram32_lds(GRAM32_WAVES)));
             if ((rc = upload(s, &r.E, Eh, "rsr_E"))) return rc;
             if ((rc = dev_alloc(s, &r.big_eps, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_scal, (size_t)C * 2))) return rc;
             if ((rc = dev_alloc(s, &r.big_quad, (size_t)C * ((m + RSRB_QROWS - 1) / RSRB_QROWS)))) return rc;
+            if ((rc = dev_alloc(s, &r.big_u, (size_t)C * n))) return rc;
             if ((rc = dev_alloc(s, &r.big_rhs, (size_t)C * m))) return rc;
             if ((rc = dev_alloc(s, &r.big_dfac, (size_t)C * ((m + RSR_PANEL - 1) / RSR_PANEL) * RSR_PANEL * RSR_PANEL))) return rc;
         }

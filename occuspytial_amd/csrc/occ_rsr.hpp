@@ -45,6 +45,7 @@ struct RsrArgs {
     double *big_eps;    // [C][m]
     double *big_scal;   // [C][2] (unused since round 3)
     double *big_quad;   // [C][ceil(m / 64)] theta' Qr theta by slices of 64 rows (k_rsrb_tau -> k_rsrb_assemble)
+    double *big_u;      // [C][n] u = z - 1/2 - omega X beta + sqrt(omega) eps (k_rsrb_u -> k_rsrb_ktu)
     double *big_rhs;    // [C][m]
     double *big_dfac;   // [C][ceil(m / RSR_PANEL)][RSR_PANEL][RSR_PANEL] the factored diagonal blocks (k_rsrb_step -> k_rsrb_solve)
     double tau_rate, tau_shape;
@@ -226,8 +227,8 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
 // omega where they are used -- the kernel streams 2 x 32 columns of K (5 MB at n = 10 000) per workgroup through the Infinity
 // Cache, 16.8 GB per iteration at m = 1 280 with four chains: bound by that stream (7.7 TB/s), not by the matrix cores.  The
 // products row[cc] * w are the ones the one-chain form takes, in the same order per output element: the same bits.
-template <int NC>
-__global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram32(const RsrArgs a, int e, int sync_on)
+template <int NC, int WV>
+__global__ void __launch_bounds__(64 * WV, 4) k_rsr_gram32(const RsrArgs a, int e, int sync_on)
 {
     extern __shared__ __attribute__((aligned(16))) double s_g32[];
     const int chain0 = (int)blockIdx.y * NC;
@@ -276,25 +277,75 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram32(const RsrArgs a,
             for (int c = 0; c < NC; ++c) ww[c][t] = vi ? om[c][ii] : 0.0;
         }
     };
-    // A wave's sites are the same in both forms -- 16 consecutive ones out of every 16 x GRAM_WAVES, in ascending order (which
+    // A wave's sites are the same in both forms -- 16 consecutive ones out of every 16 x WV, in ascending order (which
     // is what decides the bits of a partial tile) -- taken in batches of 4 NB: batch b starts at site_of(b).
     constexpr int SUBS = 4 / NB;
-    auto site_of = [&](int b) { return wave * 16 + (b / SUBS) * 16 * GRAM_WAVES + (b % SUBS) * 4 * NB; };
-    int b = 0;
-    if (site_of(0) < a.n) load(site_of(0), a0, a1, b0, b1, w);
-    for (; site_of(b) < a.n; ++b) {
-        if (site_of(b + 1) < a.n) load(site_of(b + 1), na0, na1, nb0, nb1, nw);
+    auto site_of = [&](int b) { return wave * 16 + (b / SUBS) * 16 * WV + (b % SUBS) * 4 * NB; };
+    auto mm = [&](const double (&x0)[NB], const double (&x1)[NB], const double (&y0)[NB], const double (&y1)[NB], const double (&ww)[NC][NB]) {
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const double y0 = b0[t] * w[c][t], y1 = b1[t] * w[c][t];
-                acc[c][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], y0, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], y1, acc[c][1], 0, 0, 0);
-                if (!diag) acc[c][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], y0, acc[c][2], 0, 0, 0);
-                acc[c][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], y1, acc[c][3], 0, 0, 0);
+                if (NC > 1 && !on[c]) continue;  // (an odd chain count's last workgroup row: one chain's products only)
+                const double z0 = y0[t] * ww[c][t], z1 = y1[t] * ww[c][t];
+                acc[c][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[t], z0, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[t], z1, acc[c][1], 0, 0, 0);
+                if (!diag) acc[c][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[t], z0, acc[c][2], 0, 0, 0);  // (a diagonal block's lower-left tile is the transpose of its upper-right one)
+                acc[c][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[t], z1, acc[c][3], 0, 0, 0);
             }
         }
+    };
+    // Round 4: on this device an f64 MFMA and the vector ALU's other instructions do not overlap (tools/mfma_f64_peak.hip:
+    // 78 TFLOP/s with nothing else in the loop, 63 with 16 v_add_u32 per four MFMAs) -- and this loop had ~80 vector
+    // instructions per 16 MFMAs: 64-bit address arithmetic, bounds selects, the copies from the next batch's registers into
+    // the current one's (the matrix pipes were busy 69 % of the time).  Now: the full batches in pairs, the two register sets
+    // taking turns (no copy); every load as uniform base + 32-bit byte offset, one v_add_u32 per slice and batch; no bounds
+    // test (full batches).  Batches in the same ascending order: the same bits.  The rest goes through the checked loop below.
+    const char *Ka = reinterpret_cast<const char *>(a.K + (size_t)ba * 32), *Kb = reinterpret_cast<const char *>(a.K + (size_t)bc * 32);
+    const unsigned row_bytes = (unsigned)a.ldk * 8u;
+    int nfull = 0;
+    while (site_of(nfull) + 4 * NB <= a.n) ++nfull;
+    const int npairs = nfull / 2;
+    int b = 2 * npairs;
+    if (npairs > 0) {
+        unsigned kx[NB], ky[NB], wx[NB], wy[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const unsigned ix = (unsigned)(site_of(0) + 4 * t + lk), iy = (unsigned)(site_of(1) + 4 * t + lk);
+            kx[t] = ix * row_bytes + (unsigned)lc * 8u;
+            ky[t] = iy * row_bytes + (unsigned)lc * 8u;
+            wx[t] = ix * 8u;
+            wy[t] = iy * 8u;
+        }
+        const unsigned kstep = (unsigned)(site_of(2) - site_of(0)) * row_bytes, wstep = (unsigned)(site_of(2) - site_of(0)) * 8u;
+        auto loadf = [&](unsigned (&ko)[NB], unsigned (&wo)[NB], double (&x0)[NB], double (&x1)[NB], double (&y0)[NB], double (&y1)[NB], double (&ww)[NC][NB]) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                x0[t] = *reinterpret_cast<const double *>(Ka + ko[t]);
+                x1[t] = *reinterpret_cast<const double *>(Ka + ko[t] + 128);
+                y0[t] = *reinterpret_cast<const double *>(Kb + ko[t]);
+                y1[t] = *reinterpret_cast<const double *>(Kb + ko[t] + 128);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ww[c][t] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(om[c]) + wo[t]);
+                ko[t] += kstep;
+                wo[t] += wstep;
+            }
+        };
+        loadf(kx, wx, a0, a1, b0, b1, w);
+        for (int k = 0; k + 1 < npairs; ++k) {
+            loadf(ky, wy, na0, na1, nb0, nb1, nw);
+            mm(a0, a1, b0, b1, w);
+            loadf(kx, wx, a0, a1, b0, b1, w);
+            mm(na0, na1, nb0, nb1, nw);
+        }
+        loadf(ky, wy, na0, na1, nb0, nb1, nw);
+        mm(a0, a1, b0, b1, w);
+        mm(na0, na1, nb0, nb1, nw);
+    }
+    if (site_of(b) < a.n) load(site_of(b), a0, a1, b0, b1, w);
+    for (; site_of(b) < a.n; ++b) {  // what is left: at most one full batch and a partial one
+        if (site_of(b + 1) < a.n) load(site_of(b + 1), na0, na1, nb0, nb1, nw);
+        mm(a0, a1, b0, b1, w);
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
             a0[t] = na0[t]; a1[t] = na1[t]; b0[t] = nb0[t]; b1[t] = nb1[t];
@@ -309,16 +360,16 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram32(const RsrArgs a,
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) s_g32[(((size_t)tile * GRAM_WAVES + wave) * 64 + lane) * 4 + v] = acc[c][tile][v];
+            for (int v = 0; v < 4; ++v) s_g32[(((size_t)tile * WV + wave) * 64 + lane) * 4 + v] = acc[c][tile][v];
         __syncthreads();
         if (on[c] && wave < 4 && !(diag && wave == 2)) {
             const int ra = ba * 32 + (wave >> 1) * 16, rc = bc * 32 + (wave & 1) * 16;  // tile `wave`: rows ra.., columns rc..
             double *G = a.gram + (size_t)(chain0 + c) * a.m * a.m;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                double t = s_g32[(((size_t)wave * GRAM_WAVES + 0) * 64 + lane) * 4 + v];
+                double t = s_g32[(((size_t)wave * WV + 0) * 64 + lane) * 4 + v];
 #pragma unroll
-                for (int ww = 1; ww < GRAM_WAVES; ++ww) t += s_g32[(((size_t)wave * GRAM_WAVES + ww) * 64 + lane) * 4 + v];  // fixed order
+                for (int ww = 1; ww < WV; ++ww) t += s_g32[(((size_t)wave * WV + ww) * 64 + lane) * 4 + v];  // fixed order
                 const int r = ra + 4 * v + lk, cidx = rc + lc;
                 if (r < a.m && cidx < a.m) G[(size_t)r * a.m + cidx] = t;
             }
@@ -330,7 +381,8 @@ __host__ __device__ inline int rsr_gram32_blocks(int m)
     const int T2 = (m + 31) / 32;
     return T2 * (T2 + 1) / 2;
 }
-constexpr size_t RSR_GRAM32_LDS = (size_t)4 * GRAM_WAVES * 64 * 4 * sizeof(double);
+constexpr int GRAM32_WAVES = 8;  // waves per workgroup of k_rsr_gram32: two workgroups per CU, one's epilogue beside the other's loop (16: 1.25 against 1.20 ms)
+__host__ __device__ constexpr size_t rsr_gram32_lds(int wv) { return (size_t)4 * wv * 64 * 4 * sizeof(double); }
 
 // Row stride of the Cholesky factor in LDS: odd, so that a column walk (one row per lane) touches every bank once.
 __host__ __device__ inline int rsr_ld(int m) { return 16 * ((m + 15) / 16) + 1; }
@@ -680,6 +732,80 @@ __global__ void __launch_bounds__(256) k_rsr_eta_beta(const RsrArgs a, OCC_KARGS
 // is not the small path's (the two agree to rounding, like the oracle).  Plain kernels: at m = 1 280 the conditional is
 // ~10^9 flops of Cholesky per chain and iteration beside a 2 10^10-flop Gram matrix -- milliseconds where the
 // reference's host code takes seconds -- and not the path BASELINE's metric is quoted on.
+// K'u for large bases (round 4).  k_rsr_gram's K'u workgroups each form u for themselves and push K through MFMAs whose B
+// operand has one non-zero column, chain by chain: 80 workgroups per chain, 0.1 ms at m = 1 280.  Here: u once per chain
+// (k_rsrb_u), then one workgroup per basis column takes that column -- a contiguous row of the transposed copy of K -- once
+// for FOUR chains (k_rsrb_ktu).  Sums in a fixed order: a thread's sites ascending, the 64 lanes (wave_sum), the four waves.
+__global__ void __launch_bounds__(256) k_rsrb_u(const RsrArgs a, int e, int sync_on)
+{
+    __shared__ int s_noise_ok;
+    const int chain = blockIdx.y, i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const ChainScalars &sc = a.scs[chain];
+    const Ctl ctl = sc.ctl[e];
+    if (ctl.koff || ctl.it >= sc.it_stop) return;
+    if (sync_on && a.sync != nullptr) {  // the noise of this iteration comes from the side stream's previous sequence
+        if (threadIdx.x == 0) s_noise_ok = sync_wait(a.sync, SYNC_NOISE, a.sync[SYNC_MAIN_SEQ + e]) ? 1 : 0;
+        __syncthreads();
+        if (!s_noise_ok) {
+            if (threadIdx.x == 0) a.scs[chain].err = -2;  // OCC_E_HIP: the side stream never arrived
+            return;
+        }
+    }
+    if (i >= a.n) return;
+    const size_t ci = (size_t)chain * a.n + i;
+    const double w = a.omega_b[ctl.it & 1][ci], ev = a.enorm[ctl.it & 1][ci], zv = (double)a.z[ci];
+    double xb = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const double x = a.Xt[(size_t)min(j, a.p - 1) * a.n + i], b = (j < a.p) ? sc.beta[min(j, a.p - 1)] : 0.0;
+        xb = fma(x, b, xb);
+    }
+    a.big_u[ci] = fma(sqrt(w), ev, fma(-w, xb, zv - 0.5));
+}
+__global__ void __launch_bounds__(256) k_rsrb_ktu(const RsrArgs a, int e)
+{
+    __shared__ double s_p[4][4];
+    const int col = blockIdx.x, chain0 = (int)blockIdx.y * 4, tid = threadIdx.x, n = a.n;
+    bool on[4];
+    const double *u[4];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int chain = min(chain0 + c, a.C - 1);
+        const ChainScalars &sc = a.scs[chain];
+        const Ctl ctl = sc.ctl[e];
+        on[c] = chain0 + c < a.C && !(ctl.koff || ctl.it >= sc.it_stop) && sc.err == 0;
+        u[c] = a.big_u + (size_t)chain * n;
+        any = any || on[c];
+    }
+    if (!any) return;
+    const double *kr = a.Kt + (size_t)col * n;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int UB = 4;
+    for (int i0 = tid; i0 < n; i0 += 256 * UB) {
+        double kv[UB], uv[4][UB];
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+            const int i = min(i0 + 256 * b, n - 1);
+            kv[b] = (i0 + 256 * b < n) ? kr[i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) uv[c][b] = u[c][i];
+        }
+#pragma unroll
+        for (int b = 0; b < UB; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fma(kv[b], uv[c][b], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double sm = wave_sum(acc[c]);
+        if ((tid & 63) == 0) s_p[tid >> 6][c] = sm;
+    }
+    __syncthreads();
+    const unsigned onm = (on[0] ? 1u : 0u) | (on[1] ? 2u : 0u) | (on[2] ? 4u : 0u) | (on[3] ? 8u : 0u);
+    if (tid < 4 && ((onm >> tid) & 1u)) a.rhs[(size_t)(chain0 + tid) * a.nchunk * a.m + col] = ((s_p[0][tid] + s_p[1][tid]) + s_p[2][tid]) + s_p[3][tid];
+}
+
 // theta' Qr theta in slices of 64 rows (a workgroup of 16 waves, four rows per wave, columns over the lanes), one partial
 // per workgroup; the noise of the prior term for those rows.  (Round 2: one workgroup per chain read all of Qr, 13 MB at
 // m = 1 280: 0.56 ms.)
