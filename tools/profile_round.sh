@@ -69,7 +69,7 @@ if has rsrb; then
 # 4b. ... and with the reference's default threshold at 100x100: 1 280 basis columns, the device-memory solve (k_rsrb_*)
 run rocprofv3 --kernel-trace --stats --output-format csv -d $out/rsrb_stats -- python3 tools/rsr_time.py 100 100 1280 4 100 > $out/rsrb.log 2> $out/rsrb_stats.log
 cp "$(ls -t $out/rsrb_stats/*/*kernel_stats.csv | head -n 1)" profiles/${tag}_rsrb_kernel_stats.csv
-tail -n 1 $out/rsrb.log > profiles/${tag}_rsrb_bench.txt
+{ echo "under rocprofv3 --kernel-trace:"; tail -n 1 $out/rsrb.log; echo "not profiled:"; python3 tools/rsr_time.py 100 100 1280 4 100 | tail -n 1; python3 tools/rsr_time.py 100 100 1280 3 100 | tail -n 1; } > profiles/${tag}_rsrb_bench.txt
 fi
 if has sizes; then
 # 5. other sizes and paths, one line each (chain-iterations/s; which path every case takes)
