@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64 * WV, 4) k_rsr_gram32(const RsrArgs a, int 
     const unsigned row_bytes = (unsigned)a.ldk * 8u;
     int nfull = 0;
     while (site_of(nfull) + 4 * NB <= a.n) ++nfull;
-    const int npairs = nfull / 2;
+    const int npairs = ((unsigned long long)a.n * a.ldk * 8ull < (1ull << 32)) ? nfull / 2 : 0;  // (32-bit byte offsets; else everything through the checked loop)
     int b = 2 * npairs;
     if (npairs > 0) {
         unsigned kx[NB], ky[NB], wx[NB], wy[NB];
