@@ -672,22 +672,24 @@ def test_reduced_rank_large_basis_matches_oracle(oracle, q):
         for name in ('alpha', 'beta', 'tau', 'theta', 'z'):
             eng.set(name, orc.get(name))
     eng.close()
-    keys = [KEY + c for c in range(2)]
-    starts = [dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.0 + c, eta=0.3 * rng.standard_normal(m)) for c in range(2)]
+    # three chains: a full pair of k_rsr_gram32's and a half-empty one; each of chains 1 and 2 alone gives the same bits
+    keys = [KEY + c for c in range(3)]
+    starts = [dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.0 + c, eta=0.3 * rng.standard_normal(m)) for c in range(3)]
     batch = Engine(prob, keys)
-    for c in range(2):
+    for c in range(3):
         batch.set_start(c, **starts[c])
     A, B, T = batch.run(9, 1)
-    solo = Engine(prob, [keys[1]])
-    solo.set_start(0, **starts[1])
-    for i in range(9):
-        solo.step()
-        if i >= 1:
-            assert np.array_equal(solo.get('alpha'), A[1, i - 1]) and np.array_equal(solo.get('beta'), B[1, i - 1]) and solo.get('tau') == T[1, i - 1]
-    assert np.array_equal(solo.get('theta'), batch.get('theta', 1))
+    for ch in (1, 2):
+        solo = Engine(prob, [keys[ch]])
+        solo.set_start(0, **starts[ch])
+        for i in range(9):
+            solo.step()
+            if i >= 1:
+                assert np.array_equal(solo.get('alpha'), A[ch, i - 1]) and np.array_equal(solo.get('beta'), B[ch, i - 1]) and solo.get('tau') == T[ch, i - 1]
+        assert np.array_equal(solo.get('theta'), batch.get('theta', ch))
+        solo.close()
     assert abs(batch.get('eta', 0) - prob.rsr['K'] @ batch.get('theta', 0)).max() < 1e-11
     batch.close()
-    solo.close()
 
 
 @pytest.mark.parametrize('env', [{}, {'OCC_CU_SPLIT': '0'}, {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EVENT_SYNC': '1'}, {'OCC_DEBUG_STREAMS_SERIALISED': '1'}],
