@@ -111,6 +111,59 @@ static void run_int(int wgs, int threads, int iters, double *d)
     const double flop = (double)wgs * (threads / 64) * iters * 8 * 2048.0;
     std::printf("%4d workgroups x %4d threads, groups of 4 MFMAs, %2d v_add_u32 per group: %8.3f ms, %6.1f TFLOP/s\n", wgs, threads, NI, ms, flop / ms * 1e-9);
 }
+// ... and with NL global loads (8 bytes per lane, L1-resident lines) per group of four MFMAs, their values feeding the next group
+template <int NL, int WIDE>
+__global__ void __launch_bounds__(1024) k_ld(double *out, const double *src, int iters, double x)
+{
+    v4d acc[8];
+    for (int q = 0; q < 8; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+    double a0 = x + threadIdx.x, a1 = x * 2, b0 = x - threadIdx.x, b1 = x * 3;
+    const char *base = reinterpret_cast<const char *>(src);
+    unsigned off = (threadIdx.x & 63) * (WIDE ? 16u : 8u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            double v[NL > 0 ? NL : 1];
+            if (WIDE) {
+#pragma unroll
+                for (int k = 0; k < NL; k += 2) {
+                    typedef double v2 __attribute__((ext_vector_type(2)));
+                    const v2 t = *reinterpret_cast<const v2 *>(base + off + 1024 * k);
+                    v[k] = t[0]; v[k + 1] = t[1];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NL; ++k) v[k] = *reinterpret_cast<const double *>(base + off + 512 * k);
+            }
+            acc[4 * g + 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[4 * g + 0], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[4 * g + 3], 0, 0, 0);
+            if (NL > 0) { a0 = v[0]; b0 = v[NL - 1]; }
+            if (NL > 2) { a1 = v[1]; b1 = v[NL - 2]; }
+        }
+    }
+    double s = 0.0;
+    for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (s == 12345.678) out[0] = s;
+}
+template <int NL, int WIDE>
+static void run_ld(int wgs, int threads, int iters, double *d, const double *src)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_ld<NL, WIDE>), dim3(wgs), dim3(threads), 0, 0, d, src, 10, 0.5);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_ld<NL, WIDE>), dim3(wgs), dim3(threads), 0, 0, d, src, iters, 0.5);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)wgs * (threads / 64) * iters * 8 * 2048.0;
+    std::printf("%4d workgroups x %4d threads, groups of 4 MFMAs, %d doubles per lane loaded per group by %s: %8.3f ms, %6.1f TFLOP/s\n", wgs, threads, NL,
+                WIDE ? "global_load_dwordx4" : "global_load_dwordx2", ms, flop / ms * 1e-9);
+}
 template <int NACC>
 static void run(int wgs, int threads, int iters, double *d)
 {
@@ -131,6 +184,9 @@ int main()
 {
     double *d;
     hipMalloc(&d, 64);
+    double *src;
+    hipMalloc(&src, 1 << 16);
+    hipMemset(src, 0, 1 << 16);
     for (int rep = 0; rep < 1; ++rep) {
         run<8>(256, 1024, 20000, d);   // 4 waves per SIMD
         run<8>(512, 512, 20000, d);    // 4 waves per SIMD, two workgroups per CU
@@ -138,6 +194,11 @@ int main()
         run<4>(256, 1024, 40000, d);
         run<1>(256, 1024, 160000, d);  // one accumulator: every MFMA waits for the one before
         run<8>(2560, 1024, 2000, d);   // ten rounds of workgroups
+        run_ld<4, 0>(256, 1024, 20000, d, src);
+        run_ld<6, 0>(256, 1024, 20000, d, src);
+        run_ld<4, 1>(256, 1024, 20000, d, src);
+        run_ld<8, 0>(256, 1024, 20000, d, src);
+        run_ld<8, 1>(256, 1024, 20000, d, src);
         run_int<4>(256, 1024, 20000, d);
         run_int<8>(256, 1024, 20000, d);
         run_int<16>(256, 1024, 20000, d);
