@@ -66,7 +66,7 @@ typedef struct occ_problem {
     double tau_rate, tau_shape;
     /* Reduced-rank model (LogitRSRGibbs, logit.py:269-485), optional: rsr_dim = m > 0 selects it.  The spatial
      * effects are eta = K theta with K the n x m Moran-operator basis the host computed (logit.py:413-446);
-     * rsr_Q = K'QK (m x m), rsr_E its eigenfactor, E E' = K'QK (logit.py:321-323); all row-major; m <= 2048 (up to 128 the
+     * rsr_Q = K'QK (m x m), rsr_E its eigenfactor, E E' = K'QK (logit.py:321-323); all row-major; m <= 4096 (up to 128 the
      * system is solved in LDS and registers, beyond that panel by panel in device memory). */
     int32_t rsr_dim;
     const double *rsr_K, *rsr_Q, *rsr_E;

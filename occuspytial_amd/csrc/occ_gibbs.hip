@@ -1306,7 +1306,7 @@ static int build_layout(occ_sampler *s, const occ_problem *pb, HostLayout &L)
         return set_error(s, OCC_E_BADARG, "p and q must lie in [1, 32]");
     if (pb->rsr_dim > 0 && (pb->p > MAXC || pb->q > MAXC)) return set_error(s, OCC_E_BADARG, "the reduced-rank model takes at most 8 covariates of each kind");
     if (pb->rsr_dim < 0 || pb->rsr_dim > RSR_BIG_MAX || (pb->rsr_dim > 0 && (!pb->rsr_K || !pb->rsr_Q || !pb->rsr_E)))
-        return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 2048 columns (rsr_K, rsr_Q, rsr_E)");
+        return set_error(s, OCC_E_BADARG, "the reduced-rank basis needs 1 to 4096 columns (rsr_K, rsr_Q, rsr_E)");
     if (!(pb->tau_rate > 0.0) || !(pb->tau_shape > 0.0)) return set_error(s, OCC_E_BADARG, "tau_rate and tau_shape must be positive");
     const int n = (int)pb->n, S = (int)pb->n_surveyed, R = (int)pb->n_rows, p = pb->p, q = pb->q;
     L.n = n; L.S = S; L.R = R; L.p = p; L.q = q; L.rsr_dim = pb->rsr_dim;

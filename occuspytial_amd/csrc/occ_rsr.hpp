@@ -22,7 +22,7 @@
 namespace occ {
 
 constexpr int RSR_MAX_DIM = 128;  // m x m doubles of LDS for the Cholesky factor: 128 KB of the CU's 160 KB
-constexpr int RSR_BIG_MAX = 2048; // beyond RSR_MAX_DIM: the factor lives in global memory, factorised panel by panel (k_rsrb_*)
+constexpr int RSR_BIG_MAX = 4096; // (what the reference's own dense n x n set-up reaches: 13 % of 31 000 sites) beyond RSR_MAX_DIM: the factor lives in global memory, factorised panel by panel (k_rsrb_*)
 constexpr int RSR_PANEL = 32;     // ... columns per panel
 constexpr uint32_t STREAM_RSR = 9;
 

@@ -219,7 +219,7 @@ class LogitRSRGibbs(LogitICARGibbs):
     ``tau_shape`` becomes ``0.5 + 0.5 q`` -- all as in the reference.  The basis is computed on the host with dense
     n x n linear algebra, once (as the reference does); per iteration the device forms
     :math:`K^\top\Omega K + \tau K^\top QK` and solves the q x q system (``csrc/occ_rsr.hpp``: in LDS and registers up to
-    128 basis columns, panel by panel in device memory up to 2048 -- the reference's default threshold keeps about 13 % of a
+    128 basis columns, panel by panel in device memory up to 4096 -- the reference's default threshold keeps about 13 % of a
     lattice's sites: 1 280 columns at 100x100).  ``device`` selects the HIP device.
     """
 
@@ -229,8 +229,8 @@ class LogitRSRGibbs(LogitICARGibbs):
 
     def _configure_rsr(self, r, q, hparams):
         rsr = self._problem.enable_rsr(r=r, q=q, default_tau_shape=not hparams)
-        if rsr['dim'] > 2048:
-            raise ValueError(f'{rsr["dim"]} basis columns selected; the device path supports at most 2048 '
+        if rsr['dim'] > 4096:
+            raise ValueError(f'{rsr["dim"]} basis columns selected; the device path supports at most 4096 '
                              '(raise the threshold `r` or pass `q`)')
         fixed = self.fixed
         fixed.q = rsr['dim']

@@ -196,7 +196,7 @@ def test_reduced_rank_default_threshold_keeps_more_than_128_columns():
     Q, W, X, y, *_ = make_lattice_problem(40, 40, visits=3, p=2, q=2, random_state=3)
     s = LogitRSRGibbs(Q, W, X, y, random_state=4)
     m = s.fixed.q
-    assert 150 < m <= 2048 and s.fixed.K.shape == (1600, m)
+    assert 150 < m <= 4096 and s.fixed.K.shape == (1600, m)
     out = s.sample(12, burnin=2, chains=2, progressbar=False)
     assert out['alpha'].shape == (2, 10, 2) and out['beta'].shape == (2, 10, 2) and out['tau'].shape == (2, 10)
     assert np.all(np.isfinite(out['beta'])) and np.all(out['tau'] > 0) and not np.allclose(out['tau'][0], out['tau'][1])

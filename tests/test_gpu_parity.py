@@ -692,6 +692,33 @@ def test_reduced_rank_large_basis_matches_oracle(oracle, q):
     batch.close()
 
 
+def test_reduced_rank_basis_of_more_than_2048_columns(oracle):
+    """The basis may have up to 4 096 columns (what the reference's own dense n x n set-up can reach: its default threshold
+    keeps 13 % of the sites): 2 100 columns on a 50 x 50 lattice, two iterations in lock step with the oracle."""
+    from occuspytial_amd._engine import Engine
+    from occuspytial_amd._problem import FlatProblem
+    from occuspytial_amd.utils import make_lattice_problem
+    Q, W, X, y, *_ = make_lattice_problem(50, 50, visits=2, p=2, q=2, random_state=6)
+    prob = FlatProblem(Q, W, X, y)
+    m = prob.enable_rsr(q=2100)['dim']
+    assert m == 2100
+    rng = np.random.default_rng(11)
+    start = dict(alpha=rng.standard_normal(2), beta=rng.standard_normal(2), tau=1.5, eta=0.1 * rng.standard_normal(m))
+    eng = Engine(prob, [KEY])
+    orc = oracle.OracleSampler(prob, KEY)
+    eng.set_start(0, **start)
+    orc.set_start(**start)
+    for it in range(2):
+        eng.step()
+        orc.step()
+        for name, tol in (('tau', 1e-11), ('theta', 1e-8), ('eta', 1e-8), ('beta', 1e-8), ('alpha', 1e-9)):
+            assert _rel(eng.get(name), orc.get(name)) < tol, (it, name, _rel(eng.get(name), orc.get(name)))
+        assert np.array_equal(eng.get('z'), orc.get('z'))
+        for name in ('alpha', 'beta', 'tau', 'theta', 'z'):
+            eng.set(name, orc.get(name))
+    eng.close()
+
+
 @pytest.mark.parametrize('env', [{}, {'OCC_CU_SPLIT': '0'}, {'OCC_NO_SIDE_STREAM': '1'}, {'OCC_EVENT_SYNC': '1'}, {'OCC_DEBUG_STREAMS_SERIALISED': '1'}],
                          ids=['two-streams-flag-handovers', 'no-cu-partition', 'one-stream', 'no-flag-handovers', 'stream-probe-says-serialised'])
 def test_reduced_rank_graph_replay_equals_stepping_and_batching(monkeypatch, env):
