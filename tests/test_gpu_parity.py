@@ -193,8 +193,8 @@ def test_calls_with_different_windows_steps_and_reads_between_them_equal_one_run
     the device, by the kernel that snapshots the state (round 3: no copy engine between a call's entry and its first kernel),
     or by an upload when the call cannot take that way (occ_step; a call after something else touched the state).  The
     recorded rows come back through page-locked staging that grows between calls.  A run cut into calls of different
-    lengths and burn-ins, with single steps and state reads in between, must leave the chains where ONE run leaves them and
-    return the same rows."""
+    lengths and burn-ins, with single steps, state reads, state writes and checkpoint / restore round trips in between, must
+    leave the chains where ONE run leaves them and return the same rows."""
     from occuspytial_amd._engine import Engine
     from occuspytial_amd._problem import FlatProblem
     from occuspytial_amd.utils import make_lattice_problem
@@ -209,7 +209,10 @@ def test_calls_with_different_windows_steps_and_reads_between_them_equal_one_run
         cut.set_start(c, **starts[c])
     A, B, T = one.run(61, 0)
     rows = []
-    plan = [('run', 2, 0), ('run', 7, 3), ('step',), ('run', 1, 0), ('get',), ('run', 30, 29), ('step',), ('step',), ('run', 18, 5)]
+    # ('set',): a state write between calls (the value it already has: the host's mirror of the chains' scalars is void after
+    # it); ('ckpt',): checkpoint and restore (every chain's state leaves and re-enters the device)
+    plan = [('run', 2, 0), ('set',), ('run', 7, 3), ('step',), ('ckpt',), ('run', 1, 0), ('get',), ('run', 30, 29), ('set',), ('step',),
+            ('step',), ('ckpt',), ('run', 18, 5)]
     for item in plan:
         if item[0] == 'run':
             a, b, t = cut.run(item[1], item[2])
@@ -217,6 +220,12 @@ def test_calls_with_different_windows_steps_and_reads_between_them_equal_one_run
         elif item[0] == 'step':
             cut.step()
             rows.append((1, 1, None, None, None))
+        elif item[0] == 'set':
+            for c in (1, 3):
+                cut.set('alpha', cut.get('alpha', c), c)
+                cut.set('tau', cut.get('tau', c), c)
+        elif item[0] == 'ckpt':
+            cut.restore(cut.checkpoint())
         else:
             assert np.all(np.isfinite(cut.get('eta', 2)))
     assert sum(r[0] for r in rows) == 61
