@@ -216,17 +216,16 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) k_rsr_gram(const RsrArgs a, i
 }
 
 // ---- the Gram matrix for LARGE bases (m > RSR_MAX_DIM): 32 x 32 output blocks ---------------------------------------------
-// k_rsr_gram above reads 2 x 16 columns of K per v_mfma_f64_16x16x4_f64: 2 flop per byte from the L2, exactly the ratio of a
-// CU's L2 path (64 B/clk) to its f64 matrix rate (128 flop/clk) -- at m = 1 280 it ran at 36 % of the matrix peak with the
-// miss path saturated (3 240 workgroups per chain, each pulling 2 x 1.25 MB of K).  Here a workgroup owns a 32 x 32 block
-// of G's upper triangle: per four sites a wave loads 2 x 2 x 16 columns and issues FOUR MFMAs (three on a diagonal block,
-// whose lower-left tile is the transpose of its upper-right one) -- twice the flop per byte, a quarter of the workgroups.
-// Same operands, same instruction order per output element, the 16 partial tiles of a tile added in wave order: the bits of
-// k_rsr_gram.  K's rows are padded to a multiple of 32 columns (zeros).  Dynamic LDS: [4 tiles][16 waves][64 lanes][4] doubles.
+// k_rsr_gram above forms one 16 x 16 tile per workgroup (2 x 16 columns of K per MFMA); at m = 1 280 that is 3 240
+// workgroups per chain, each pulling 2 x 1.25 MB of K, and it ran at 36 % of the matrix peak.  Here a workgroup owns a
+// 32 x 32 block of G's upper triangle: per four sites a wave loads 2 x 2 x 16 columns and issues FOUR MFMAs (three on a
+// diagonal block, whose lower-left tile is the transpose of its upper-right one) -- twice the flop per byte, a quarter of the
+// workgroups.  Same operands, same instruction order per output element, a tile's WV partial tiles added in wave order.  K's
+// rows are padded to a multiple of 32 columns (zeros).  Dynamic LDS: [4 tiles][WV waves][64 lanes][4] doubles.
 // NC chains per workgroup (grid.y = ceil(C / NC)): K's columns are loaded ONCE for the NC chains and weighted by each chain's
-// omega where they are used -- the kernel streams 2 x 32 columns of K (5 MB at n = 10 000) per workgroup through the Infinity
-// Cache, 16.8 GB per iteration at m = 1 280 with four chains: bound by that stream (7.7 TB/s), not by the matrix cores.  The
-// products row[cc] * w are the ones the one-chain form takes, in the same order per output element: the same bits.
+// omega where they are used.  The products row[cc] * w are the ones the one-chain form takes, in the same order per output
+// element: the same bits whether a chain runs alone or beside others (both forms with WV = GRAM32_WAVES).
+// What bounds it is neither K's stream nor the matrix pipes' peak but the vector instructions beside the MFMAs (see the loop).
 template <int NC, int WV>
 __global__ void __launch_bounds__(64 * WV, 4) k_rsr_gram32(const RsrArgs a, int e, int sync_on)
 {
